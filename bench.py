@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd frames/s of the rasterizer hot path at 1080p on 1 M synthetic Gaussians
+(BASELINE.json metric), one process per GPU.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one view: GaussianRasterizer forward + backward through the C ABI (preprocess, key
+generation, radix sort, tile ranges, compositing, compositing backward, preprocess backward),
+inputs resident in HBM.  With N > 1 every rank renders a different view of the same replicated
+Gaussians and the step ends with one RCCL all-reduce of the flat 59*P-float gradient bucket
+(per-view data parallelism); value = N views / max-over-ranks step time.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "hierarchical-3d-gaussians_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(P, V, L, N, T, M, depth=True):
+    """SURVEY.md §8(d) byte model, per stage, for the measured P (Gaussians), V (visible), L (tile
+    instances), N (pixels), T (tiles), M (SH coefficients).  Each boundary tensor is counted once
+    read / once written; irreducible intermediates once written + once read; the sort as one pass."""
+    rec, inst = 48, 48
+    ch = 4 if depth else 3
+    b = {}
+    b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P
+    b["scan"] = 8 * (P // 256 + 1)
+    b["duplicate_keys"] = 16 * P + 12 * L
+    b["radix_sort"] = 24 * L
+    b["tile_ranges"] = 8 * L + 8 * T
+    b["render_fwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N + 8 * N
+    b["memset_bwd"] = inst * L
+    b["render_bwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N * 2 + inst * L
+    b["preprocess_bwd"] = inst * L + P * 44 + V * 12 * M + 12 * P + P * (56 + 12 * M)
+    return b
+
+
+def cpu_baseline(scene, cam, bg, gc, gd, L_total, seed=3, n_tiles=64):
+    """Naive PyTorch-CPU per-pixel alpha blend (= the oracle, float32) timed on the host cores on a
+    bounded sample: the per-Gaussian stage for the whole scene + dense blending fwd+bwd of `n_tiles`
+    randomly chosen tiles; the blend time is scaled by tile-instance count to a full frame."""
+    import numpy as np
+    from oracle import raster_oracle as ro
+    torch.set_num_threads(os.cpu_count() or 1)
+    kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+              bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+              sh_degree=scene.sh_degree, campos=cam.camera_center, dtype=torch.float32)
+
+    def run(tiles):
+        req = lambda t: t.clone().requires_grad_(True)
+        m3, sc, rot, op, sh = map(req, (scene.means3D, scene.scales, scene.rotations, scene.opacities, scene.shs))
+        m2 = torch.zeros(scene.P, 3, requires_grad=True)
+        t0 = time.perf_counter()
+        out = ro.rasterize(m3, m2, sh, None, op, sc, rot, None, tiles=tiles, **kw)
+        loss = (out.color * gc).sum() + (out.invdepth * gd).sum()
+        loss.backward()
+        return time.perf_counter() - t0, out
+
+    T = ((cam.image_width + 15) // 16) * ((cam.image_height + 15) // 16)
+    rng = np.random.default_rng(seed)
+    tiles = rng.choice(T, size=min(n_tiles, T), replace=False).tolist()
+    small = sorted(tiles[:max(1, len(tiles) // 4)])
+    tiles = sorted(tiles)
+    # two sample sizes -> t = a + b * instances: a = per-Gaussian stage (fwd+bwd, whole scene),
+    # b = blend cost per tile instance
+    t1, out1 = run(small)
+    t2, out2 = run(tiles)
+    rg = out2.binning.ranges
+    L1 = int((rg[small, 1] - rg[small, 0]).sum())
+    L2 = int((rg[tiles, 1] - rg[tiles, 0]).sum())
+    b = max((t2 - t1) / max(L2 - L1, 1), 0.0)
+    a = max(t1 - b * L1, 0.0)
+    t_frame = a + b * L_total
+    return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": f"oracle (naive PyTorch-CPU dense per-pixel blend, float32, {torch.get_num_threads()} threads): "
+                      f"fwd+bwd of the per-Gaussian stage for the whole scene plus {len(small)} and {len(tiles)} "
+                      f"of {T} tiles ({L1} / {L2} of {L_total} tile instances) in {t1:.2f} s / {t2:.2f} s; "
+                      f"linear fit {a:.2f} s + {b * 1e6:.3f} us/instance extrapolated to the full frame"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-timing", action="store_true")
+    args = ap.parse_args()
+
+    from hgs import _lib, dp, synth
+    import diff_gaussian_rasterization as dgr
+
+    rank, local, world = dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path (see oracle/ for the checker)")
+    if _lib.lib().hgs_device_count() < 1:
+        raise SystemExit("libhgs.so sees no HIP device")
+    dev = torch.device("cuda", local if torch.cuda.device_count() > local else 0)
+    torch.cuda.set_device(dev)
+    W, H, P = args.width, args.height, args.gaussians
+
+    base_cam = synth.make_camera(W, H)
+    scene_cpu = synth.make_scene(P, base_cam, seed=0)            # same Gaussians on every rank
+    cam_cpu = base_cam if world == 1 else synth.orbit_camera(W, H, rank, world)
+    gc_cpu, gd_cpu = synth.upstream_grads(H, W, seed=1)
+    bg_cpu = torch.zeros(3)
+    scene, cam = scene_cpu.to(dev), cam_cpu.to(dev)
+    gc, gd, bg = gc_cpu.to(dev), gd_cpu.to(dev), bg_cpu.to(dev)
+    e_i = torch.empty(0, dtype=torch.int32, device=dev)
+    e_f = torch.empty(0, dtype=torch.float32, device=dev)
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree,
+        campos=cam.camera_center, prefiltered=False, debug=False, do_depth=True, render_indices=e_i,
+        parent_indices=e_i, interpolation_weights=e_f, num_node_kids=e_i)
+    rast = dgr.GaussianRasterizer(rs)
+    dgr._RasterizeGaussians.variant = args.variant
+    params = dict(means3D=scene.means3D, shs=scene.shs, opacities=scene.opacities, scales=scene.scales,
+                  rotations=scene.rotations)
+    for t in params.values():
+        t.requires_grad_(True)
+    means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
+    bucket = dp.GradBucket({k: tuple(v.shape) for k, v in params.items()}, dev) if world > 1 else None
+    info = {}
+
+    def step():
+        color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                  opacities=params["opacities"], scales=params["scales"],
+                                  rotations=params["rotations"])
+        info["L"] = color.grad_fn.num_rendered
+        info["radii"] = radii
+        grads = torch.autograd.grad([color, invd], [params[k] for k in params] + [means2D], [gc, gd])
+        if bucket is not None:
+            bucket.fill(dict(zip(params.keys(), grads)))
+            bucket.all_reduce()
+        return grads
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    timing = (not args.no_stage_timing)
+    barrier()
+    if timing:
+        _lib.timing_read(reset=True)
+        _lib.timing_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stages = {}
+    if timing:
+        _lib.timing_enable(False)
+        stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.timing_read(reset=True).items() if c}
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        L = int(info["L"])
+        V = int((info["radii"] > 0).sum().item())
+        N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), scene.shs.shape[1]
+        ab = algorithmic_bytes(P, V, L, N, T, M)
+        total_bytes = sum(ab.values())
+        result = {
+            "metric": "fwd+bwd frames/s @1080p, 1M Gaussians", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{P} frustum-filling synthetic Gaussians (SURVEY §8(d) spec, seed 0), "
+                                   f"{W}x{H}, SH degree 3, depth channel on, fwd+bwd through GaussianRasterizer",
+                       "gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H,
+                       "parallelism": f"per-view dp{world}" + (" + RCCL all-reduce of the 59P-float grad bucket" if world > 1 else ""),
+                       "render_variant": args.variant},
+            "algorithmic_bytes_per_frame": total_bytes,
+            "frame_hbm_frac": total_bytes * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
+        }
+        if stages:
+            dom = max(stages, key=stages.get)
+            achieved = ab[dom] / (stages[dom] * 1e-3) / 1e9
+            traffic = None
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc_path):
+                try:
+                    traffic = json.load(open(pmc_path)).get(dom)
+                except Exception:
+                    traffic = None
+            result["roofline"] = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                                  "avg_ms": stages[dom], "algorithmic_bytes": ab[dom],
+                                  "note": "compositing kernels are VALU/LDS-bound (gather/blend, no MFMA); "
+                                          "the HBM fraction is reported because the metric mandates it"}
+            result["stages_ms"] = stages
+            result["stages_gbs"] = {k: ab[k] / (v * 1e-3) / 1e9 for k, v in stages.items() if k in ab}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(scene_cpu, cam_cpu, bg_cpu, gc_cpu, gd_cpu, L)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count() or 1,
+                                          "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

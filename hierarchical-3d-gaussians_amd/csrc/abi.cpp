@@ -1,0 +1,279 @@
+// C ABI of libhgs.so (declared in include/hgs.h): argument validation, workspace
+// carving, stage sequencing.  No torch types; the Python host (or any FFI) owns memory.
+#include "common.h"
+
+#include <string.h>
+
+#include <mutex>
+#include <vector>
+
+namespace hgs {
+
+// ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
+enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+             ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
+                                            "render_fwd", "memset_bwd", "render_bwd", "preprocess_bwd"};
+struct Pending { int stage; hipEvent_t a, b; };
+static bool g_timing = false;
+static std::mutex g_tmu;
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static double g_ms[ST_COUNT];
+static uint32_t g_calls[ST_COUNT];
+
+struct StageTimer {
+  int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
+  StageTimer(int st, hipStream_t stream) : stage(st), s(stream), on(g_timing) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_tmu);
+    for (hipEvent_t* e : {&a, &b}) {
+      if (!g_pool.empty()) { *e = g_pool.back(); g_pool.pop_back(); }
+      else if (hipEventCreate(e) != hipSuccess) { on = false; return; }
+    }
+    (void)hipEventRecord(a, s);
+  }
+  ~StageTimer() {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lk(g_tmu);
+    g_pending.push_back({stage, a, b});
+  }
+};
+#define HGS_TIMED(stage, stream, expr) [&]() { hgs::StageTimer _t(stage, stream); return (expr); }()
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+size_t GeomWs::bytes(int32_t P) {
+  const size_t p = (size_t)(P > 0 ? P : 1);
+  const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
+  return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
+         align_up((nblk + 1) * 4) + kAlign;
+}
+GeomWs GeomWs::carve_from(void* base, int32_t P) {
+  const size_t p = (size_t)(P > 0 ? P : 1);
+  const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
+  char* c = static_cast<char*>(base);
+  GeomWs g;
+  g.records = carve<float>(c, p * kRecFloats);
+  g.depths = carve<float>(c, p);
+  g.rects = carve<uint32_t>(c, p * 2);
+  g.tiles_touched = carve<uint32_t>(c, p);
+  g.offsets = carve<uint32_t>(c, p);
+  g.flags = carve<uint32_t>(c, p);
+  g.block_sums = carve<uint32_t>(c, nblk + 1);
+  return g;
+}
+
+size_t BinWs::bytes(uint32_t L, int32_t T) {
+  const size_t l = L ? L : 1;
+  return 2 * align_up(l * 8) + 2 * align_up(l * 4) + align_up((size_t)T * 8) + sort_tmp_bytes(L ? L : 1) + kAlign;
+}
+BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
+  const size_t l = L ? L : 1;
+  char* c = static_cast<char*>(base);
+  BinWs b;
+  b.keys_in = carve<uint64_t>(c, l);
+  b.vals_in = carve<uint32_t>(c, l);
+  b.keys_out = carve<uint64_t>(c, l);
+  b.vals_out = carve<uint32_t>(c, l);
+  b.ranges = carve<uint32_t>(c, (size_t)T * 2);
+  b.sort_tmp = c;
+  return b;
+}
+
+size_t ImgWs::bytes(int32_t W, int32_t H) { return 2 * align_up((size_t)W * H * 4) + kAlign; }
+ImgWs ImgWs::carve_from(void* base, int32_t W, int32_t H) {
+  char* c = static_cast<char*>(base);
+  ImgWs im;
+  im.final_T = carve<float>(c, (size_t)W * H);
+  im.n_contrib = carve<uint32_t>(c, (size_t)W * H);
+  return im;
+}
+
+static int validate(const hgs_raster_args* a) {
+  if (!a) { set_error("null args"); return HGS_ERR_INVALID; }
+  if (a->P < 0 || a->width <= 0 || a->height <= 0) { set_error("bad sizes P=%d W=%d H=%d", a->P, a->width, a->height); return HGS_ERR_INVALID; }
+  if (grid_x(a->width) > 1023 || grid_y(a->height) > 1023) { set_error("image larger than 16368 px per side is not supported"); return HGS_ERR_INVALID; }
+  if (!a->bg || !a->viewmatrix || !a->projmatrix || !a->campos) { set_error("bg/viewmatrix/projmatrix/campos must be device pointers"); return HGS_ERR_INVALID; }
+  if (a->P > 0) {
+    if (!a->means3D || !a->opacities) { set_error("means3D/opacities missing"); return HGS_ERR_INVALID; }
+    if ((a->shs != nullptr) == (a->colors_precomp != nullptr)) { set_error("provide exactly one of shs / colors_precomp"); return HGS_ERR_INVALID; }
+    const bool sr = a->scales && a->rotations;
+    if (sr == (a->cov3D_precomp != nullptr) || ((a->scales != nullptr) != (a->rotations != nullptr))) {
+      set_error("provide exactly one of (scales, rotations) / cov3D_precomp");
+      return HGS_ERR_INVALID;
+    }
+    if (a->shs) {
+      if (a->sh_degree < 0 || a->sh_degree > 3) { set_error("sh_degree %d not in 0..3", a->sh_degree); return HGS_ERR_INVALID; }
+      if (a->M < (a->sh_degree + 1) * (a->sh_degree + 1) || a->M > 16) { set_error("M=%d incompatible with sh_degree=%d (max 16 coefficients)", a->M, a->sh_degree); return HGS_ERR_INVALID; }
+    }
+    if ((a->interpolation_weights != nullptr) != (a->num_node_kids != nullptr)) { set_error("interpolation_weights and num_node_kids must be given together"); return HGS_ERR_INVALID; }
+  }
+  return HGS_OK;
+}
+
+}  // namespace hgs
+
+using namespace hgs;
+
+extern "C" {
+
+int hgs_abi_version(void) { return HGS_ABI_VERSION; }
+const char* hgs_last_error(void) { return g_err; }
+int hgs_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return -1;
+  return n;
+}
+
+int hgs_raster_ws_sizes(int32_t P, int32_t width, int32_t height, uint32_t L, size_t* geom_bytes,
+                        size_t* bin_bytes, size_t* img_bytes, size_t* bwd_bytes) {
+  if (P < 0 || width <= 0 || height <= 0) { set_error("bad sizes"); return HGS_ERR_INVALID; }
+  const int T = grid_x(width) * grid_y(height);
+  if (geom_bytes) *geom_bytes = GeomWs::bytes(P);
+  if (bin_bytes) *bin_bytes = BinWs::bytes(L, T);
+  if (img_bytes) *img_bytes = ImgWs::bytes(width, height);
+  if (bwd_bytes) *bwd_bytes = align_up((size_t)(L ? L : 1) * kInstStride * 4) + kAlign;
+  return HGS_OK;
+}
+
+int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radii, uint32_t* L_out_host,
+                          hgs_stream_t stream, int device) {
+  int rc = validate(a);
+  if (rc) return rc;
+  if (!geom_ws || !L_out_host || (a->P > 0 && !radii)) { set_error("null workspace/output"); return HGS_ERR_INVALID; }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const GeomWs g = GeomWs::carve_from(geom_ws, a->P);
+  *L_out_host = 0;
+  if (a->P == 0) return HGS_OK;
+  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
+  const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
+  HGS_HIP(hipMemcpyAsync(L_out_host, g.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  HGS_HIP(hipStreamSynchronize(s));
+  return HGS_OK;
+}
+
+int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
+                          float* out_color, float* out_invdepth, hgs_stream_t stream, int device) {
+  int rc = validate(a);
+  if (rc) return rc;
+  if (!geom_ws || !bin_ws || !img_ws || !out_color) { set_error("null workspace/output"); return HGS_ERR_INVALID; }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = grid_x(a->width) * grid_y(a->height);
+  const GeomWs g = GeomWs::carve_from(geom_ws, a->P);
+  const BinWs b = BinWs::carve_from(bin_ws, L, T);
+  const ImgWs im = ImgWs::carve_from(img_ws, a->width, a->height);
+  if (L > 0) {
+    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_keys(*a, g, b, L, s)))) return rc;
+    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, key_end_bit(T), s, a->debug)))) return rc;
+  }
+  if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, T, s, a->debug)))) return rc;
+  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
+}
+
+int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bin_ws, const void* img_ws,
+                   void* bwd_ws, uint32_t L, const float* out_color, const float* out_invdepth,
+                   const float* dL_dcolor, const float* dL_dinvdepth, const hgs_raster_grads* grads,
+                   hgs_stream_t stream, int device) {
+  int rc = validate(a);
+  if (rc) return rc;
+  if (!geom_ws || !bin_ws || !img_ws || !bwd_ws || !out_color || !dL_dcolor || !grads) { set_error("null workspace/input"); return HGS_ERR_INVALID; }
+  if (a->P > 0) {
+    if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity) { set_error("missing gradient outputs"); return HGS_ERR_INVALID; }
+    if ((a->shs && !grads->dL_dshs) || (a->colors_precomp && !grads->dL_dcolors) ||
+        (a->scales && (!grads->dL_dscales || !grads->dL_drotations)) || (a->cov3D_precomp && !grads->dL_dcov3D)) {
+      set_error("gradient outputs do not match the inputs that were provided");
+      return HGS_ERR_INVALID;
+    }
+  }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (a->P == 0) return HGS_OK;
+  const int T = grid_x(a->width) * grid_y(a->height);
+  const GeomWs g = GeomWs::carve_from(const_cast<void*>(geom_ws), a->P);
+  const BinWs b = BinWs::carve_from(const_cast<void*>(bin_ws), L, T);
+  const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), a->width, a->height);
+  float* inst = static_cast<float*>(bwd_ws);
+  if (L > 0) {
+    {
+      StageTimer _t(ST_MEMSET_BWD, s);
+      HGS_HIP(hipMemsetAsync(inst, 0, (size_t)L * kInstStride * sizeof(float), s));
+    }
+    if ((rc = HGS_TIMED(ST_RENDER_BWD, s, launch_render_bwd(*a, g, b, im, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, inst, s)))) return rc;
+  }
+  hgs_raster_grads gr = *grads;
+  if (!a->shs) gr.dL_dshs = nullptr;
+  if (!a->colors_precomp) gr.dL_dcolors = nullptr;
+  if (!a->scales) { gr.dL_dscales = nullptr; gr.dL_drotations = nullptr; }
+  if (!a->cov3D_precomp) gr.dL_dcov3D = nullptr;
+  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, gr, s));
+}
+
+int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, const void* geom_ws,
+                         const void* bin_ws, const void* img_ws, hgs_raster_views* out) {
+  if (!out || !geom_ws || !bin_ws || !img_ws) { set_error("null argument"); return HGS_ERR_INVALID; }
+  const int T = grid_x(width) * grid_y(height);
+  const GeomWs g = GeomWs::carve_from(const_cast<void*>(geom_ws), P);
+  const BinWs b = BinWs::carve_from(const_cast<void*>(bin_ws), L, T);
+  const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), width, height);
+  out->keys_sorted = b.keys_out;
+  out->point_list = b.vals_out;
+  out->ranges = b.ranges;
+  out->tiles_touched = g.tiles_touched;
+  out->offsets = g.offsets;
+  out->depths = g.depths;
+  out->rects = g.rects;
+  out->records = g.records;
+  out->final_T = im.final_T;
+  out->n_contrib = im.n_contrib;
+  return HGS_OK;
+}
+
+int hgs_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  g_timing = on != 0;
+  return HGS_OK;
+}
+int hgs_timing_stage_count(void) { return ST_COUNT; }
+const char* hgs_timing_stage_name(int i) { return (i >= 0 && i < ST_COUNT) ? kStageNames[i] : ""; }
+int hgs_timing_read(double* ms_out, uint32_t* calls_out, int reset) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  for (const Pending& p : g_pending) {
+    float ms = 0.f;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      g_ms[p.stage] += ms;
+      g_calls[p.stage] += 1;
+    }
+    g_pool.push_back(p.a);
+    g_pool.push_back(p.b);
+  }
+  g_pending.clear();
+  for (int i = 0; i < ST_COUNT; ++i) {
+    if (ms_out) ms_out[i] = g_ms[i];
+    if (calls_out) calls_out[i] = g_calls[i];
+    if (reset) { g_ms[i] = 0.0; g_calls[i] = 0; }
+  }
+  return HGS_OK;
+}
+
+size_t hgs_sort_tmp_bytes(uint32_t n) { return sort_tmp_bytes(n ? n : 1); }
+
+int hgs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+                   void* tmp, uint32_t n, int end_bit, hgs_stream_t stream, int device) {
+  if (n && (!keys_in || !vals_in || !keys_out || !vals_out || !tmp)) { set_error("null argument"); return HGS_ERR_INVALID; }
+  HGS_HIP(hipSetDevice(device));
+  return sort_pairs(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, static_cast<hipStream_t>(stream), false);
+}
+
+}  // extern "C"

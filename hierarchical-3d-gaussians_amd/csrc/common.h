@@ -1,0 +1,106 @@
+// Internal helpers shared by the libhgs translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/hgs.h"
+
+namespace hgs {
+
+void set_error(const char* fmt, ...);
+
+#define HGS_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      hgs::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(_e)); \
+      return HGS_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+// After a kernel launch: always pick up launch errors; in debug mode also
+// synchronise so that an asynchronous fault is attributed to this kernel.
+#define HGS_LAUNCH_CHECK(name, stream, debug)                                           \
+  do {                                                                                  \
+    hipError_t _e = hipGetLastError();                                                  \
+    if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                 \
+    if (_e != hipSuccess) {                                                             \
+      hgs::set_error("kernel %s failed: %s", name, hipGetErrorString(_e));              \
+      return HGS_ERR_HIP;                                                               \
+    }                                                                                   \
+  } while (0)
+
+constexpr size_t kAlign = 256;
+inline size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+template <typename T>
+inline T* carve(char*& p, size_t count) {
+  T* r = reinterpret_cast<T*>(p);
+  p += align_up(count * sizeof(T));
+  return r;
+}
+
+constexpr int kTile = HGS_TILE;
+constexpr int kRecFloats = 12;              // per-Gaussian 2D record, 3 x float4
+constexpr int kInstStride = HGS_INST_GRAD_STRIDE;
+constexpr int kPreBlock = 256;              // Gaussians per preprocess / binning workgroup
+
+// ---- workspace layouts ------------------------------------------------------
+struct GeomWs {
+  float* records;          // [P,12]
+  float* depths;           // [P]
+  uint32_t* rects;         // [P,2]
+  uint32_t* tiles_touched; // [P]
+  uint32_t* offsets;       // [P] exclusive
+  uint32_t* flags;         // [P] bit0..2 colour clamp, bit3 tx clamped, bit4 ty clamped
+  uint32_t* block_sums;    // [nblk+1] exclusive scan of per-workgroup instance counts; [nblk] = L
+  static size_t bytes(int32_t P);
+  static GeomWs carve_from(void* base, int32_t P);
+};
+
+struct BinWs {
+  uint64_t* keys_in;   // [L]
+  uint32_t* vals_in;   // [L]
+  uint64_t* keys_out;  // [L] sorted
+  uint32_t* vals_out;  // [L] sorted = point_list
+  uint32_t* ranges;    // [T,2]
+  void* sort_tmp;
+  static size_t bytes(uint32_t L, int32_t T);
+  static BinWs carve_from(void* base, uint32_t L, int32_t T);
+};
+
+struct ImgWs {
+  float* final_T;       // [H*W]
+  uint32_t* n_contrib;  // [H*W]
+  static size_t bytes(int32_t W, int32_t H);
+  static ImgWs carve_from(void* base, int32_t W, int32_t H);
+};
+
+inline int grid_x(int W) { return (W + kTile - 1) / kTile; }
+inline int grid_y(int H) { return (H + kTile - 1) / kTile; }
+inline int key_end_bit(int T) {
+  int b = 0;
+  while ((1 << b) < T) ++b;
+  return 32 + (b < 1 ? 1 : b);
+}
+
+// ---- stage launchers (each returns an HGS_* code) ----------------------------
+int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug);
+int launch_duplicate_keys(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s);
+int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, bool debug);
+int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                      float* out_color, float* out_invdepth, hipStream_t s);
+int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
+                      const float* out_color, const float* out_invdepth, const float* dL_dcolor,
+                      const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
+int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads,
+                          const hgs_raster_grads& out, hipStream_t s);
+size_t sort_tmp_bytes(uint32_t n);
+int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
+               void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);
+
+}  // namespace hgs

@@ -1,0 +1,238 @@
+// Per-Gaussian projection math shared by the forward and backward preprocess kernels.
+//
+// Everything that feeds a DISCRETE decision (cull, radius, tile rectangle, depth key)
+// follows the float32 operation order of oracle/raster_oracle.py::geometry_spec with
+// floating-point contraction switched off, so radii / tile rectangles / (tile|depth)
+// keys are bit-identical to the oracle's.  Restates the public 3DGS projection
+// (SURVEY.md App. A 1-5); conventions pinned by the reference's
+// utils/general_utils.py:82-114 (quaternion -> R, Sigma = L L^T) and
+// scene/cameras.py:95-97 (row-vector matrices).
+#pragma once
+#include "common.h"
+
+namespace hgs {
+
+struct Proj {
+  float tx, ty, tz;        // view-space position
+  float hx, hy, hw, pw;    // clip-space, 1/(w+eps)
+  float txc, tyc;          // clamped tx, ty (EWA)
+  bool clampx, clampy;
+  float fx, fy;
+  float J00, J02, J11, J12;
+  float T0[3], T1[3];      // T = J * W
+  float U0[3], U1[3];      // U = T * Sigma
+  float c3[6];             // Sigma (xx,xy,xz,yy,yz,zz)
+  float a, b, c, det;      // 2D covariance (+0.3 dilation) and determinant
+  float conA, conB, conC;  // conic
+  float px, py;            // pixel-centre position
+  float rad_f;             // screen radius (float, integral)
+  int minx, miny, maxx, maxy;
+  bool visible;
+};
+
+__device__ __forceinline__ void quat_to_rot(const float q[4], float R[9]) {
+#pragma clang fp contract(off)
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  R[0] = 1.0f - 2.0f * (y * y + z * z);
+  R[1] = 2.0f * (x * y - r * z);
+  R[2] = 2.0f * (x * z + r * y);
+  R[3] = 2.0f * (x * y + r * z);
+  R[4] = 1.0f - 2.0f * (x * x + z * z);
+  R[5] = 2.0f * (y * z - r * x);
+  R[6] = 2.0f * (x * z - r * y);
+  R[7] = 2.0f * (y * z + r * x);
+  R[8] = 1.0f - 2.0f * (x * x + y * y);
+}
+
+__device__ __forceinline__ void cov3d_from_scale_rot(const float sc[3], float mod, const float q[4],
+                                                     float c3[6], float R[9], float s[3]) {
+#pragma clang fp contract(off)
+  s[0] = mod * sc[0];
+  s[1] = mod * sc[1];
+  s[2] = mod * sc[2];
+  quat_to_rot(q, R);
+  float L[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L[i * 3 + k] = R[i * 3 + k] * s[k];
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j) {
+      c3[n++] = (L[i * 3 + 0] * L[j * 3 + 0] + L[i * 3 + 1] * L[j * 3 + 1]) + L[i * 3 + 2] * L[j * 3 + 2];
+    }
+}
+
+__device__ __forceinline__ float xform_row(const float* m, float x, float y, float z, int row) {
+#pragma clang fp contract(off)
+  return ((m[row] * x + m[4 + row] * y) + m[8 + row] * z) + m[12 + row];
+}
+
+__device__ __forceinline__ int tile_clamp(float v, int hi) {
+#pragma clang fp contract(off)
+  float t = truncf(v * 0.0625f);
+  if (t != t) t = 0.0f;
+  t = fminf((float)hi, fmaxf(0.0f, t));
+  return (int)t;
+}
+
+// vm / pm: stored (column-major standard) matrices in registers or LDS.
+__device__ __forceinline__ void project_gaussian(const float p[3], const float* vm, const float* pm,
+                                                 int W, int H, float tanfovx, float tanfovy,
+                                                 int gx, int gy, Proj& o) {
+#pragma clang fp contract(off)
+  const float x = p[0], y = p[1], z = p[2];
+  o.tx = xform_row(vm, x, y, z, 0);
+  o.ty = xform_row(vm, x, y, z, 1);
+  o.tz = xform_row(vm, x, y, z, 2);
+  o.visible = o.tz > 0.2f;
+  o.hx = xform_row(pm, x, y, z, 0);
+  o.hy = xform_row(pm, x, y, z, 1);
+  o.hw = xform_row(pm, x, y, z, 3);
+  o.pw = 1.0f / (o.hw + 0.0000001f);
+  const float ndcx = o.hx * o.pw;
+  const float ndcy = o.hy * o.pw;
+
+  o.fx = (float)W / (2.0f * tanfovx);
+  o.fy = (float)H / (2.0f * tanfovy);
+  const float limx = 1.3f * tanfovx;
+  const float limy = 1.3f * tanfovy;
+  const float txtz = o.tx / o.tz;
+  const float tytz = o.ty / o.tz;
+  o.clampx = (txtz < -limx) || (txtz > limx);
+  o.clampy = (tytz < -limy) || (tytz > limy);
+  o.txc = fminf(limx, fmaxf(-limx, txtz)) * o.tz;
+  o.tyc = fminf(limy, fmaxf(-limy, tytz)) * o.tz;
+  const float tz2 = o.tz * o.tz;
+  o.J00 = o.fx / o.tz;
+  o.J02 = -(o.fx * o.txc) / tz2;
+  o.J11 = o.fy / o.tz;
+  o.J12 = -(o.fy * o.tyc) / tz2;
+  // standard-orientation view rotation: Wm[i][j] = vm[j*4+i]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.T0[j] = o.J00 * vm[j * 4 + 0] + o.J02 * vm[j * 4 + 2];
+    o.T1[j] = o.J11 * vm[j * 4 + 1] + o.J12 * vm[j * 4 + 2];
+  }
+  const float* c3 = o.c3;
+  const float S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.U0[j] = (o.T0[0] * S[0][j] + o.T0[1] * S[1][j]) + o.T0[2] * S[2][j];
+    o.U1[j] = (o.T1[0] * S[0][j] + o.T1[1] * S[1][j]) + o.T1[2] * S[2][j];
+  }
+  o.a = ((o.U0[0] * o.T0[0] + o.U0[1] * o.T0[1]) + o.U0[2] * o.T0[2]) + 0.3f;
+  o.b = (o.U0[0] * o.T1[0] + o.U0[1] * o.T1[1]) + o.U0[2] * o.T1[2];
+  o.c = ((o.U1[0] * o.T1[0] + o.U1[1] * o.T1[1]) + o.U1[2] * o.T1[2]) + 0.3f;
+  o.det = o.a * o.c - o.b * o.b;
+  if (o.det == 0.0f) o.visible = false;
+  const float det_inv = 1.0f / o.det;
+  o.conA = o.c * det_inv;
+  o.conB = (-o.b) * det_inv;
+  o.conC = o.a * det_inv;
+
+  const float mid = 0.5f * (o.a + o.c);
+  const float disc = fmaxf(0.1f, mid * mid - o.det);
+  const float sq = sqrtf(disc);
+  const float lam = fmaxf(mid + sq, mid - sq);
+  o.rad_f = ceilf(3.0f * sqrtf(lam));
+  o.px = ((ndcx + 1.0f) * (float)W - 1.0f) * 0.5f;
+  o.py = ((ndcy + 1.0f) * (float)H - 1.0f) * 0.5f;
+  o.minx = tile_clamp(o.px - o.rad_f, gx);
+  o.maxx = tile_clamp(o.px + o.rad_f + 15.0f, gx);
+  o.miny = tile_clamp(o.py - o.rad_f, gy);
+  o.maxy = tile_clamp(o.py + o.rad_f + 15.0f, gy);
+  const bool finite = (fabsf(o.rad_f) <= 3.0e38f) && (fabsf(o.px) <= 3.0e38f) && (fabsf(o.py) <= 3.0e38f);
+  if (!finite || (o.maxx - o.minx) * (o.maxy - o.miny) <= 0) o.visible = false;
+}
+
+// Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity'; oracle: raster_oracle.lod_opacity).
+__device__ __forceinline__ float lod_opacity(float o, float w, int kids, float* dout_do) {
+  if (kids < 2) {
+    if (dout_do) *dout_do = 1.0f;
+    return o;
+  }
+  const float invk = 1.0f / (float)kids;
+  const float oc = fminf(o, 0.99f);
+  const float base = 1.0f - oc;
+  const float pw = powf(base, invk);
+  if (dout_do) {
+    const float dstack = (o < 0.99f) ? invk * pw / base : 0.0f;
+    *dout_do = w + (1.0f - w) * dstack;
+  }
+  return w * o + (1.0f - w) * (1.0f - pw);
+}
+
+constexpr float SH_C0 = 0.28209479177387814f;
+constexpr float SH_C1 = 0.4886025119029199f;
+constexpr float SH_C2_0 = 1.0925484305920792f;
+constexpr float SH_C2_1 = -1.0925484305920792f;
+constexpr float SH_C2_2 = 0.31539156525252005f;
+constexpr float SH_C2_3 = -1.0925484305920792f;
+constexpr float SH_C2_4 = 0.5462742152960396f;
+constexpr float SH_C3_0 = -0.5900435899266435f;
+constexpr float SH_C3_1 = 2.890611442640554f;
+constexpr float SH_C3_2 = -0.4570457994644658f;
+constexpr float SH_C3_3 = 0.3731763325901154f;
+constexpr float SH_C3_4 = -0.4570457994644658f;
+constexpr float SH_C3_5 = 1.445305721320277f;
+constexpr float SH_C3_6 = -0.5900435899266435f;
+
+// SH basis values for a unit direction (utils/sh_utils.py:57-112 polynomial).
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16]) {
+  b[0] = SH_C0;
+  if (deg > 0) {
+    b[1] = -SH_C1 * y;
+    b[2] = SH_C1 * z;
+    b[3] = -SH_C1 * x;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      b[4] = SH_C2_0 * xy;
+      b[5] = SH_C2_1 * yz;
+      b[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+      b[7] = SH_C2_3 * xz;
+      b[8] = SH_C2_4 * (xx - yy);
+      if (deg > 2) {
+        b[9] = SH_C3_0 * y * (3.0f * xx - yy);
+        b[10] = SH_C3_1 * xy * z;
+        b[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+        b[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+        b[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+        b[14] = SH_C3_5 * z * (xx - yy);
+        b[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+      }
+    }
+  }
+}
+
+// d(basis_k)/d(x,y,z)
+__device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float dbx[16],
+                                              float dby[16], float dbz[16]) {
+  dbx[0] = dby[0] = dbz[0] = 0.0f;
+  if (deg > 0) {
+    dbx[1] = 0.0f;      dby[1] = -SH_C1;    dbz[1] = 0.0f;
+    dbx[2] = 0.0f;      dby[2] = 0.0f;      dbz[2] = SH_C1;
+    dbx[3] = -SH_C1;    dby[3] = 0.0f;      dbz[3] = 0.0f;
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      dbx[4] = SH_C2_0 * y;          dby[4] = SH_C2_0 * x;          dbz[4] = 0.0f;
+      dbx[5] = 0.0f;                 dby[5] = SH_C2_1 * z;          dbz[5] = SH_C2_1 * y;
+      dbx[6] = SH_C2_2 * -2.0f * x;  dby[6] = SH_C2_2 * -2.0f * y;  dbz[6] = SH_C2_2 * 4.0f * z;
+      dbx[7] = SH_C2_3 * z;          dby[7] = 0.0f;                 dbz[7] = SH_C2_3 * x;
+      dbx[8] = SH_C2_4 * 2.0f * x;   dby[8] = SH_C2_4 * -2.0f * y;  dbz[8] = 0.0f;
+      if (deg > 2) {
+        dbx[9] = SH_C3_0 * 6.0f * xy;               dby[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy);      dbz[9] = 0.0f;
+        dbx[10] = SH_C3_1 * yz;                     dby[10] = SH_C3_1 * xz;                          dbz[10] = SH_C3_1 * xy;
+        dbx[11] = SH_C3_2 * -2.0f * xy;             dby[11] = SH_C3_2 * (4.0f * zz - xx - 3.0f * yy); dbz[11] = SH_C3_2 * 8.0f * yz;
+        dbx[12] = SH_C3_3 * -6.0f * xz;             dby[12] = SH_C3_3 * -6.0f * yz;                  dbz[12] = SH_C3_3 * (6.0f * zz - 3.0f * xx - 3.0f * yy);
+        dbx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy); dby[13] = SH_C3_4 * -2.0f * xy;            dbz[13] = SH_C3_4 * 8.0f * xz;
+        dbx[14] = SH_C3_5 * 2.0f * xz;              dby[14] = SH_C3_5 * -2.0f * yz;                  dbz[14] = SH_C3_5 * (xx - yy);
+        dbx[15] = SH_C3_6 * (3.0f * xx - 3.0f * yy); dby[15] = SH_C3_6 * -6.0f * xy;                 dbz[15] = 0.0f;
+      }
+    }
+  }
+}
+
+}  // namespace hgs

@@ -1,0 +1,277 @@
+// K9 (expand_to_size) and K10 (get_interpolation_weights): the per-view hierarchy LOD cut.
+//
+// Replaces gaussian_hierarchy._C.expand_to_size / get_interpolation_weights
+// (train_post.py:91-113, render_hierarchy.py:58-80; reference source absent, semantics
+// in oracle/lod_oracle.py and DESIGN.md).  Top-down frontier expansion: work is
+// proportional to the nodes ABOVE the cut, not to the hierarchy size; the only
+// full-size pass is the flag compaction (4 B per node), which also makes the output
+// order deterministic (ascending node index) despite the atomic frontier appends.
+#include "common.h"
+
+namespace hgs {
+namespace {
+
+constexpr int kNodeInts = 7;   // depth,parent,start,count_leafs,count_merged,start_children,count_children
+constexpr int kBoxFloats = 8;  // min.xyz+extent, max.xyz+pad
+constexpr int kMaxLevels = 64;
+constexpr float kFltMax = 3.4028234663852886e38f;
+
+struct Vec3 { float x, y, z; };
+
+__device__ __forceinline__ float node_size(const float* __restrict__ boxes, int n, Vec3 v) {
+#pragma clang fp contract(off)
+  const float4 mn = reinterpret_cast<const float4*>(boxes)[(size_t)n * 2 + 0];
+  const float4 mx = reinterpret_cast<const float4*>(boxes)[(size_t)n * 2 + 1];
+  const float dx = fmaxf(fmaxf(mn.x - v.x, v.x - mx.x), 0.0f);
+  const float dy = fmaxf(fmaxf(mn.y - v.y, v.y - mx.y), 0.0f);
+  const float dz = fmaxf(fmaxf(mn.z - v.z, v.z - mx.z), 0.0f);
+  const float d2 = (dx * dx + dy * dy) + dz * dz;
+  const float dist = sqrtf(d2);
+  const float s = mn.w / dist;
+  return d2 > 0.0f ? s : kFltMax;
+}
+
+__global__ void lod_init_kernel(uint32_t* counts, int32_t* frontier, int N) {
+  if (threadIdx.x == 0) {
+    counts[0] = N > 0 ? 1u : 0u;
+    frontier[0] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void lod_expand_level_kernel(const int32_t* __restrict__ nodes,
+                                                               const float* __restrict__ boxes, float tau, Vec3 vp,
+                                                               const int32_t* __restrict__ fin,
+                                                               const uint32_t* __restrict__ count_in,
+                                                               int32_t* __restrict__ fout,
+                                                               uint32_t* __restrict__ count_out,
+                                                               uint32_t* __restrict__ emit_cnt) {
+  const uint32_t n_in = *count_in;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_in; i += gridDim.x * 256u) {
+    const int n = fin[i];
+    const int32_t* nd = nodes + (size_t)n * kNodeInts;
+    const int nch = nd[6];
+    const float s = node_size(boxes, n, vp);
+    if (s > tau && nch > 0) {
+      const uint32_t base = atomicAdd(count_out, (uint32_t)nch);
+      const int c0 = nd[5];
+      for (int k = 0; k < nch; ++k) fout[base + k] = c0 + k;
+    } else {
+      emit_cnt[n] = (uint32_t)(nd[3] + nd[4]);
+    }
+  }
+}
+
+// per-workgroup sums of emit_cnt (256 nodes per workgroup)
+__global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __restrict__ emit_cnt, int N,
+                                                             uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[4];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t v = (i < N) ? emit_cnt[i] : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+__global__ __launch_bounds__(1024) void lod_scan_sums_kernel(uint32_t* __restrict__ sums, int n) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = (i < n) ? sums[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < n) sums[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (tid == 0) sums[n] = carry_s;
+}
+
+__global__ __launch_bounds__(256) void lod_emit_kernel(const int32_t* __restrict__ nodes,
+                                                       const uint32_t* __restrict__ emit_cnt, int N,
+                                                       const uint32_t* __restrict__ block_sums,
+                                                       int32_t* __restrict__ render_indices,
+                                                       int32_t* __restrict__ parent_indices,
+                                                       int32_t* __restrict__ node_indices, int capacity) {
+  __shared__ uint32_t wave_tot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = blockIdx.x * 256 + tid;
+  const uint32_t cnt = (n < N) ? emit_cnt[n] : 0u;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+  if (cnt == 0) return;
+  const uint32_t pos = block_sums[blockIdx.x] + wbase + inc - cnt;
+  const int32_t* nd = nodes + (size_t)n * kNodeInts;
+  const int start = nd[2];
+  const int par = nd[1];
+  const int pstart = par >= 0 ? nodes[(size_t)par * kNodeInts + 2] : -1;
+  for (uint32_t k = 0; k < cnt; ++k) {
+    const uint32_t o = pos + k;
+    if (o < (uint32_t)capacity) {
+      render_indices[o] = start + (int)k;
+      parent_indices[o] = pstart >= 0 ? pstart : start + (int)k;
+      node_indices[o] = n;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lod_weights_kernel(const int32_t* __restrict__ node_indices, int n, float tau,
+                                                          const int32_t* __restrict__ nodes,
+                                                          const float* __restrict__ boxes, Vec3 vp,
+                                                          float* __restrict__ weights,
+                                                          int32_t* __restrict__ num_siblings) {
+#pragma clang fp contract(off)
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int nd = node_indices[i];
+  const int par = nodes[(size_t)nd * kNodeInts + 1];
+  float w = 1.0f;
+  int kids = 1;
+  if (par >= 0) {
+    const float sp = node_size(boxes, par, vp);
+    const float sn = node_size(boxes, nd, vp);
+    kids = nodes[(size_t)par * kNodeInts + 6];
+    if (sp < kFltMax && sp > sn) {
+      const float t = (sp - tau) / (sp - sn);
+      w = fminf(1.0f, fmaxf(0.0f, t));
+    }
+  }
+  weights[i] = w;
+  num_siblings[i] = kids;
+}
+
+struct ExpandTmp {
+  uint32_t* emit_cnt;    // [N]
+  int32_t* frontier_a;   // [N]
+  int32_t* frontier_b;   // [N]
+  uint32_t* counts;      // [kMaxLevels + 2]
+  uint32_t* block_sums;  // [nblk + 1]
+};
+
+inline ExpandTmp carve_expand(void* tmp, int32_t N) {
+  const size_t n = (size_t)(N > 0 ? N : 1);
+  char* p = static_cast<char*>(tmp);
+  ExpandTmp t;
+  t.emit_cnt = carve<uint32_t>(p, n);
+  t.frontier_a = carve<int32_t>(p, n);
+  t.frontier_b = carve<int32_t>(p, n);
+  t.counts = carve<uint32_t>(p, kMaxLevels + 2);
+  t.block_sums = carve<uint32_t>(p, (n + 255) / 256 + 1);
+  return t;
+}
+
+}  // namespace
+}  // namespace hgs
+
+using namespace hgs;
+
+extern "C" {
+
+size_t hgs_expand_tmp_bytes(int32_t N) {
+  const size_t n = (size_t)(N > 0 ? N : 1);
+  return 3 * align_up(n * 4) + align_up((kMaxLevels + 2) * 4) + align_up(((n + 255) / 256 + 1) * 4) + kAlign;
+}
+
+int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, float size, const float viewpoint[3],
+                       const float viewdir[3], int32_t* render_indices, int32_t* parent_indices,
+                       int32_t* nodes_for_render_indices, int32_t capacity, void* tmp, int32_t* count_out_host,
+                       hgs_stream_t stream, int device) {
+  (void)viewdir;  // always zeros at the reference's call sites (train_post.py:96, render_hierarchy.py:63)
+  if (!count_out_host) { set_error("null count_out_host"); return HGS_ERR_INVALID; }
+  *count_out_host = 0;
+  if (N <= 0) return HGS_OK;
+  if (!nodes || !boxes || !viewpoint || !render_indices || !parent_indices || !nodes_for_render_indices || !tmp) {
+    set_error("null argument");
+    return HGS_ERR_INVALID;
+  }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ExpandTmp t = carve_expand(tmp, N);
+  const Vec3 vp = {viewpoint[0], viewpoint[1], viewpoint[2]};
+  HGS_HIP(hipMemsetAsync(t.emit_cnt, 0, (size_t)N * 4, s));
+  HGS_HIP(hipMemsetAsync(t.counts, 0, (kMaxLevels + 2) * 4, s));
+  hipLaunchKernelGGL(lod_init_kernel, dim3(1), dim3(64), 0, s, t.counts, t.frontier_a, N);
+  HGS_LAUNCH_CHECK("lod_init", s, false);
+  // Level-synchronous expansion.  The frontier size of a level is only known on the device, so
+  // every level is launched with a grid-stride kernel; the host polls the level counters every
+  // 8 levels to stop early (a hierarchy deeper than kMaxLevels is rejected).
+  int32_t* fin = t.frontier_a;
+  int32_t* fout = t.frontier_b;
+  const int grid = 1024;
+  int level = 0;
+  bool finished = false;
+  while (!finished) {
+    const int stop = level + 8;
+    for (; level < stop && level < kMaxLevels; ++level) {
+      hipLaunchKernelGGL(lod_expand_level_kernel, dim3(grid), dim3(256), 0, s, nodes, boxes, size, vp, fin,
+                         t.counts + level, fout, t.counts + level + 1, t.emit_cnt);
+      HGS_LAUNCH_CHECK("lod_expand_level", s, false);
+      int32_t* sw = fin; fin = fout; fout = sw;
+    }
+    uint32_t next = 0;
+    HGS_HIP(hipMemcpyAsync(&next, t.counts + level, 4, hipMemcpyDeviceToHost, s));
+    HGS_HIP(hipStreamSynchronize(s));
+    if (next == 0) finished = true;
+    else if (level >= kMaxLevels) { set_error("hierarchy deeper than %d levels", kMaxLevels); return HGS_ERR_INVALID; }
+  }
+  const int nblk = (N + 255) / 256;
+  hipLaunchKernelGGL(lod_block_sums_kernel, dim3(nblk), dim3(256), 0, s, t.emit_cnt, N, t.block_sums);
+  HGS_LAUNCH_CHECK("lod_block_sums", s, false);
+  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(1), dim3(1024), 0, s, t.block_sums, nblk);
+  HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
+  hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,
+                     render_indices, parent_indices, nodes_for_render_indices, capacity);
+  HGS_LAUNCH_CHECK("lod_emit", s, false);
+  uint32_t total = 0;
+  HGS_HIP(hipMemcpyAsync(&total, t.block_sums + nblk, 4, hipMemcpyDeviceToHost, s));
+  HGS_HIP(hipStreamSynchronize(s));
+  if (total > (uint32_t)capacity) {
+    set_error("expand_to_size: %u entries exceed the output capacity %d", total, capacity);
+    return HGS_ERR_INVALID;
+  }
+  *count_out_host = (int32_t)total;
+  return HGS_OK;
+}
+
+int hgs_interp_weights(const int32_t* node_indices, int32_t n, float size, const int32_t* nodes, const float* boxes,
+                       int32_t N, const float viewpoint[3], const float viewdir[3], float* interpolation_weights,
+                       int32_t* num_siblings, hgs_stream_t stream, int device) {
+  (void)viewdir; (void)N;
+  if (n <= 0) return HGS_OK;
+  if (!node_indices || !nodes || !boxes || !viewpoint || !interpolation_weights || !num_siblings) {
+    set_error("null argument");
+    return HGS_ERR_INVALID;
+  }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const Vec3 vp = {viewpoint[0], viewpoint[1], viewpoint[2]};
+  hipLaunchKernelGGL(lod_weights_kernel, dim3((n + 255) / 256), dim3(256), 0, s, node_indices, n, size, nodes, boxes,
+                     vp, interpolation_weights, num_siblings);
+  HGS_LAUNCH_CHECK("lod_weights", s, false);
+  return HGS_OK;
+}
+
+}  // extern "C"

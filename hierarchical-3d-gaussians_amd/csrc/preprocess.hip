@@ -1,0 +1,440 @@
+// K1 (preprocess forward) and K8 (preprocess backward): one lane per Gaussian.
+//
+// Restates the per-Gaussian stage of the op called at
+// gaussian_renderer/__init__.py:105-113 (reference source absent; algorithm per
+// SURVEY.md App. A 1-6, 9-10).  HBM-bound streaming kernels: 236 B in per Gaussian
+// at SH degree 3 (fwd), 236 B in + 248 B out (bwd).
+#include "gaussian_math.h"
+
+namespace hgs {
+
+namespace {
+
+struct CamLds {
+  float vm[16];
+  float pm[16];
+  float cam[3];
+};
+
+__device__ __forceinline__ void load_camera(const hgs_raster_args& a, CamLds& c) {
+  // 35 floats, wave-uniform addresses -> scalar loads.
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    c.vm[i] = a.viewmatrix[i];
+    c.pm[i] = a.projmatrix[i];
+  }
+  c.cam[0] = a.campos[0];
+  c.cam[1] = a.campos[1];
+  c.cam[2] = a.campos[2];
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+__device__ __forceinline__ void load_sh(const float* __restrict__ shs, int idx, int M, float sh[48]) {
+  const int n = M * 3;
+  const float* src = shs + (size_t)idx * n;
+  if ((n & 3) == 0) {
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      if (i * 4 < n) {
+        const float4 v = s4[i];
+        sh[i * 4 + 0] = v.x;
+        sh[i * 4 + 1] = v.y;
+        sh[i * 4 + 2] = v.z;
+        sh[i * 4 + 3] = v.w;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 48; ++i)
+      if (i < n) sh[i] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
+                                                                   int32_t* __restrict__ radii) {
+  __shared__ uint32_t wave_tot[kPreBlock / 64];
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  const int gx = (a.width + kTile - 1) / kTile;
+  const int gy = (a.height + kTile - 1) / kTile;
+  CamLds cam;
+  load_camera(a, cam);
+
+  uint32_t touched = 0;
+  if (idx < a.P) {
+    Proj pr;
+    const float p[3] = {a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]};
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
+    } else {
+      const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
+      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+      const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      float R[9], s[3];
+      cov3d_from_scale_rot(sc, a.scale_modifier, q, pr.c3, R, s);
+    }
+    project_gaussian(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, gx, gy, pr);
+
+    int32_t rad = 0;
+    uint32_t flags = 0;
+    if (pr.visible) {
+      touched = (uint32_t)((pr.maxx - pr.minx) * (pr.maxy - pr.miny));
+      rad = (int32_t)pr.rad_f;
+      // colour
+      float rgb[3];
+      if (a.colors_precomp) {
+        rgb[0] = a.colors_precomp[idx * 3 + 0];
+        rgb[1] = a.colors_precomp[idx * 3 + 1];
+        rgb[2] = a.colors_precomp[idx * 3 + 2];
+      } else {
+        float sh[48];
+        load_sh(a.shs, idx, a.M, sh);
+        float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
+        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= inv; dy *= inv; dz *= inv;
+        float b[16];
+        sh_basis(a.sh_degree, dx, dy, dz, b);
+        const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nb) {
+            r0 += b[k] * sh[k * 3 + 0];
+            r1 += b[k] * sh[k * 3 + 1];
+            r2 += b[k] * sh[k * 3 + 2];
+          }
+        }
+        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+        if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
+        if (r1 < 0.f) { r1 = 0.f; flags |= 2u; }
+        if (r2 < 0.f) { r2 = 0.f; flags |= 4u; }
+        rgb[0] = r0; rgb[1] = r1; rgb[2] = r2;
+      }
+      if (pr.clampx) flags |= 8u;
+      if (pr.clampy) flags |= 16u;
+      float opac = a.opacities[idx];
+      if (a.interpolation_weights && a.num_node_kids)
+        opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
+      // conic pre-scaled to base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
+      const float kLog2e = 1.4426950408889634f;
+      const float A2 = -0.5f * kLog2e * pr.conA;
+      const float B2 = -kLog2e * pr.conB;
+      const float C2 = -0.5f * kLog2e * pr.conC;
+      const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
+                                ((uint32_t)(pr.maxx - pr.minx) << 20);
+      float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * 3;
+      rec[0] = make_float4(pr.px, pr.py, A2, B2);
+      rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
+      rec[2] = make_float4(rgb[2], 1.0f / pr.tz, 0.0f, __uint_as_float(rectbits));
+      g.depths[idx] = pr.tz;
+      g.rects[idx * 2 + 0] = (uint32_t)pr.minx | ((uint32_t)pr.miny << 16);
+      g.rects[idx * 2 + 1] = (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16);
+    }
+    radii[idx] = rad;
+    g.tiles_touched[idx] = touched;
+    g.flags[idx] = flags;
+  }
+  // per-workgroup instance count (feeds the offsets scan)
+  const uint32_t ws = wave_sum_u32(touched);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kPreBlock / 64; ++w) t += wave_tot[w];
+    g.block_sums[blockIdx.x] = t;
+  }
+}
+
+// Exclusive scan of the per-workgroup sums (single workgroup; nblk = P/256).
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums, int n) {
+  __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = (i < n) ? sums[i] : 0u;
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
+    const uint32_t carry = carry_s;
+    if (i < n) sums[i] = carry + wbase + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + wbase + inc;
+    __syncthreads();
+  }
+  if (tid == 0) sums[n] = carry_s;
+}
+
+// ---------------------------------------------------------------------------
+// K8: chain rule from the per-instance sums of the render backward to the op's
+// inputs.  Instance sums (12 floats each, see render.hip):
+//   0: sum X*dx   1: sum X*dy   2: sum X*dx^2   3: sum X*dx*dy   4: sum X*dy^2
+//   5: sum G*dL/dalpha          6..8: sum w*dL/dC_k              9: sum w*dL/dD
+// with X = dL/dpower, w = alpha*T.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
+                                                                   const float* __restrict__ inst,
+                                                                   hgs_raster_grads out) {
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  if (idx >= a.P) return;
+  const int gx = (a.width + kTile - 1) / kTile;
+  const int gy = (a.height + kTile - 1) / kTile;
+  const uint32_t n = g.tiles_touched[idx];
+
+  float d_mean[3] = {0.f, 0.f, 0.f};
+  float d_m2[3] = {0.f, 0.f, 0.f};
+  float d_op = 0.f;
+  float d_scale[3] = {0.f, 0.f, 0.f};
+  float d_rot[4] = {0.f, 0.f, 0.f, 0.f};
+  float d_c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float d_col[3] = {0.f, 0.f, 0.f};
+  const int M3 = a.M * 3;
+
+  if (n == 0) {
+    // culled: all-zero gradients
+    if (out.dL_dshs) {
+      float* dst = out.dL_dshs + (size_t)idx * M3;
+      for (int i = 0; i < M3; ++i) dst[i] = 0.f;
+    }
+  } else {
+    CamLds cam;
+    load_camera(a, cam);
+    // ---- sum the instance partials (contiguous run: emission order) ----------
+    float s[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) s[i] = 0.f;
+    const float4* ip = reinterpret_cast<const float4*>(inst) + (size_t)g.offsets[idx] * 3;
+    for (uint32_t k = 0; k < n; ++k) {
+      const float4 v0 = ip[k * 3 + 0], v1 = ip[k * 3 + 1], v2 = ip[k * 3 + 2];
+      s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w;
+      s[4] += v1.x; s[5] += v1.y; s[6] += v1.z; s[7] += v1.w;
+      s[8] += v2.x; s[9] += v2.y;
+    }
+    // ---- recompute the forward projection -------------------------------------
+    Proj pr;
+    const float p[3] = {a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]};
+    float R[9], sv[3], q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
+    } else {
+      const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
+      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+      q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+      cov3d_from_scale_rot(sc, a.scale_modifier, q, pr.c3, R, sv);
+    }
+    project_gaussian(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, gx, gy, pr);
+    const uint32_t flags = g.flags[idx];
+
+    const float A = pr.conA, B = pr.conB, C = pr.conC;
+    const float gA = -0.5f * s[2], gB = -s[3], gC = -0.5f * s[4];
+    const float ggx = -(A * s[0] + B * s[1]);
+    const float ggy = -(C * s[1] + B * s[0]);
+    d_m2[0] = ggx * 0.5f * (float)a.width;
+    d_m2[1] = ggy * 0.5f * (float)a.height;
+
+    // screen position -> clip space -> world
+    const float dndcx = d_m2[0], dndcy = d_m2[1];
+    const float dhx = dndcx * pr.pw, dhy = dndcy * pr.pw;
+    const float dhw = -(dndcx * pr.hx + dndcy * pr.hy) * pr.pw * pr.pw;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      d_mean[j] += cam.pm[j * 4 + 0] * dhx + cam.pm[j * 4 + 1] * dhy + cam.pm[j * 4 + 3] * dhw;
+
+    // conic -> 2D covariance
+    const float a2 = pr.a, b2 = pr.b, c2 = pr.c;
+    const float di2 = 1.0f / (pr.det * pr.det);
+    const float ga = (-c2 * c2 * gA + b2 * c2 * gB - b2 * b2 * gC) * di2;
+    const float gb = (2.f * b2 * c2 * gA - (a2 * c2 + b2 * b2) * gB + 2.f * a2 * b2 * gC) * di2;
+    const float gc = (-b2 * b2 * gA + a2 * b2 * gB - a2 * a2 * gC) * di2;
+    const float hb = 0.5f * gb;
+    // dL/dSigma (full symmetric matrix) = T^T G2 T
+    float Gs[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        Gs[i][j] = pr.T0[i] * (ga * pr.T0[j] + hb * pr.T1[j]) + pr.T1[i] * (hb * pr.T0[j] + gc * pr.T1[j]);
+    d_c3[0] = Gs[0][0];
+    d_c3[1] = 2.f * Gs[0][1];
+    d_c3[2] = 2.f * Gs[0][2];
+    d_c3[3] = Gs[1][1];
+    d_c3[4] = 2.f * Gs[1][2];
+    d_c3[5] = Gs[2][2];
+    // dL/dT = 2 G2 T Sigma = 2 G2 U
+    float dT0[3], dT1[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      dT0[j] = 2.f * ga * pr.U0[j] + gb * pr.U1[j];
+      dT1[j] = gb * pr.U0[j] + 2.f * gc * pr.U1[j];
+    }
+    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      gJ00 += dT0[j] * cam.vm[j * 4 + 0];
+      gJ02 += dT0[j] * cam.vm[j * 4 + 2];
+      gJ11 += dT1[j] * cam.vm[j * 4 + 1];
+      gJ12 += dT1[j] * cam.vm[j * 4 + 2];
+    }
+    const float itz = 1.0f / pr.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    const float g_txc = -pr.fx * itz2 * gJ02;
+    const float g_tyc = -pr.fy * itz2 * gJ12;
+    float g_tz = -pr.fx * itz2 * gJ00 + 2.f * pr.fx * pr.txc * itz3 * gJ02 - pr.fy * itz2 * gJ11 +
+                 2.f * pr.fy * pr.tyc * itz3 * gJ12;
+    float g_tx = 0.f, g_ty = 0.f;
+    if (flags & 8u) g_tz += g_txc * (pr.txc * itz); else g_tx = g_txc;
+    if (flags & 16u) g_tz += g_tyc * (pr.tyc * itz); else g_ty = g_tyc;
+    // inverse depth
+    g_tz += -s[9] * itz2;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      d_mean[j] += cam.vm[j * 4 + 0] * g_tx + cam.vm[j * 4 + 1] * g_ty + cam.vm[j * 4 + 2] * g_tz;
+
+    // Sigma -> scale / rotation
+    if (!a.cov3D_precomp) {
+      float dM[3][3];   // dL/dM, M_ik = R_ik s_k ; dL/dM = 2 Gs M
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc += Gs[i][j] * (R[j * 3 + k] * sv[k]);
+          dM[i][k] = 2.f * acc;
+        }
+      float gR[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+          acc += R[i * 3 + k] * dM[i][k];
+          gR[i][k] = dM[i][k] * sv[k];
+        }
+        d_scale[k] = a.scale_modifier * acc;
+      }
+      const float r = q[0], x = q[1], y = q[2], z = q[3];
+      d_rot[0] = 2.f * (-z * gR[0][1] + y * gR[0][2] + z * gR[1][0] - x * gR[1][2] - y * gR[2][0] + x * gR[2][1]);
+      d_rot[1] = 2.f * (y * gR[0][1] + z * gR[0][2] + y * gR[1][0] - 2.f * x * gR[1][1] - r * gR[1][2] +
+                        z * gR[2][0] + r * gR[2][1] - 2.f * x * gR[2][2]);
+      d_rot[2] = 2.f * (-2.f * y * gR[0][0] + x * gR[0][1] + r * gR[0][2] + x * gR[1][0] + z * gR[1][2] -
+                        r * gR[2][0] + z * gR[2][1] - 2.f * y * gR[2][2]);
+      d_rot[3] = 2.f * (-2.f * z * gR[0][0] - r * gR[0][1] + x * gR[0][2] + r * gR[1][0] - 2.f * z * gR[1][1] +
+                        y * gR[1][2] + x * gR[2][0] + y * gR[2][1]);
+    }
+
+    // opacity (through the LOD remap)
+    {
+      float dod = 1.0f;
+      if (a.interpolation_weights && a.num_node_kids)
+        (void)lod_opacity(a.opacities[idx], a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
+      d_op = s[5] * dod;
+    }
+
+    // colour
+    float gr[3] = {s[6], s[7], s[8]};
+    if (a.colors_precomp) {
+      d_col[0] = gr[0]; d_col[1] = gr[1]; d_col[2] = gr[2];
+    } else {
+      if (flags & 1u) gr[0] = 0.f;
+      if (flags & 2u) gr[1] = 0.f;
+      if (flags & 4u) gr[2] = 0.f;
+      float sh[48];
+      load_sh(a.shs, idx, a.M, sh);
+      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+      float b[16], dbx[16], dby[16], dbz[16];
+      sh_basis(a.sh_degree, ux, uy, uz, b);
+      sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
+      const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+      float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+      float* dst = out.dL_dshs + (size_t)idx * M3;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < a.M) {
+          float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+          if (k < nb) {
+            o0 = b[k] * gr[0]; o1 = b[k] * gr[1]; o2 = b[k] * gr[2];
+            const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
+            gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
+          }
+          dst[k * 3 + 0] = o0; dst[k * 3 + 1] = o1; dst[k * 3 + 2] = o2;
+        }
+      }
+      for (int k = 16; k < a.M; ++k) { dst[k * 3 + 0] = 0.f; dst[k * 3 + 1] = 0.f; dst[k * 3 + 2] = 0.f; }
+      // through the normalisation dir = d/|d|
+      const float dot = ux * gdx + uy * gdy + uz * gdz;
+      d_mean[0] += (gdx - ux * dot) * inv;
+      d_mean[1] += (gdy - uy * dot) * inv;
+      d_mean[2] += (gdz - uz * dot) * inv;
+    }
+  }
+
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    out.dL_dmeans3D[idx * 3 + j] = d_mean[j];
+    out.dL_dmeans2D[idx * 3 + j] = d_m2[j];
+  }
+  out.dL_dopacity[idx] = d_op;
+  if (out.dL_dcolors) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out.dL_dcolors[idx * 3 + j] = d_col[j];
+  }
+  if (out.dL_dscales) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) out.dL_dscales[idx * 3 + j] = d_scale[j];
+  }
+  if (out.dL_drotations)
+    reinterpret_cast<float4*>(out.dL_drotations)[idx] = make_float4(d_rot[0], d_rot[1], d_rot[2], d_rot[3]);
+  if (out.dL_dcov3D) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) out.dL_dcov3D[(size_t)idx * 6 + j] = d_c3[j];
+  }
+}
+
+}  // namespace
+
+int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s) {
+  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
+  if (nblk > 0) {
+    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, radii);
+    HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
+  }
+  return HGS_OK;
+}
+
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug) {
+  const int nblk = (P + kPreBlock - 1) / kPreBlock;
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, nblk);
+  HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+  return HGS_OK;
+}
+
+int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads,
+                          const hgs_raster_grads& out, hipStream_t s) {
+  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
+  if (nblk > 0) {
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, out);
+    HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
+  }
+  return HGS_OK;
+}
+
+}  // namespace hgs

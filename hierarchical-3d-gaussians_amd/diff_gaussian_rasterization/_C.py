@@ -1,0 +1,221 @@
+"""``diff_gaussian_rasterization._C`` -- the extension-module surface of the reference's
+hierarchy-rasterizer submodule (imported at gaussian_renderer/__init__.py:17), implemented
+over the C ABI of libhgs.so.  Thin glue only: argument checks, torch-owned workspaces,
+pointer passing.  All arithmetic happens in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from hgs import _lib
+
+
+def _require_gpu(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA/HIP tensor (got {t.device}); this op has no CPU path")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+
+
+def _opt(t, name, P, inner):
+    """None for an absent/empty optional input, else the validated tensor."""
+    if t is None or t.numel() == 0:
+        return None
+    _require_gpu(t, name)
+    if t.shape[0] != P or t.numel() != P * inner:
+        raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [{P}, ...] with {inner} values per Gaussian")
+    return t
+
+
+def _small(t, name, n):
+    if not torch.is_tensor(t):
+        raise RuntimeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be on the GPU (got {t.device})")
+    t = t.to(torch.float32).contiguous()
+    if t.numel() != n:
+        raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
+    return t
+
+
+def _lod(weights, kids, P):
+    """The hierarchy tensors are accepted empty on any device (gaussian_renderer/__init__.py:39-42,244-245)."""
+    if weights is None or kids is None or weights.numel() == 0 or kids.numel() == 0:
+        return None, None
+    if not weights.is_cuda or not kids.is_cuda:
+        raise RuntimeError("non-empty interpolation_weights / num_node_kids must be GPU tensors")
+    if weights.numel() < P or kids.numel() < P:
+        raise RuntimeError(f"interpolation_weights/num_node_kids hold {weights.numel()}/{kids.numel()} entries, need >= {P}")
+    w = weights.to(torch.float32).contiguous()
+    k = kids.to(torch.int32).contiguous()
+    return w, k
+
+
+class _Call:
+    """Everything one forward needs to hand back to the backward."""
+    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "P", "W", "H", "device")
+
+
+def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
+                debug, interpolation_weights, num_node_kids, do_depth, variant=0):
+    _require_gpu(means3D, "means3D")
+    if means3D.dim() != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    P = means3D.shape[0]
+    if sh is not None and sh.numel() == 0:
+        sh = None
+    if sh is not None:
+        _require_gpu(sh, "shs")
+        if sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3:
+            raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
+    colors = _opt(colors, "colors_precomp", P, 3)
+    scales = _opt(scales, "scales", P, 3)
+    rotations = _opt(rotations, "rotations", P, 4)
+    cov3D_precomp = _opt(cov3D_precomp, "cov3D_precomp", P, 6)
+    if P > 0:
+        _require_gpu(opacity, "opacities")
+        if opacity.numel() != P:
+            raise RuntimeError(f"opacities must hold {P} values")
+        if (sh is None) == (colors is None):
+            raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+    M = sh.shape[1] if sh is not None else 0
+    bg = _small(background, "bg", 3)
+    vm = _small(viewmatrix, "viewmatrix", 16)
+    pm = _small(projmatrix, "projmatrix", 16)
+    cp = _small(campos, "campos", 3)
+    w, k = _lod(interpolation_weights, num_node_kids, P)
+    a = _lib.RasterArgs()
+    a.P, a.M, a.sh_degree = P, M, int(degree)
+    a.width, a.height = int(image_width), int(image_height)
+    a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
+    a.do_depth, a.debug, a.variant, a.reserved = int(bool(do_depth)), int(bool(debug)), int(variant), 0
+    p = _lib.ptr
+    a.bg, a.viewmatrix, a.projmatrix, a.campos = p(bg), p(vm), p(pm), p(cp)
+    a.means3D, a.shs, a.colors_precomp, a.opacities = p(means3D), p(sh), p(colors), p(opacity)
+    a.scales, a.rotations, a.cov3D_precomp = p(scales), p(rotations), p(cov3D_precomp)
+    a.interpolation_weights, a.num_node_kids = p(w), p(k)
+    keep = (bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, w, k)
+    return a, keep, P, M
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                        viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
+                        prefiltered, debug, render_indices, parent_indices, interpolation_weights,
+                        num_node_kids, do_depth, variant=0):
+    """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
+    invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward."""
+    if (render_indices is not None and render_indices.numel() > 0) or \
+            (parent_indices is not None and parent_indices.numel() > 0):
+        raise NotImplementedError(
+            "in-op LOD gather (non-empty render_indices/parent_indices) is not available; the reference's "
+            "render_post always passes them empty (gaussian_renderer/__init__.py:244-245)")
+    lib = _lib.lib()
+    a, keep, P, M = _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier,
+                                cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
+                                image_width, sh, degree, campos, debug, interpolation_weights, num_node_kids,
+                                do_depth, variant)
+    dev = means3D.device
+    H, W = int(image_height), int(image_width)
+    u8 = dict(dtype=torch.uint8, device=dev)
+    sz = [C.c_size_t() for _ in range(4)]
+    _lib.check(lib.hgs_raster_ws_sizes(P, W, H, 0, *[C.byref(s) for s in sz]), "hgs_raster_ws_sizes")
+    geom = torch.empty(sz[0].value, **u8)
+    img = torch.empty(sz[2].value, **u8)
+    radii = torch.empty(P, dtype=torch.int32, device=dev)
+    L = C.c_uint32(0)
+    _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), _lib.ptr(geom), _lib.ptr(radii), C.byref(L),
+                                         _stream(dev), dev.index or 0), "hgs_raster_fwd_stage1")
+    _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L.value, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
+    binb = torch.empty(sz[1].value, **u8)
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev) if do_depth else \
+        torch.zeros(1, H, W, dtype=torch.float32, device=dev)
+    _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L.value,
+                                         _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
+                                         _stream(dev), dev.index or 0), "hgs_raster_fwd_stage2")
+    call = _Call()
+    call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
+    call.L, call.P, call.W, call.H, call.device = L.value, P, W, H, dev
+    return L.value, color, radii, geom, binb, img, invdepth, call
+
+
+def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth):
+    """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
+    dL_dscales, dL_drotations); entries for absent inputs are None."""
+    lib = _lib.lib()
+    a, P, dev = call.args, call.P, call.device
+    f32 = dict(dtype=torch.float32, device=dev)
+    bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D, w, k = call.keep
+    dL_dcolor = dL_dcolor.to(torch.float32).contiguous()
+    use_depth = bool(a.do_depth) and dL_dinvdepth is not None
+    if use_depth:
+        dL_dinvdepth = dL_dinvdepth.to(torch.float32).contiguous()
+    g = _lib.RasterGrads()
+    d_m3 = torch.empty(P, 3, **f32)
+    d_m2 = torch.empty(P, 3, **f32)
+    d_op = torch.empty(P, 1, **f32)
+    d_sh = torch.empty_like(sh) if sh is not None else None
+    d_col = torch.empty(P, 3, **f32) if colors is not None else None
+    d_sc = torch.empty(P, 3, **f32) if scales is not None else None
+    d_rot = torch.empty(P, 4, **f32) if rotations is not None else None
+    d_cov = torch.empty(P, 6, **f32) if cov3D is not None else None
+    p = _lib.ptr
+    g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)
+    g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
+    bwd_bytes = C.c_size_t()
+    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L, None, None, None, C.byref(bwd_bytes)),
+               "hgs_raster_ws_sizes")
+    scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
+    _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L,
+                                  p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
+                                  p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),
+                                  dev.index or 0), "hgs_raster_bwd")
+    return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot
+
+
+def raster_views(call):
+    """Test/introspection helper: typed torch views of the sorted keys, point list, tile ranges, ..."""
+    lib = _lib.lib()
+    v = _lib.RasterViews()
+    _lib.check(lib.hgs_raster_views_get(call.P, call.W, call.H, call.L, _lib.ptr(call.geom), _lib.ptr(call.binb),
+                                        _lib.ptr(call.img), C.byref(v)), "hgs_raster_views_get")
+
+    def view(buf, addr, dtype, count):
+        off = addr - buf.data_ptr()
+        itemsize = torch.empty(0, dtype=dtype).element_size()
+        return buf[off:off + count * itemsize].view(dtype)
+
+    P, L, W, H = call.P, call.L, call.W, call.H
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    return {
+        "keys_sorted": view(call.binb, v.keys_sorted, torch.int64, L),
+        "point_list": view(call.binb, v.point_list, torch.int32, L),
+        "ranges": view(call.binb, v.ranges, torch.int32, T * 2).view(T, 2),
+        "tiles_touched": view(call.geom, v.tiles_touched, torch.int32, P),
+        "offsets": view(call.geom, v.offsets, torch.int32, P),
+        "depths": view(call.geom, v.depths, torch.float32, P),
+        "rects": view(call.geom, v.rects, torch.int32, P * 2).view(P, 2),
+        "records": view(call.geom, v.records, torch.float32, P * 12).view(P, 12),
+        "final_T": view(call.img, v.final_T, torch.float32, H * W).view(H, W),
+        "n_contrib": view(call.img, v.n_contrib, torch.int32, H * W).view(H, W),
+    }
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """Frustum test used by the upstream API (z > 0.2 in view space)."""
+    _require_gpu(means3D, "means3D")
+    vm = viewmatrix.to(torch.float32)
+    z = means3D @ vm[:3, 2] + vm[3, 2]
+    return z > 0.2

@@ -1,0 +1,105 @@
+"""Drop-in ``diff_gaussian_rasterization`` for AMD MI355X (gfx950).
+
+Same import names and call surface as the reference's hierarchy-rasterizer submodule
+(/root/reference/.gitmodules:4-6), as used by gaussian_renderer/__init__.py:14,17,44-64,
+105-113,247-277,319-389:
+
+    GaussianRasterizationSettings(image_height=..., ..., num_node_kids=...)   # 17 keyword fields
+    GaussianRasterizer(raster_settings=...)(means3D=..., means2D=..., shs=..., colors_precomp=...,
+        opacities=..., scales=..., rotations=..., cov3D_precomp=...) -> (color, radii, invdepth)
+    _C                                                                        # extension-module surface
+
+The op is a ``torch.autograd.Function`` over the C ABI of libhgs.so (hand-written HIP).  There
+is no CPU or PyTorch fallback: without the built library and a GPU every call raises.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+    render_indices: torch.Tensor
+    parent_indices: torch.Tensor
+    interpolation_weights: torch.Tensor
+    num_node_kids: torch.Tensor
+    do_depth: bool = False
+
+
+def _empty_like_none(t):
+    return t if t is not None else torch.Tensor([])
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                raster_settings):
+        rs = raster_settings
+        num_rendered, color, radii, geom, binb, img, invdepth, call = _C.rasterize_gaussians(
+            rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.render_indices, rs.parent_indices,
+            rs.interpolation_weights, rs.num_node_kids, rs.do_depth, getattr(_RasterizeGaussians, "variant", 0))
+        ctx.call = call
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(color, invdepth)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_invdepth):
+        color, invdepth = ctx.saved_tensors
+        call = ctx.call
+        if grad_color is None:
+            grad_color = torch.zeros_like(color)
+        d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(
+            call, color, invdepth, grad_color, grad_invdepth)
+        ctx.call = None
+        # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
+        return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, None
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, raster_settings)
+
+
+class GaussianRasterizer(nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            rs = self.raster_settings
+            return _C.mark_visible(positions, rs.viewmatrix, rs.projmatrix)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or \
+                ((scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                   cov3D_precomp, self.raster_settings)
+
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C"]

@@ -1,0 +1,143 @@
+"""Seeded synthetic workloads for the rasterizer hot path.
+
+Cameras follow the reference's conventions (scene/cameras.py:89-98,
+utils/graphics_utils.py:38-77): matrices are stored transposed (row-vector
+convention), ``full_proj = world_view @ projection``, +z forward, y down,
+znear 0.01 / zfar 100.  Everything is generated on the CPU from a
+``torch.Generator`` so the oracle and the GPU see identical bits.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+import torch
+
+
+@dataclass
+class Camera:
+    image_width: int
+    image_height: int
+    FoVx: float
+    FoVy: float
+    world_view_transform: torch.Tensor   # [4,4] stored (transposed) form
+    full_proj_transform: torch.Tensor    # [4,4]
+    camera_center: torch.Tensor          # [3]
+    znear: float = 0.01
+    zfar: float = 100.0
+
+    @property
+    def tanfovx(self):
+        return math.tan(self.FoVx * 0.5)
+
+    @property
+    def tanfovy(self):
+        return math.tan(self.FoVy * 0.5)
+
+    def to(self, device):
+        return Camera(self.image_width, self.image_height, self.FoVx, self.FoVy,
+                      self.world_view_transform.to(device), self.full_proj_transform.to(device),
+                      self.camera_center.to(device), self.znear, self.zfar)
+
+
+def projection_matrix(znear, zfar, fovx, fovy, primx=0.5, primy=0.5):
+    """Standard-orientation perspective matrix with P[3,2]=1 (z forward);
+    same contract as utils/graphics_utils.py:51-77."""
+    ty = math.tan(fovy / 2) * znear
+    tx = math.tan(fovx / 2) * znear
+    top, bottom = primy * 2 * ty, (1 - primy) * 2 * -ty
+    right, left = primx * 2 * tx, (1 - primx) * 2 * -tx
+    Pm = torch.zeros(4, 4)
+    Pm[0, 0] = 2.0 * znear / (right - left)
+    Pm[1, 1] = 2.0 * znear / (top - bottom)
+    Pm[0, 2] = (right + left) / (right - left)
+    Pm[1, 2] = (top + bottom) / (top - bottom)
+    Pm[3, 2] = 1.0
+    Pm[2, 2] = zfar / (zfar - znear)
+    Pm[2, 3] = -(zfar * znear) / (zfar - znear)
+    return Pm
+
+
+def make_camera(width, height, fovy_deg=60.0, R=None, T=None, znear=0.01, zfar=100.0) -> Camera:
+    """R: camera-to-world rotation (3x3, as scene/dataset_readers.py:89 stores it), T: world-to-camera
+    translation.  Defaults: camera at the origin looking down +z."""
+    fovy = math.radians(fovy_deg)
+    fy = height / (2.0 * math.tan(fovy / 2))
+    fovx = 2.0 * math.atan(width / (2.0 * fy))          # square pixels
+    R = np.eye(3) if R is None else np.asarray(R, dtype=np.float64)
+    T = np.zeros(3) if T is None else np.asarray(T, dtype=np.float64)
+    Rt = np.zeros((4, 4))
+    Rt[:3, :3] = R.T
+    Rt[:3, 3] = T
+    Rt[3, 3] = 1.0
+    wv = torch.tensor(np.float32(Rt)).transpose(0, 1).contiguous()
+    proj = projection_matrix(znear, zfar, fovx, fovy).transpose(0, 1)
+    full = (wv.unsqueeze(0).bmm(proj.unsqueeze(0))).squeeze(0).contiguous()
+    center = wv.inverse()[3, :3].contiguous()
+    return Camera(width, height, fovx, fovy, wv, full, center, znear, zfar)
+
+
+def orbit_camera(width, height, k, n, radius=0.6, fovy_deg=60.0) -> Camera:
+    """k-th of n cameras on a small circle around the origin, all looking roughly down +z
+    (per-view data-parallel workloads)."""
+    ang = 2 * math.pi * k / max(n, 1)
+    c = np.array([radius * math.cos(ang), radius * math.sin(ang), 0.0])
+    yaw = 0.05 * math.cos(ang)
+    pitch = 0.05 * math.sin(ang)
+    Ry = np.array([[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]])
+    Rx = np.array([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]])
+    Rc2w = Ry @ Rx
+    T = -Rc2w.T @ c
+    return make_camera(width, height, fovy_deg, R=Rc2w, T=T)
+
+
+@dataclass
+class Scene:
+    means3D: torch.Tensor      # [P,3]
+    scales: torch.Tensor       # [P,3] activated (exp)
+    rotations: torch.Tensor    # [P,4] normalised (w,x,y,z)
+    opacities: torch.Tensor    # [P,1] activated (sigmoid)
+    shs: torch.Tensor          # [P,M,3]
+    sh_degree: int
+
+    def to(self, device):
+        return Scene(*(t.to(device) for t in (self.means3D, self.scales, self.rotations,
+                                               self.opacities, self.shs)), self.sh_degree)
+
+    @property
+    def P(self):
+        return self.means3D.shape[0]
+
+
+def make_scene(P, cam: Camera, seed=0, sh_degree=3, s_px=(0.5, 4.0), z_range=(2.0, 20.0)) -> Scene:
+    """Frustum-filling Gaussians exactly as specified in SURVEY.md §8(d) / BASELINE.md §3."""
+    g = torch.Generator().manual_seed(seed)
+    U = lambda *s: torch.rand(*s, generator=g)
+    N = lambda *s: torch.randn(*s, generator=g)
+    z = z_range[0] + (z_range[1] - z_range[0]) * U(P)
+    x = z * cam.tanfovx * (2 * U(P) - 1)
+    y = z * cam.tanfovy * (2 * U(P) - 1)
+    means = torch.stack([x, y, z], 1)
+    fx = cam.image_width / (2.0 * cam.tanfovx)
+    spx = torch.exp(math.log(s_px[0]) + (math.log(s_px[1]) - math.log(s_px[0])) * U(P))
+    scales = (z * spx / fx)[:, None] * (0.3 + 0.7 * U(P, 3))
+    q = N(P, 4)
+    q = q / q.norm(dim=1, keepdim=True)
+    opac = (0.05 + 0.9 * U(P))[:, None]
+    M = (sh_degree + 1) ** 2
+    shs = torch.empty(P, M, 3)
+    shs[:, 0] = 0.5 * N(P, 3)
+    if M > 1:
+        shs[:, 1:] = 0.05 * N(P, M - 1, 3)
+    # camera-space -> world (camera may not sit at the origin)
+    wv = cam.world_view_transform.double()
+    c2w = wv.inverse()
+    mh = torch.cat([means.double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ c2w
+    return Scene(mh[:, :3].float().contiguous(), scales.contiguous(), q.contiguous(),
+                 opac.contiguous(), shs.contiguous(), sh_degree)
+
+
+def upstream_grads(H, W, seed=1):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)

@@ -1,0 +1,214 @@
+/*
+ * hgs.h -- C ABI of libhgs.so, the MI355X (gfx950) implementation of the
+ * hierarchical-3D-Gaussian rasterizer hot path.
+ *
+ * Plain C: raw device pointers, sizes and a hipStream_t passed as void*.  No
+ * torch / C++ types cross this boundary.  Every entry point below names the
+ * reference interface it stands in for (paths relative to the reference
+ * checkout, graphdeco-inria/hierarchical-3d-gaussians):
+ *
+ *   diff_gaussian_rasterization._C   (submodules/hierarchy-rasterizer, .gitmodules:4-6;
+ *                                     imported at gaussian_renderer/__init__.py:14,17)
+ *   gaussian_hierarchy._C            (submodules/gaussianhierarchy, .gitmodules:10-12;
+ *                                     imported at train_post.py:26, render_hierarchy.py:27,
+ *                                     scene/gaussian_model.py:24)
+ *   simple_knn._C                    (submodules/simple-knn, .gitmodules:7-9;
+ *                                     imported at scene/gaussian_model.py:21)
+ *
+ * Conventions
+ *   - return value 0 = success; anything else is an error code and
+ *     hgs_last_error() (thread-local) holds the message;
+ *   - every function that touches the GPU takes (stream, device) and calls
+ *     hipSetDevice(device) first -- backward runs on an autograd worker thread;
+ *   - all device buffers are caller-owned (torch's caching allocator in the
+ *     Python host); the library keeps no pointer after a call returns;
+ *   - matrices are the reference's stored (row-vector convention) [4,4]
+ *     float32 tensors, i.e. column-major standard matrices
+ *     (scene/cameras.py:95-97).
+ */
+#ifndef HGS_H
+#define HGS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HGS_ABI_VERSION 1
+#define HGS_TILE 16
+#define HGS_INST_GRAD_STRIDE 12 /* floats per (tile, Gaussian) instance in the backward scratch */
+
+enum {
+  HGS_OK = 0,
+  HGS_ERR_INVALID = 1, /* bad argument */
+  HGS_ERR_HIP = 2,     /* a HIP runtime call or kernel failed */
+  HGS_ERR_IO = 3,      /* file I/O */
+  HGS_ERR_NOMEM = 4
+};
+
+typedef void* hgs_stream_t; /* hipStream_t */
+
+int hgs_abi_version(void);
+const char* hgs_last_error(void);
+/* number of HIP devices visible; <0 on error.  Used by the host to fail loudly. */
+int hgs_device_count(void);
+
+/* ---------------------------------------------------------------------------
+ * Rasterizer.  Replaces diff_gaussian_rasterization._C.rasterize_gaussians /
+ * rasterize_gaussians_backward as called through GaussianRasterizer.forward
+ * (gaussian_renderer/__init__.py:64,105-113; :267-277; :339,381-389) with the
+ * settings of GaussianRasterizationSettings (:44-62).
+ * ------------------------------------------------------------------------- */
+typedef struct hgs_raster_args {
+  int32_t P;          /* Gaussians passed to the op */
+  int32_t M;          /* SH coefficients stored per Gaussian ((max_sh_degree+1)^2), 0 with colors_precomp */
+  int32_t sh_degree;  /* active degree 0..3 */
+  int32_t width, height;
+  float tanfovx, tanfovy;
+  float scale_modifier;
+  int32_t do_depth;   /* write the inverse-depth channel */
+  int32_t debug;      /* synchronise + check after every launch */
+  int32_t variant;    /* 0 = library default; >0 selects a render-kernel variant (bench/tuning only) */
+  int32_t reserved;
+  const float* bg;          /* device [3] */
+  const float* viewmatrix;  /* device [16] */
+  const float* projmatrix;  /* device [16] */
+  const float* campos;      /* device [3] */
+  const float* means3D;         /* [P,3] */
+  const float* shs;             /* [P,M,3] or NULL */
+  const float* colors_precomp;  /* [P,3]  or NULL (exactly one of shs / colors_precomp) */
+  const float* opacities;       /* [P] */
+  const float* scales;          /* [P,3] or NULL */
+  const float* rotations;       /* [P,4] or NULL */
+  const float* cov3D_precomp;   /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
+  const float* interpolation_weights; /* [>=P] or NULL : hierarchy mode (gaussian_renderer/__init__.py:262) */
+  const int32_t* num_node_kids;       /* [>=P] or NULL : hierarchy mode (gaussian_renderer/__init__.py:263) */
+} hgs_raster_args;
+
+/* Workspace sizes in bytes.  geom: per-Gaussian state (P); bin: per-instance
+ * keys/lists + tile ranges (L = number of (tile,Gaussian) instances, known after
+ * stage 1); img: per-pixel state; bwd: backward scratch. */
+int hgs_raster_ws_sizes(int32_t P, int32_t width, int32_t height, uint32_t L,
+                        size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes, size_t* bwd_bytes);
+
+/* Stage 1: per-Gaussian preprocess (cull, project, 3D->2D covariance, SH colour,
+ * tile rectangle) + offsets scan.  Writes radii[P]; returns L on the host (one
+ * 4-byte D2H copy + stream sync -- the only sync of the forward pass). */
+int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radii,
+                          uint32_t* L_out_host, hgs_stream_t stream, int device);
+
+/* Stage 2: key generation, radix sort by (tile|depth), tile ranges, tile
+ * compositing.  out_color [3,H,W], out_invdepth [1,H,W] (may be NULL when
+ * !do_depth). */
+int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws,
+                          uint32_t L, float* out_color, float* out_invdepth,
+                          hgs_stream_t stream, int device);
+
+typedef struct hgs_raster_grads {
+  float* dL_dmeans3D;   /* [P,3] */
+  float* dL_dmeans2D;   /* [P,3]  gradient w.r.t. NDC-scaled screen position (consumer: scene/gaussian_model.py:687-689) */
+  float* dL_dshs;       /* [P,M,3] or NULL */
+  float* dL_dcolors;    /* [P,3]  or NULL */
+  float* dL_dopacity;   /* [P] */
+  float* dL_dscales;    /* [P,3] or NULL */
+  float* dL_drotations; /* [P,4] or NULL */
+  float* dL_dcov3D;     /* [P,6] or NULL */
+} hgs_raster_grads;
+
+/* Backward.  Needs the forward outputs (out_color, out_invdepth) and the
+ * workspaces exactly as stage 2 left them.  dL_dinvdepth may be NULL. */
+int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bin_ws,
+                   const void* img_ws, void* bwd_ws, uint32_t L,
+                   const float* out_color, const float* out_invdepth,
+                   const float* dL_dcolor, const float* dL_dinvdepth,
+                   const hgs_raster_grads* grads, hgs_stream_t stream, int device);
+
+/* Introspection for the parity tests ("bit-exact on tile/sort indices"):
+ * device pointers into the workspaces after stage 2. */
+typedef struct hgs_raster_views {
+  const uint64_t* keys_sorted;   /* [L] (tile<<32 | depth bits) */
+  const uint32_t* point_list;    /* [L] Gaussian id per sorted instance */
+  const uint32_t* ranges;        /* [T,2] start,end per tile */
+  const uint32_t* tiles_touched; /* [P] */
+  const uint32_t* offsets;       /* [P] exclusive scan of tiles_touched */
+  const float* depths;           /* [P] view-space z */
+  const uint32_t* rects;         /* [P,2] packed (x | y<<16) min, max in tile units */
+  const float* records;          /* [P,12] per-Gaussian 2D record */
+  const float* final_T;          /* [H*W] */
+  const uint32_t* n_contrib;     /* [H*W] */
+} hgs_raster_views;
+int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, const void* geom_ws,
+                         const void* bin_ws, const void* img_ws, hgs_raster_views* out);
+
+/* Standalone device sort of (u64 key, u32 value) pairs, stable, LSD radix over
+ * bits [0, end_bit).  Exposed for the sort parity tests.  tmp_bytes from
+ * hgs_sort_tmp_bytes. Result lands in keys_out/vals_out. */
+size_t hgs_sort_tmp_bytes(uint32_t n);
+int hgs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out,
+                   uint32_t* vals_out, void* tmp, uint32_t n, int end_bit,
+                   hgs_stream_t stream, int device);
+
+/* Optional per-stage timing with hipEvents recorded on the caller's stream (bench.py's
+ * per-kernel roofline figures).  Off by default; no reference counterpart (the reference
+ * records CUDA events it never reads: train_single.py:41-42,86,124). */
+int hgs_timing_enable(int on);
+int hgs_timing_stage_count(void);
+const char* hgs_timing_stage_name(int i);
+/* Resolves all pending events (blocks until they completed) and returns the accumulated
+ * milliseconds and call counts per stage; reset != 0 clears the accumulators. */
+int hgs_timing_read(double* ms_out, uint32_t* calls_out, int reset);
+
+/* ---------------------------------------------------------------------------
+ * Hierarchy LOD cut.  Replaces gaussian_hierarchy._C.expand_to_size and
+ * get_interpolation_weights (train_post.py:91-113, render_hierarchy.py:58-80).
+ *   nodes int32 [N,7] = depth,parent,start,count_leafs,count_merged,start_children,count_children
+ *   boxes f32  [N,2,4] = min.xyz + extent, max.xyz + pad
+ * ------------------------------------------------------------------------- */
+size_t hgs_expand_tmp_bytes(int32_t N);
+/* Fills render_indices / parent_indices / nodes_for_render_indices (device, capacity
+ * `capacity` entries) and returns the number of entries in *count_out_host (host sync). */
+int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, float size,
+                       const float viewpoint[3], const float viewdir[3],
+                       int32_t* render_indices, int32_t* parent_indices,
+                       int32_t* nodes_for_render_indices, int32_t capacity, void* tmp,
+                       int32_t* count_out_host, hgs_stream_t stream, int device);
+int hgs_interp_weights(const int32_t* node_indices, int32_t n, float size, const int32_t* nodes,
+                       const float* boxes, int32_t N, const float viewpoint[3], const float viewdir[3],
+                       float* interpolation_weights, int32_t* num_siblings,
+                       hgs_stream_t stream, int device);
+
+/* ---------------------------------------------------------------------------
+ * simple_knn._C.distCUDA2 (scene/gaussian_model.py:190): mean squared distance
+ * to the 3 nearest neighbours.  tmp_bytes from hgs_knn_tmp_bytes.
+ * ------------------------------------------------------------------------- */
+size_t hgs_knn_tmp_bytes(int32_t P);
+int hgs_dist2_knn3(const float* xyz, int32_t P, float* out_mean_d2, void* tmp,
+                   hgs_stream_t stream, int device);
+
+/* ---------------------------------------------------------------------------
+ * .hier files.  Replaces gaussian_hierarchy._C.load_hierarchy / write_hierarchy
+ * (scene/gaussian_model.py:329,420-427).  Host memory only.
+ * ------------------------------------------------------------------------- */
+typedef struct hgs_hier_host {
+  int32_t P;      /* Gaussians */
+  int32_t N;      /* nodes */
+  int32_t M;      /* SH coefficients per Gaussian (16) */
+  int32_t reserved;
+  float* xyz;         /* [P,3] */
+  float* shs;         /* [P,M,3] */
+  float* alpha;       /* [P] activated opacity */
+  float* log_scales;  /* [P,3] */
+  float* rots;        /* [P,4] */
+  int32_t* nodes;     /* [N,7] */
+  float* boxes;       /* [N,2,4] */
+} hgs_hier_host;
+int hgs_hier_load(const char* path, hgs_hier_host* out); /* allocates; release with hgs_hier_free */
+int hgs_hier_write(const char* path, const hgs_hier_host* in);
+void hgs_hier_free(hgs_hier_host* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HGS_H */

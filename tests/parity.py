@@ -1,0 +1,149 @@
+"""Shared helpers of the GPU parity tests: run the HIP op and the CPU oracle on the same
+seeded inputs and report the differences.
+
+Tolerances (BASELINE.json north_star: 'bit-exact on tile/sort indices, within 1e-5 rel on
+pixels and gradients'):
+  * integers (radii, tile rects, depth bits, sorted keys, point list, tile ranges): exact;
+  * pixels / gradients: max|hip - oracle| <= REL_TOL * max|oracle| per tensor, and relative
+    L2 error <= REL_TOL, oracle in float64.  Pixels where the oracle reports a discrete blend
+    decision within 1e-5 (relative) of its threshold ("fragile": alpha vs 1/255, T vs 1e-4)
+    are excluded from the pixel comparison; their count is bounded by FRAGILE_FRAC.
+"""
+import math
+
+import numpy as np
+import torch
+
+from hgs import synth
+from oracle import raster_oracle as ro
+
+REL_TOL = 1e-5
+FRAGILE_FRAC = 1e-3
+
+
+def settings_kwargs(cam, bg, sh_degree, do_depth=True, debug=False, scale_modifier=1.0, device="cpu",
+                    interpolation_weights=None, num_node_kids=None):
+    e_i = torch.empty(0, dtype=torch.int32, device=device)
+    e_f = torch.empty(0, dtype=torch.float32, device=device)
+    return dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx,
+                tanfovy=cam.tanfovy, bg=bg.to(device), scale_modifier=scale_modifier,
+                viewmatrix=cam.world_view_transform.to(device), projmatrix=cam.full_proj_transform.to(device),
+                sh_degree=sh_degree, campos=cam.camera_center.to(device), prefiltered=False, debug=debug,
+                do_depth=do_depth, render_indices=e_i, parent_indices=e_i,
+                interpolation_weights=e_f if interpolation_weights is None else interpolation_weights.to(device),
+                num_node_kids=e_i if num_node_kids is None else num_node_kids.to(device))
+
+
+def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
+               interpolation_weights=None, num_node_kids=None, do_depth=True, dtype=torch.float64):
+    req = lambda t: None if t is None else t.clone().requires_grad_(True)
+    m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
+    sh = req(scene.shs) if colors_precomp is None else None
+    col = req(colors_precomp)
+    cov = req(cov3D_precomp)
+    if cov is not None:
+        sc = rot = None
+    m2 = torch.zeros(scene.P, 3, requires_grad=True)
+    out = ro.rasterize(m3, m2, sh, col, op, sc, rot, cov, image_height=cam.image_height,
+                       image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+                       scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform,
+                       projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree, campos=cam.camera_center,
+                       interpolation_weights=interpolation_weights, num_node_kids=num_node_kids, dtype=dtype)
+    loss = (out.color * gc.to(dtype)).sum()
+    if do_depth:
+        loss = loss + (out.invdepth * gd.to(dtype)).sum()
+    loss.backward()
+    grads = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad)
+    if sh is not None: grads["shs"] = sh.grad
+    if col is not None: grads["colors_precomp"] = col.grad
+    if sc is not None: grads["scales"] = sc.grad; grads["rotations"] = rot.grad
+    if cov is not None: grads["cov3D_precomp"] = cov.grad
+    return out, grads
+
+
+def run_hip(scene, cam, bg, gc, gd, device, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
+            interpolation_weights=None, num_node_kids=None, do_depth=True, variant=0, debug=True):
+    import diff_gaussian_rasterization as dgr
+    dgr._RasterizeGaussians.variant = variant
+    req = lambda t: None if t is None else t.clone().to(device).requires_grad_(True)
+    m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
+    sh = req(scene.shs) if colors_precomp is None else None
+    col = req(colors_precomp)
+    cov = req(cov3D_precomp)
+    if cov is not None:
+        sc = rot = None
+    m2 = torch.zeros(scene.P, 3, device=device, requires_grad=True)
+    rs = dgr.GaussianRasterizationSettings(**settings_kwargs(
+        cam, bg, scene.sh_degree, do_depth=do_depth, debug=debug, scale_modifier=scale_modifier, device=device,
+        interpolation_weights=interpolation_weights, num_node_kids=num_node_kids))
+    rast = dgr.GaussianRasterizer(raster_settings=rs)
+    color, radii, invd = rast(means3D=m3, means2D=m2, shs=sh, colors_precomp=col, opacities=op, scales=sc,
+                              rotations=rot, cov3D_precomp=cov)
+    call = color.grad_fn.call if color.grad_fn is not None else None
+    views = dgr._C.raster_views(call) if call is not None else None
+    views_cpu = {k: v.cpu().clone() for k, v in views.items()} if views else None
+    L = call.L if call is not None else 0
+    loss = (color * gc.to(device)).sum()
+    if do_depth:
+        loss = loss + (invd * gd.to(device)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad)
+    if sh is not None: grads["shs"] = sh.grad
+    if col is not None: grads["colors_precomp"] = col.grad
+    if sc is not None: grads["scales"] = sc.grad; grads["rotations"] = rot.grad
+    if cov is not None: grads["cov3D_precomp"] = cov.grad
+    dgr._RasterizeGaussians.variant = 0
+    return dict(color=color.detach().cpu(), radii=radii.cpu(), invdepth=invd.detach().cpu(), views=views_cpu, L=L,
+                grads={k: v.detach().cpu() for k, v in grads.items()})
+
+
+def err_stats(hip, ref):
+    a, b = hip.double().reshape(-1), ref.double().reshape(-1)
+    scale = b.abs().max().item()
+    if scale == 0:
+        return dict(maxrel=a.abs().max().item(), l2=a.norm().item(), scale=0.0)
+    return dict(maxrel=((a - b).abs().max() / scale).item(),
+                l2=((a - b).norm() / b.norm()).item(), scale=scale)
+
+
+def check_indices(hip, oracle_out):
+    """Bit-exact comparison of every integer the forward produces.  Returns a dict of mismatch counts."""
+    geom, binning = oracle_out.geom, oracle_out.binning
+    v = hip["views"]
+    res = {}
+    res["radii"] = int((hip["radii"].numpy() != geom.radii).sum())
+    res["tiles_touched"] = int((v["tiles_touched"].numpy().astype(np.uint32) != geom.tiles_touched).sum())
+    res["num_rendered"] = abs(int(hip["L"]) - int(binning.num_rendered))
+    vis = geom.visible
+    res["depth_bits"] = int((v["depths"].numpy().view(np.uint32)[vis] != geom.depth.view(np.uint32)[vis]).sum())
+    rects = v["rects"].numpy().astype(np.uint32)
+    rmin = (geom.rect_min[:, 0].astype(np.uint32) | (geom.rect_min[:, 1].astype(np.uint32) << 16))
+    rmax = (geom.rect_max[:, 0].astype(np.uint32) | (geom.rect_max[:, 1].astype(np.uint32) << 16))
+    res["rects"] = int(((rects[:, 0] != rmin) | (rects[:, 1] != rmax))[vis].sum())
+    if res["num_rendered"] == 0:
+        excl = np.cumsum(geom.tiles_touched.astype(np.int64)) - geom.tiles_touched
+        res["offsets"] = int((v["offsets"].numpy().astype(np.int64)[vis] != excl[vis]).sum())
+        res["keys_sorted"] = int((v["keys_sorted"].numpy().view(np.uint64) != binning.keys_sorted).sum())
+        res["point_list"] = int((v["point_list"].numpy() != binning.point_list).sum())
+        res["ranges"] = int((v["ranges"].numpy() != binning.ranges).sum())
+    return res
+
+
+def compare(hip, oracle_out, oracle_grads, do_depth=True):
+    ok = torch.from_numpy(~oracle_out.fragile)
+    stats = {"fragile_frac": float(oracle_out.fragile.mean())}
+    c_h, c_o = hip["color"][:, ok], oracle_out.color.detach()[:, ok]
+    stats["color"] = err_stats(c_h, c_o)
+    if do_depth:
+        stats["invdepth"] = err_stats(hip["invdepth"][:, ok], oracle_out.invdepth.detach()[:, ok])
+    for k, g in oracle_grads.items():
+        stats["d_" + k] = err_stats(hip["grads"][k], g)
+    return stats
+
+
+def default_case(P, W, H, seed=0, sh_degree=3, fovy=60.0):
+    cam = synth.make_camera(W, H, fovy)
+    scene = synth.make_scene(P, cam, seed=seed, sh_degree=sh_degree)
+    gc, gd = synth.upstream_grads(H, W)
+    return cam, scene, gc, gd

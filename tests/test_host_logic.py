@@ -1,0 +1,78 @@
+"""Host-side behaviour that needs no GPU: the op surface the reference's glue expects
+(gaussian_renderer/__init__.py:44-64,105-113,247-277), loud failure without a GPU, .hier I/O."""
+import inspect
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import diff_gaussian_rasterization as dgr
+from hgs import synth
+
+
+def test_settings_fields_match_reference_call_sites():
+    # keyword set used at gaussian_renderer/__init__.py:44-62 (render) and :247-265 (render_post)
+    expected = {"image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix",
+                "projmatrix", "sh_degree", "campos", "prefiltered", "debug", "do_depth", "render_indices",
+                "parent_indices", "interpolation_weights", "num_node_kids"}
+    assert set(dgr.GaussianRasterizationSettings._fields) == expected
+    sig = inspect.signature(dgr.GaussianRasterizer.forward)
+    assert list(sig.parameters)[1:] == ["means3D", "means2D", "opacities", "shs", "colors_precomp", "scales",
+                                        "rotations", "cov3D_precomp"]
+    assert hasattr(dgr, "_C")                                   # imported at gaussian_renderer/__init__.py:17
+
+
+def test_op_fails_loudly_without_gpu_and_never_falls_back():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cam = synth.make_camera(32, 32)
+    e_i, e_f = torch.empty(0, dtype=torch.int32), torch.empty(0)
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=32, image_width=32, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+        campos=cam.camera_center, prefiltered=False, debug=False, do_depth=True, render_indices=e_i,
+        parent_indices=e_i, interpolation_weights=e_f, num_node_kids=e_i)
+    sc = synth.make_scene(8, cam)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dgr.GaussianRasterizer(rs)(means3D=sc.means3D, means2D=torch.zeros(8, 3), shs=sc.shs, opacities=sc.opacities,
+                                   scales=sc.scales, rotations=sc.rotations)
+    import simple_knn._C as knn
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        knn.distCUDA2(torch.zeros(4, 3))
+
+
+def test_product_code_never_imports_the_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "hierarchical-3d-gaussians_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, os.path.join(dirpath, f)
+
+
+def test_hier_roundtrip(tmp_path):
+    from gaussian_hierarchy._C import load_hierarchy, write_hierarchy
+    from hgs import hierarchy
+    cam = synth.make_camera(64, 64)
+    sc = synth.make_scene(37, cam, seed=4)
+    h = hierarchy.build_hierarchy(sc)
+    path = str(tmp_path / "toy.hier")
+    write_hierarchy(path, h.xyz, h.shs, h.alpha, h.log_scales, h.rots, h.nodes, h.boxes)
+    xyz, shs, alpha, ls, rots, nodes, boxes = load_hierarchy(path)
+    assert shs.shape == (h.xyz.shape[0], 16, 3) and alpha.shape == (h.xyz.shape[0], 1)
+    assert nodes.dtype == torch.int32 and nodes.shape[1] == 7 and boxes.shape[1:] == (2, 4)
+    for a, b in ((xyz, h.xyz), (shs, h.shs), (alpha, h.alpha), (ls, h.log_scales), (rots, h.rots),
+                 (nodes, h.nodes), (boxes, h.boxes)):
+        assert torch.equal(a, b)
+    with pytest.raises(RuntimeError):
+        load_hierarchy(str(tmp_path / "missing.hier"))
+    bad = tmp_path / "bad.hier"
+    bad.write_bytes(b"NOTAHIER" + b"\0" * 64)
+    with pytest.raises(RuntimeError, match="HGSHIER1"):
+        load_hierarchy(str(bad))
+    trunc = tmp_path / "trunc.hier"
+    trunc.write_bytes(open(path, "rb").read()[:200])
+    with pytest.raises(RuntimeError, match="truncated"):
+        load_hierarchy(str(trunc))

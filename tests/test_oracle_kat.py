@@ -1,0 +1,151 @@
+"""Hand-derivable known answers for the oracle + internal consistency:
+vectorised blend == literal per-pixel loop; float32 geometry spec == float64 torch geometry."""
+import math
+
+import numpy as np
+import torch
+
+from hgs import synth
+from oracle import raster_oracle as ro
+
+
+def _render(scene, cam, bg=None, **kw):
+    bg = torch.zeros(3) if bg is None else bg
+    return ro.rasterize(scene.means3D, None, scene.shs, None, scene.opacities, scene.scales, scene.rotations, None,
+                        image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx,
+                        tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                        projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree, campos=cam.camera_center, **kw)
+
+
+def _one(z=4.0, s=0.05, o=0.8, dc=(1.0, 0.0, -1.0), xy=(0.0, 0.0)):
+    sc = synth.Scene(torch.tensor([[xy[0], xy[1], z]]), torch.full((1, 3), s), torch.tensor([[1.0, 0, 0, 0]]),
+                     torch.tensor([[o]]), torch.zeros(1, 16, 3), 3)
+    sc.shs[0, 0] = torch.tensor(dc)
+    return sc
+
+
+def test_single_isotropic_gaussian_on_axis():
+    cam = synth.make_camera(64, 48)
+    out = _render(_one(), cam)
+    fy = 48 / (2 * cam.tanfovy)
+    var = (fy * 0.05 / 4.0) ** 2 + 0.3
+    cx, cy = 31.5, 23.5
+    ys, xs = torch.meshgrid(torch.arange(48.0), torch.arange(64.0), indexing="ij")
+    alpha = torch.clamp(0.8 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * var)), max=0.99)
+    alpha = torch.where(alpha < 1 / 255.0, torch.zeros_like(alpha), alpha).double()
+    rad = math.ceil(3 * math.sqrt(var))
+    assert int(out.radii[0]) == rad
+    mask = torch.zeros(48, 64, dtype=torch.bool)
+    mask[16:32, 16:48] = True                                     # the Gaussian's 3-sigma tile rectangle
+    expect = torch.where(mask, alpha, torch.zeros_like(alpha))
+    c0 = 0.5 + 0.28209479177387814
+    assert (out.color[0] - c0 * expect).abs().max() < 1e-7
+    assert (out.color[1] - 0.5 * expect).abs().max() < 1e-7
+    assert (out.color[2] - (0.5 - 0.28209479177387814) * expect).abs().max() < 1e-7
+    assert (out.invdepth[0] - expect / 4.0).abs().max() < 1e-7
+    assert abs(out.final_T[24, 32] - (1 - float(expect[24, 32]))) < 1e-7
+
+
+def test_two_gaussians_depth_order_independent_of_input_order():
+    cam = synth.make_camera(48, 48)
+    a, b = _one(z=3.0, o=0.6, dc=(1, 1, 1)), _one(z=6.0, s=0.2, o=0.9, dc=(-1, 0, 1))
+    cat = lambda f, g: torch.cat([f, g])
+    def scene(x, y):
+        return synth.Scene(cat(x.means3D, y.means3D), cat(x.scales, y.scales), cat(x.rotations, y.rotations),
+                           cat(x.opacities, y.opacities), cat(x.shs, y.shs), 3)
+    o1, o2 = _render(scene(a, b), cam), _render(scene(b, a), cam)
+    assert torch.equal(o1.color, o2.color)
+    # centre pixel: C = c1 a1 + c2 a2 (1 - a1)
+    oa, ob = _render(a, cam), _render(b, cam)
+    y, x = 24, 24
+    a1 = 1 - oa.final_T[y, x]
+    assert abs(float(o1.color[0, y, x]) - float(oa.color[0, y, x] + ob.color[0, y, x] * (1 - a1))) < 1e-9
+
+
+def test_near_plane_cull_and_background_passthrough():
+    cam = synth.make_camera(32, 32)
+    bg = torch.tensor([0.2, 0.4, 0.6])
+    out = _render(_one(z=0.2), cam, bg)                           # z <= 0.2 is culled
+    assert int(out.radii[0]) == 0 and out.binning.num_rendered == 0
+    assert torch.allclose(out.color, bg.double()[:, None, None].expand(3, 32, 32))
+    assert float(out.invdepth.abs().max()) == 0.0
+    out = _render(_one(z=0.2001), cam, bg)
+    assert int(out.radii[0]) > 0
+
+
+def test_vectorised_blend_equals_literal_per_pixel_loop():
+    cam = synth.make_camera(40, 24)
+    scene = synth.make_scene(60, cam, seed=5, s_px=(1.0, 6.0))
+    bg = torch.tensor([0.1, 0.0, 0.3])
+    out = _render(scene, cam, bg)
+    geom, binning = out.geom, out.binning
+    # continuous per-Gaussian values in float64, computed independently of rasterize()
+    p = scene.means3D.double()
+    ph = torch.cat([p, torch.ones(scene.P, 1, dtype=torch.float64)], 1) @ cam.full_proj_transform.double()
+    ndc = ph[:, :2] / (ph[:, 3:4] + 1e-7)
+    gx = ((ndc[:, 0] + 1) * 40 - 1) * 0.5
+    gy = ((ndc[:, 1] + 1) * 24 - 1) * 0.5
+    d = p - cam.camera_center.double()
+    d = d / d.norm(dim=1, keepdim=True)
+    rgb = torch.clamp_min(ro.eval_sh_torch(3, scene.shs.double(), d) + 0.5, 0)
+    tz = (torch.cat([p, torch.ones(scene.P, 1, dtype=torch.float64)], 1) @ cam.world_view_transform.double())[:, 2]
+    ref, dep = ro.naive_per_pixel_blend(gx.numpy(), gy.numpy(), geom.conic.astype(np.float64),
+                                        scene.opacities.double().reshape(-1).numpy(), rgb.numpy(), (1 / tz).numpy(),
+                                        binning.point_list, binning.ranges, 40, 24, bg.double().numpy())
+    ok = ~out.fragile
+    assert np.abs(out.color.numpy() - ref)[:, ok].max() < 5e-6      # conic: float32 spec vs float64 torch
+    assert np.abs(out.invdepth.numpy()[0] - dep)[ok].max() < 5e-6
+
+
+def test_binning_spec_invariants():
+    cam = synth.make_camera(200, 120)
+    scene = synth.make_scene(3000, cam, seed=2)
+    out = _render(scene, cam, tiles=[])
+    g, b = out.geom, out.binning
+    assert b.num_rendered == int(g.tiles_touched.sum())
+    assert np.all(b.keys_sorted[1:] >= b.keys_sorted[:-1])
+    tiles = (b.keys_sorted >> np.uint64(32)).astype(np.int64)
+    cnt = np.bincount(tiles, minlength=b.ranges.shape[0])
+    assert np.array_equal(b.ranges[:, 1] - b.ranges[:, 0], cnt)
+    # stability: equal keys keep ascending Gaussian order
+    same = b.keys_sorted[1:] == b.keys_sorted[:-1]
+    assert np.all(b.point_list[1:][same] > b.point_list[:-1][same])
+    # every instance's tile lies inside its Gaussian's rectangle
+    gx = g.grid[0]
+    tx, ty = tiles % gx, tiles // gx
+    pl = b.point_list
+    assert np.all((tx >= g.rect_min[pl, 0]) & (tx < g.rect_max[pl, 0]) & (ty >= g.rect_min[pl, 1]) & (ty < g.rect_max[pl, 1]))
+
+
+def test_oracle_gradients_match_finite_differences():
+    cam = synth.make_camera(32, 32)
+    scene = synth.make_scene(12, cam, seed=9, s_px=(2.0, 6.0))
+    gc, gd = synth.upstream_grads(32, 32)
+    def loss_of(m3, op):
+        o = ro.rasterize(m3, None, scene.shs, None, op, scene.scales, scene.rotations, None, image_height=32,
+                         image_width=32, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3),
+                         scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                         sh_degree=3, campos=cam.camera_center)
+        return (o.color * gc.double()).sum() + (o.invdepth * gd.double()).sum()
+    m3 = scene.means3D.double().clone().requires_grad_(True)
+    op = scene.opacities.double().clone().requires_grad_(True)
+    loss_of(m3, op).backward()
+    eps = 1e-6
+    for (i, j) in [(0, 0), (3, 1), (7, 2)]:
+        d = torch.zeros_like(m3); d[i, j] = eps
+        fd = (loss_of((m3 + d).detach(), op.detach()) - loss_of((m3 - d).detach(), op.detach())) / (2 * eps)
+        assert abs(float(fd) - float(m3.grad[i, j])) <= 1e-4 * max(1.0, abs(float(fd))), (i, j, float(fd), float(m3.grad[i, j]))
+    d = torch.zeros_like(op); d[5, 0] = eps
+    fd = (loss_of(m3.detach(), (op + d).detach()) - loss_of(m3.detach(), (op - d).detach())) / (2 * eps)
+    assert abs(float(fd) - float(op.grad[5, 0])) <= 1e-4 * max(1.0, abs(float(fd)))
+
+
+def test_lod_opacity_identity_and_stacking():
+    o = torch.tensor([0.1, 0.5, 0.9, 1.4], dtype=torch.float64)
+    w = torch.tensor([0.0, 0.3, 1.0, 0.5], dtype=torch.float64)
+    kids1 = torch.tensor([1, 1, 1, 1], dtype=torch.int32)
+    assert torch.equal(ro.lod_opacity(o, w, kids1), o)
+    kids = torch.tensor([3, 3, 3, 3], dtype=torch.int32)
+    r = ro.lod_opacity(o, torch.zeros(4, dtype=torch.float64), kids)
+    assert torch.allclose(1 - (1 - r[:3]) ** 3, o[:3])            # k stacked copies composite like the parent
+    assert torch.allclose(ro.lod_opacity(o, torch.ones(4, dtype=torch.float64), kids), o)

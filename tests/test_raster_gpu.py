@@ -1,0 +1,247 @@
+"""GPU parity tests of the rasterizer hot path: HIP (through the C ABI) vs the CPU oracle.
+
+Mirrors how the reference calls the op (gaussian_renderer/__init__.py:44-64,105-113 for the
+single-chunk path; :247-277 for the hierarchy path)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import parity as pa
+from hgs import synth
+
+pytestmark = pytest.mark.gpu
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _log(name, payload):
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "parity_log.jsonl"), "a") as f:
+            f.write(json.dumps({"case": name, **payload}, default=float) + "\n")
+    except OSError:
+        pass
+
+
+def _assert_case(name, hip, oo, og, do_depth=True):
+    idx = pa.check_indices(hip, oo)
+    st = pa.compare(hip, oo, og, do_depth=do_depth)
+    _log(name, {"indices": idx, "stats": st})
+    print(name, "indices", idx)
+    for k, v in st.items():
+        print("   ", k, v)
+    assert all(v == 0 for v in idx.values()), f"{name}: integer mismatch {idx}"
+    assert st["fragile_frac"] <= pa.FRAGILE_FRAC
+    for k, v in st.items():
+        if k == "fragile_frac":
+            continue
+        assert v["maxrel"] <= pa.REL_TOL, f"{name}: {k} max error {v['maxrel']:.3e} (rel. to max) > {pa.REL_TOL}"
+        assert v["l2"] <= pa.REL_TOL, f"{name}: {k} rel-L2 error {v['l2']:.3e} > {pa.REL_TOL}"
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2])
+def test_config1_1k_128(gpu, variant):
+    """BASELINE.json configs[0]: 1k random Gaussians, 128x128, fwd + bwd, every strip layout."""
+    cam, scene, gc, gd = pa.default_case(1000, 128, 128)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, variant=variant)
+    _assert_case(f"config1_v{variant}", hip, oo, og)
+
+
+def test_ragged_image_and_sh_degrees(gpu):
+    """Image size not a multiple of 16; every active SH degree."""
+    for deg in (0, 1, 2, 3):
+        cam, scene, gc, gd = pa.default_case(700, 200, 120, seed=3 + deg)
+        scene.sh_degree = deg
+        bg = torch.tensor([0.0, 0.0, 0.0])
+        oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+        hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+        _assert_case(f"ragged_deg{deg}", hip, oo, og)
+
+
+def test_dense_early_termination(gpu):
+    """Large opaque Gaussians: exercises T < 1e-4 termination and the 0.99 alpha cap."""
+    cam = synth.make_camera(96, 80)
+    scene = synth.make_scene(1500, cam, seed=11, s_px=(3.0, 12.0))
+    scene.opacities = (0.6 + 0.39 * torch.rand(scene.P, 1, generator=torch.Generator().manual_seed(5)))
+    gc, gd = synth.upstream_grads(80, 96)
+    bg = torch.tensor([1.0, 1.0, 1.0])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    assert (oo.final_T < 1e-3).mean() > 0.2, "case should saturate a good share of the pixels"
+    _assert_case("dense", hip, oo, og)
+
+
+def test_precomputed_colour_and_covariance(gpu):
+    """The pipe.convert_SHs_python / pipe.compute_cov3D_python branches
+    (gaussian_renderer/__init__.py:75-76,84-89): colours and 3D covariances handed in."""
+    from oracle import raster_oracle as ro
+    cam, scene, gc, gd = pa.default_case(800, 128, 96, seed=21)
+    bg = torch.tensor([0.2, 0.1, 0.0])
+    cols = torch.rand(scene.P, 3, generator=torch.Generator().manual_seed(9))
+    cov = torch.from_numpy(ro.cov3d_spec(scene.scales.numpy(), scene.rotations.numpy(), 1.0))
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, colors_precomp=cols, cov3D_precomp=cov)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, colors_precomp=cols, cov3D_precomp=cov)
+    _assert_case("precomp", hip, oo, og)
+
+
+def test_python_twins_agree(gpu):
+    """op(shs) == op(colors_precomp = clamp(eval_sh + 0.5)) and op(scales, rot) == op(cov3D):
+    the equivalence the reference's --convert_SHs_python / --compute_cov3D_python flags rely on."""
+    from oracle import raster_oracle as ro
+    cam, scene, gc, gd = pa.default_case(600, 112, 112, seed=31)
+    bg = torch.zeros(3)
+    d = scene.means3D - cam.camera_center[None]
+    d = d / d.norm(dim=1, keepdim=True)
+    cols = torch.clamp_min(ro.eval_sh_torch(3, scene.shs, d) + 0.5, 0.0)
+    cov = torch.from_numpy(ro.cov3d_spec(scene.scales.numpy(), scene.rotations.numpy(), 1.0))
+    a = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    b = pa.run_hip(scene, cam, bg, gc, gd, gpu, colors_precomp=cols, cov3D_precomp=cov)
+    assert torch.equal(a["radii"], b["radii"])
+    assert (a["color"] - b["color"]).abs().max() < 2e-6
+    assert (a["grads"]["means2D"] - b["grads"]["means2D"]).abs().max() <= 1e-5 * a["grads"]["means2D"].abs().max()
+
+
+def test_hierarchy_mode_opacity(gpu):
+    """render_post path: interpolation_weights / num_node_kids non-empty, do_depth False, opacities may
+    exceed 1 (abs activation, scene/gaussian_model.py:393)."""
+    cam, scene, gc, gd = pa.default_case(900, 128, 128, seed=41)
+    g = torch.Generator().manual_seed(42)
+    scene.opacities = scene.opacities * 1.3
+    w = torch.rand(scene.P + 50, generator=g)
+    kids = torch.randint(1, 5, (scene.P + 50,), generator=g, dtype=torch.int32)
+    bg = torch.zeros(3)
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, interpolation_weights=w, num_node_kids=kids, do_depth=False)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, interpolation_weights=w, num_node_kids=kids, do_depth=False)
+    _assert_case("hier_opacity", hip, oo, og, do_depth=False)
+
+
+def test_scale_modifier_and_moved_camera(gpu):
+    cam = synth.orbit_camera(160, 96, 1, 5)
+    scene = synth.make_scene(900, cam, seed=51)
+    gc, gd = synth.upstream_grads(96, 160)
+    bg = torch.tensor([0.3, 0.3, 0.3])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, scale_modifier=0.7)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, scale_modifier=0.7)
+    _assert_case("scale_mod", hip, oo, og)
+
+
+def test_edge_cases(gpu):
+    """Empty scene, everything behind the near plane, a single Gaussian."""
+    import diff_gaussian_rasterization as dgr
+    cam = synth.make_camera(64, 48)
+    bg = torch.tensor([0.25, 0.5, 0.75])
+    # (1) P = 0
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, bg, 3, device=gpu))
+    z = lambda *s: torch.zeros(*s, device=gpu)
+    color, radii, invd = dgr.GaussianRasterizer(rs)(means3D=z(0, 3), means2D=z(0, 3), shs=z(0, 16, 3),
+                                                    opacities=z(0, 1), scales=z(0, 3), rotations=z(0, 4))
+    assert torch.allclose(color.cpu(), bg[:, None, None].expand(3, 48, 64))
+    assert invd.abs().max() == 0 and radii.numel() == 0
+    # (2) all culled: z <= 0.2
+    scene = synth.make_scene(100, cam, seed=1)
+    scene.means3D[:, 2] = 0.1
+    gc, gd = synth.upstream_grads(48, 64)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    assert (hip["radii"] == 0).all() and hip["L"] == 0
+    assert torch.allclose(hip["color"], bg[:, None, None].expand(3, 48, 64))
+    assert all(float(g.abs().max()) == 0.0 for g in hip["grads"].values())
+    # (3) one Gaussian on the optical axis: analytic known answer (SURVEY App. D KAT 1)
+    one = synth.Scene(torch.tensor([[0.0, 0.0, 4.0]]), torch.full((1, 3), 0.05), torch.tensor([[1.0, 0, 0, 0]]),
+                      torch.tensor([[0.8]]), torch.zeros(1, 16, 3), 3)
+    one.shs[0, 0] = torch.tensor([1.0, 0.0, -1.0])
+    hip = pa.run_hip(one, cam, torch.zeros(3), gc, gd, gpu)
+    fy = 48 / (2 * cam.tanfovy)
+    var = (fy * 0.05 / 4.0) ** 2 + 0.3
+    cx, cy = (64 - 1) / 2.0, (48 - 1) / 2.0
+    ys, xs = torch.meshgrid(torch.arange(48.0), torch.arange(64.0), indexing="ij")
+    alpha = torch.clamp(0.8 * torch.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * var)), max=0.99)
+    alpha = torch.where(alpha < 1 / 255.0, torch.zeros_like(alpha), alpha)
+    rad = int(np.ceil(3 * np.sqrt(var)))
+    assert int(hip["radii"][0]) == rad
+    c0 = 0.5 + 0.28209479177387814
+    tile_mask = torch.zeros(48, 64, dtype=torch.bool)
+    x0, x1 = int((cx - rad) // 16), int((cx + rad + 15) // 16)
+    y0, y1 = int((cy - rad) // 16), int((cy + rad + 15) // 16)
+    tile_mask[y0 * 16:y1 * 16, x0 * 16:x1 * 16] = True
+    expect = torch.where(tile_mask, alpha, torch.zeros_like(alpha))
+    assert (hip["color"][0] - c0 * expect).abs().max() < 2e-6
+    assert (hip["color"][1] - 0.5 * expect).abs().max() < 2e-6
+    assert (hip["invdepth"][0] - expect / 4.0).abs().max() < 2e-6
+
+
+def test_rejects_bad_inputs(gpu):
+    import diff_gaussian_rasterization as dgr
+    cam = synth.make_camera(32, 32)
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    r = dgr.GaussianRasterizer(rs)
+    z = lambda *s: torch.zeros(*s, device=gpu)
+    with pytest.raises(Exception):
+        r(means3D=z(4, 3), means2D=z(4, 3), opacities=z(4, 1), scales=z(4, 3), rotations=z(4, 4))  # no colour
+    with pytest.raises(Exception):
+        r(means3D=z(4, 3), means2D=z(4, 3), shs=z(4, 16, 3), opacities=z(4, 1), scales=z(4, 3))   # no rotation
+    with pytest.raises(RuntimeError):
+        r(means3D=torch.zeros(4, 3), means2D=z(4, 3), shs=z(4, 16, 3), opacities=z(4, 1), scales=z(4, 3),
+          rotations=z(4, 4))                                                                         # CPU tensor
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 8), (63, 13), (4097, 38), (100000, 45), (1 << 20, 47), (300001, 64)])
+def test_sort_pairs_is_a_stable_sort(gpu, n, end_bit):
+    """K4 alone: bit-exact against numpy's stable argsort, with many duplicate keys."""
+    import ctypes as C
+    from hgs import _lib
+    lib = _lib.lib()
+    rng = np.random.default_rng(n)
+    hi = (1 << end_bit) - 1 if end_bit < 64 else (1 << 64) - 1
+    keys = rng.integers(0, min(hi, 1 << 62), size=n, dtype=np.uint64)
+    keys[rng.random(n) < 0.5] &= np.uint64(0xFF)            # heavy duplication
+    keys &= np.uint64(hi)
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    k_in = torch.from_numpy(keys.view(np.int64)).to(gpu)
+    v_in = torch.from_numpy(vals.view(np.int32)).to(gpu)
+    k_out, v_out = torch.empty_like(k_in), torch.empty_like(v_in)
+    tmp = torch.empty(lib.hgs_sort_tmp_bytes(n), dtype=torch.uint8, device=gpu)
+    p = _lib.ptr
+    _lib.check(lib.hgs_sort_pairs(p(k_in), p(v_in), p(k_out), p(v_out), p(tmp), n, end_bit,
+                                  C.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "sort")
+    torch.cuda.synchronize()
+    assert np.array_equal(k_out.cpu().numpy().view(np.uint64), keys[order])
+    assert np.array_equal(v_out.cpu().numpy().view(np.uint32), vals[order])
+    assert np.array_equal(k_in.cpu().numpy().view(np.uint64), keys), "input must be left intact"
+
+
+def test_full_size_properties(gpu):
+    """BASELINE metric size (1080p, 1M Gaussians): size-independent properties instead of the oracle --
+    sortedness of the keys, ranges consistent with the keys, transmittance in [0,1], determinism of the
+    forward, finite gradients, zero gradient for culled Gaussians."""
+    cam = synth.make_camera(1920, 1080)
+    scene = synth.make_scene(1_000_000, cam, seed=0)
+    gc, gd = synth.upstream_grads(1080, 1920)
+    bg = torch.zeros(3)
+    a = pa.run_hip(scene, cam, bg, gc, gd, gpu, debug=False)
+    b = pa.run_hip(scene, cam, bg, gc, gd, gpu, debug=False)
+    keys = a["views"]["keys_sorted"].numpy().view(np.uint64)
+    assert a["L"] == int(a["views"]["tiles_touched"].numpy().astype(np.int64).sum())
+    assert np.all(keys[1:] >= keys[:-1])
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    rng_ = a["views"]["ranges"].numpy().astype(np.int64)
+    cnt = np.bincount(tiles, minlength=rng_.shape[0])
+    assert np.array_equal(rng_[:, 1] - rng_[:, 0], cnt)
+    ft = a["views"]["final_T"]
+    assert float(ft.min()) >= 0.0 and float(ft.max()) <= 1.0
+    assert torch.equal(a["color"], b["color"]) and torch.equal(a["views"]["point_list"], b["views"]["point_list"])
+    for k, g in a["grads"].items():
+        assert torch.isfinite(g).all(), k
+        assert torch.equal(g, b["grads"][k]), f"{k}: backward must be deterministic (S=4 path has no float atomics)"
+    culled = a["radii"] == 0
+    assert float(a["grads"]["means3D"][culled].abs().sum()) == 0.0
+    # depth order inside every tile range
+    pl = a["views"]["point_list"].numpy()
+    d = a["views"]["depths"].numpy()[pl]
+    same_tile = tiles[1:] == tiles[:-1]
+    assert np.all(d[1:][same_tile] >= d[:-1][same_tile])
