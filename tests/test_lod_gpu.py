@@ -1,0 +1,91 @@
+"""GPU parity of the hierarchy LOD cut, distCUDA2 and the render_post-style hierarchy rendering flow
+(train_post.py:91-129, render_hierarchy.py:58-92) against the CPU oracles.  Index outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from hgs import hierarchy, synth
+from oracle import lod_oracle as lo
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(P, gpu, seed=2):
+    cam = synth.make_camera(256, 160)
+    h = hierarchy.build_hierarchy(synth.make_scene(P, cam, seed=seed))
+    return h, cam, h.nodes.to(gpu), h.boxes.to(gpu)
+
+
+@pytest.mark.parametrize("P", [1, 2, 1000, 50_000])
+def test_expand_to_size_and_weights_match_oracle(gpu, P):
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    h, cam, nodes, boxes = _setup(P, gpu)
+    G = h.xyz.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu)
+    pi = torch.zeros(G, dtype=torch.int32, device=gpu)
+    ni = torch.zeros(G, dtype=torch.int32, device=gpu)
+    w = torch.zeros(G, dtype=torch.float32, device=gpu)
+    ns = torch.zeros(G, dtype=torch.int32, device=gpu)
+    for vp in (torch.tensor([0.0, 0.0, 0.0]), torch.tensor([0.3, -0.1, 5.0]), torch.tensor([1.0, 2.0, -4.0])):
+        for tau in (0.0, 0.002, 0.01, 0.06, 0.5, 1e4):
+            # call shapes exactly as train_post.py:91-113: viewpoint on the GPU for expand, CPU for the weights
+            n = expand_to_size(nodes, boxes, tau, vp.to(gpu), torch.zeros(3), ri, pi, ni)
+            r_o, p_o, n_o = lo.expand_to_size(h.nodes.numpy(), h.boxes.numpy(), tau, vp.numpy())
+            assert n == len(r_o), (P, tau, n, len(r_o))
+            assert np.array_equal(ri[:n].cpu().numpy(), r_o)
+            assert np.array_equal(pi[:n].cpu().numpy(), p_o)
+            assert np.array_equal(ni[:n].cpu().numpy(), n_o)
+            get_interpolation_weights(ni[:n], tau, nodes, boxes, vp.cpu(), torch.zeros(3), w, ns)
+            w_o, k_o = lo.get_interpolation_weights(n_o, tau, h.nodes.numpy(), h.boxes.numpy(), vp.numpy())
+            assert np.array_equal(ns[:n].cpu().numpy(), k_o)
+            assert np.array_equal(w[:n].cpu().numpy().view(np.uint32), w_o.view(np.uint32)), "weights must be bit-exact"
+
+
+def test_dist_knn3_matches_brute_force(gpu):
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(3)
+    for P in (4, 300, 5000):
+        pts = torch.randn(P, 3, generator=g) * torch.tensor([3.0, 1.0, 0.2])
+        pts[: P // 10] = pts[: P // 10].round()                      # clusters + exact duplicates
+        got = distCUDA2(pts.to(gpu)).cpu()
+        d2 = torch.cdist(pts.double(), pts.double()) ** 2
+        d2.fill_diagonal_(float("inf"))
+        ref = d2.topk(3, dim=1, largest=False).values.mean(1).float()
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-6), P
+
+
+def test_render_post_flow(gpu):
+    """The whole hierarchy-mode step of train_post.py / render_hierarchy.py with our packages: cut ->
+    weights -> attribute lerp (as gaussian_renderer/__init__.py:199-234) -> rasterizer with the LOD tensors."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    h, cam, nodes, boxes = _setup(3000, gpu, seed=5)
+    G = h.xyz.shape[0]
+    dev = gpu
+    ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+    tau = (2 * (3 + 0.5)) * cam.tanfovx / (0.5 * cam.image_width)           # render_hierarchy.py:55-56, tau=3
+    n = expand_to_size(nodes, boxes, tau, cam.camera_center.to(dev), torch.zeros(3), ri, pi, ni)
+    assert 0 < n < G
+    get_interpolation_weights(ni[:n], tau, nodes, boxes, cam.camera_center.cpu(), torch.zeros(3), w, ns)
+    xyz, shs, op = h.xyz.to(dev), h.shs.to(dev), h.alpha.to(dev).abs()
+    sc, rot = torch.exp(h.log_scales.to(dev)), torch.nn.functional.normalize(h.rots.to(dev))
+    r, p = ri[:n].long(), pi[:n].long()
+    t = w[:n, None]
+    lerp = lambda a: t.view(-1, *([1] * (a.dim() - 1))) * a[r] + (1 - t).view(-1, *([1] * (a.dim() - 1))) * a[p]
+    pr, rr = rot[p], rot[r]
+    pr = torch.where(((rr * pr).sum(1, keepdim=True) < 0), -pr, pr)
+    rot_i = t * rr + (1 - t) * pr
+    scene = synth.Scene(lerp(xyz).cpu(), lerp(sc).cpu(), rot_i.cpu(), lerp(op).cpu(), lerp(shs).cpu(), 3)
+    gc, gd = synth.upstream_grads(cam.image_height, cam.image_width)
+    bg = torch.zeros(3)
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, interpolation_weights=w.cpu(), num_node_kids=ns.cpu(), do_depth=False)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, dev, interpolation_weights=w, num_node_kids=ns, do_depth=False)
+    idx = pa.check_indices(hip, oo)
+    st = pa.compare(hip, oo, og, do_depth=False)
+    print(idx, st)
+    assert all(v == 0 for v in idx.values()), idx
+    for k, v in st.items():
+        if k != "fragile_frac":
+            assert v["maxrel"] <= pa.REL_TOL and v["l2"] <= pa.REL_TOL, (k, v)
