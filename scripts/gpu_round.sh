@@ -1,0 +1,22 @@
+#!/bin/bash
+# One gpurun call: GPU parity tests, smoke, bench, rocprofv3 kernel stats.  Outputs under gpurun_out/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rm -f gpurun_out/parity_log.jsonl
+echo "== pytest -m gpu" 
+timeout 1200 python -m pytest tests -q -m gpu -rA -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1
+echo "pytest exit $?"; tail -40 gpurun_out/pytest_gpu.log
+echo "== smoke"
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -5 gpurun_out/smoke.log
+echo "== bench"
+timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
+for v in ${VARIANTS:-3 7 6}; do
+  timeout 300 python bench.py --steps 20 --warmup 5 --variant $v --no-cpu-baseline > gpurun_out/bench_v$v.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_v$v.json
+done
+echo "== rocprof"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stage-timing > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1; echo "rocprof exit $?"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timing > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; echo "pmc $c exit $?"
+done
+cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof gpurun_out/pmc_* | head -30; nproc; free -g | head -2
