@@ -35,7 +35,7 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     """SURVEY.md §8(d) byte model, per stage, for the measured P (Gaussians), V (visible), L (tile
     instances), N (pixels), T (tiles), M (SH coefficients).  Each boundary tensor is counted once
     read / once written; irreducible intermediates once written + once read; the sort as one pass."""
-    rec, inst = 48, 48
+    rec, inst = 64, 48
     ch = 4 if depth else 3
     b = {}
     b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P

@@ -33,10 +33,7 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_keys_kernel(int P, int gx
   excl[tid] = my_excl;
   if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
   const uint32_t block_base = g.block_sums[blockIdx.x];
-  if (idx < P) {
-    g.offsets[idx] = block_base + my_excl;
-    if (cnt) g.records[(size_t)idx * kRecFloats + 10] = __uint_as_float(block_base + my_excl);
-  }
+  if (idx < P) g.offsets[idx] = block_base + my_excl;
   __syncthreads();
   const uint32_t total = excl[kPreBlock];
   for (uint32_t s = tid; s < total; s += kPreBlock) {

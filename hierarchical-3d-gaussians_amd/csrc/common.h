@@ -44,7 +44,8 @@ inline T* carve(char*& p, size_t count) {
 }
 
 constexpr int kTile = HGS_TILE;
-constexpr int kRecFloats = 12;              // per-Gaussian 2D record, 3 x float4
+constexpr int kRecFloats = 16;              // per-Gaussian 2D record, 4 x float4 (one 64-byte line)
+constexpr int kRecVec = kRecFloats / 4;
 constexpr int kInstStride = HGS_INST_GRAD_STRIDE;
 constexpr int kPreBlock = 256;              // Gaussians per preprocess / binning workgroup
 

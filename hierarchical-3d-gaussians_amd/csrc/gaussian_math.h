@@ -148,6 +148,90 @@ __device__ __forceinline__ void project_gaussian(const float p[3], const float* 
   if (!finite || (o.maxx - o.minx) * (o.maxy - o.miny) <= 0) o.visible = false;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Double-precision twin of the projection for everything CONTINUOUS (pixel centre, conic, and the
+// whole backward chain).  The float32 chain above stays the authority for discrete decisions
+// (cull, radius, tile rectangle, depth key, clamp flags); this one removes float32's ~1e-4 px
+// error of the pixel centre at 1080p+ (ulp of 1900.x is 1.2e-4), which otherwise dominates the
+// gradient error of sub-pixel Gaussians.  K1/K8 are HBM-bound; the extra flops are free.
+// ---------------------------------------------------------------------------------------------
+struct ProjD {
+  double tx, ty, tz, hx, hy, hw, pw;
+  double txc, tyc, fx, fy;
+  double T0[3], T1[3], U0[3], U1[3];
+  double c3[6];
+  double R[9], s[3];
+  double a, b, c, det, conA, conB, conC;
+  double px, py;
+};
+
+__device__ __forceinline__ void cov3d_from_scale_rot_d(const float sc[3], float mod, const float q[4], ProjD& o) {
+  const double r = q[0], x = q[1], y = q[2], z = q[3];
+  o.s[0] = (double)mod * sc[0];
+  o.s[1] = (double)mod * sc[1];
+  o.s[2] = (double)mod * sc[2];
+  double* R = o.R;
+  R[0] = 1.0 - 2.0 * (y * y + z * z); R[1] = 2.0 * (x * y - r * z);       R[2] = 2.0 * (x * z + r * y);
+  R[3] = 2.0 * (x * y + r * z);       R[4] = 1.0 - 2.0 * (x * x + z * z); R[5] = 2.0 * (y * z - r * x);
+  R[6] = 2.0 * (x * z - r * y);       R[7] = 2.0 * (y * z + r * x);       R[8] = 1.0 - 2.0 * (x * x + y * y);
+  double L[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) L[i * 3 + k] = R[i * 3 + k] * o.s[k];
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = i; j < 3; ++j)
+      o.c3[n++] = L[i * 3 + 0] * L[j * 3 + 0] + L[i * 3 + 1] * L[j * 3 + 1] + L[i * 3 + 2] * L[j * 3 + 2];
+}
+
+// clampx / clampy: the float32 chain's EWA clamp decisions (flags bits 3,4) so both chains agree.
+__device__ __forceinline__ void project_gaussian_d(const float p[3], const float* vm, const float* pm, int W, int H,
+                                                   float tanfovx, float tanfovy, bool clampx, bool clampy,
+                                                   ProjD& o) {
+  const double x = p[0], y = p[1], z = p[2];
+  o.tx = (double)vm[0] * x + (double)vm[4] * y + (double)vm[8] * z + (double)vm[12];
+  o.ty = (double)vm[1] * x + (double)vm[5] * y + (double)vm[9] * z + (double)vm[13];
+  o.tz = (double)vm[2] * x + (double)vm[6] * y + (double)vm[10] * z + (double)vm[14];
+  o.hx = (double)pm[0] * x + (double)pm[4] * y + (double)pm[8] * z + (double)pm[12];
+  o.hy = (double)pm[1] * x + (double)pm[5] * y + (double)pm[9] * z + (double)pm[13];
+  o.hw = (double)pm[3] * x + (double)pm[7] * y + (double)pm[11] * z + (double)pm[15];
+  o.pw = 1.0 / (o.hw + 1e-7);
+  o.px = ((o.hx * o.pw + 1.0) * (double)W - 1.0) * 0.5;
+  o.py = ((o.hy * o.pw + 1.0) * (double)H - 1.0) * 0.5;
+  o.fx = (double)W / (2.0 * (double)tanfovx);
+  o.fy = (double)H / (2.0 * (double)tanfovy);
+  const double limx = 1.3 * (double)tanfovx, limy = 1.3 * (double)tanfovy;
+  o.txc = clampx ? (o.tx < 0.0 ? -limx : limx) * o.tz : o.tx;
+  o.tyc = clampy ? (o.ty < 0.0 ? -limy : limy) * o.tz : o.ty;
+  const double itz = 1.0 / o.tz;
+  const double J00 = o.fx * itz, J02 = -(o.fx * o.txc) * itz * itz;
+  const double J11 = o.fy * itz, J12 = -(o.fy * o.tyc) * itz * itz;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.T0[j] = J00 * (double)vm[j * 4 + 0] + J02 * (double)vm[j * 4 + 2];
+    o.T1[j] = J11 * (double)vm[j * 4 + 1] + J12 * (double)vm[j * 4 + 2];
+  }
+  const double* c3 = o.c3;
+  const double S[3][3] = {{c3[0], c3[1], c3[2]}, {c3[1], c3[3], c3[4]}, {c3[2], c3[4], c3[5]}};
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.U0[j] = o.T0[0] * S[0][j] + o.T0[1] * S[1][j] + o.T0[2] * S[2][j];
+    o.U1[j] = o.T1[0] * S[0][j] + o.T1[1] * S[1][j] + o.T1[2] * S[2][j];
+  }
+  o.a = o.U0[0] * o.T0[0] + o.U0[1] * o.T0[1] + o.U0[2] * o.T0[2] + 0.3;
+  o.b = o.U0[0] * o.T1[0] + o.U0[1] * o.T1[1] + o.U0[2] * o.T1[2];
+  o.c = o.U1[0] * o.T1[0] + o.U1[1] * o.T1[1] + o.U1[2] * o.T1[2] + 0.3;
+  o.det = o.a * o.c - o.b * o.b;
+  const double di = 1.0 / o.det;
+  o.conA = o.c * di;
+  o.conB = -o.b * di;
+  o.conC = o.a * di;
+}
+
 // Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity'; oracle: raster_oracle.lod_opacity).
 __device__ __forceinline__ float lod_opacity(float o, float w, int kids, float* dout_do) {
   if (kids < 2) {

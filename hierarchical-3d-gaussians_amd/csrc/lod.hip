@@ -12,7 +12,7 @@ namespace hgs {
 namespace {
 
 constexpr int kNodeInts = 7;   // depth,parent,start,count_leafs,count_merged,start_children,count_children
-constexpr int kBoxFloats = 8;  // min.xyz+extent, max.xyz+pad
+// boxes: 8 floats per node = min.xyz+extent, max.xyz+pad
 constexpr int kMaxLevels = 64;
 constexpr float kFltMax = 3.4028234663852886e38f;
 

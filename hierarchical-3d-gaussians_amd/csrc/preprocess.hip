@@ -56,6 +56,22 @@ __device__ __forceinline__ void load_sh(const float* __restrict__ shs, int idx, 
   }
 }
 
+// 16-byte stores of a Gaussian's M*3 SH gradients (12 x dwordx4 per lane at M = 16)
+__device__ __forceinline__ void store_sh(float* __restrict__ dshs, int idx, int M, const float v[48]) {
+  const int n = M * 3;
+  float* dst = dshs + (size_t)idx * n;
+  if ((n & 3) == 0) {
+    float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll
+    for (int i = 0; i < 12; ++i)
+      if (i * 4 < n) d4[i] = make_float4(v[i * 4 + 0], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 48; ++i)
+      if (i < n) dst[i] = v[i];
+  }
+}
+
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    int32_t* __restrict__ radii) {
   __shared__ uint32_t wave_tot[kPreBlock / 64];
@@ -121,17 +137,33 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       float opac = a.opacities[idx];
       if (a.interpolation_weights && a.num_node_kids)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
-      // conic pre-scaled to base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
-      const float kLog2e = 1.4426950408889634f;
-      const float A2 = -0.5f * kLog2e * pr.conA;
-      const float B2 = -kLog2e * pr.conB;
-      const float C2 = -0.5f * kLog2e * pr.conC;
+      // continuous quantities from the double-precision chain (see gaussian_math.h)
+      ProjD pd;
+      if (a.cov3D_precomp) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
+      } else {
+        const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
+        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+        cov3d_from_scale_rot_d(sc, a.scale_modifier, q, pd);
+      }
+      project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
+      // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
+      const float gx_hi = (float)pd.px, gy_hi = (float)pd.py;
+      const float gx_lo = (float)(pd.px - (double)gx_hi), gy_lo = (float)(pd.py - (double)gy_hi);
+      // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
+      const double kLog2e = 1.4426950408889634;
+      const float A2 = (float)(-0.5 * kLog2e * pd.conA);
+      const float B2 = (float)(-kLog2e * pd.conB);
+      const float C2 = (float)(-0.5 * kLog2e * pd.conC);
       const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
                                 ((uint32_t)(pr.maxx - pr.minx) << 20);
-      float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * 3;
-      rec[0] = make_float4(pr.px, pr.py, A2, B2);
+      float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
+      rec[0] = make_float4(gx_hi, gy_hi, A2, B2);
       rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
-      rec[2] = make_float4(rgb[2], 1.0f / pr.tz, 0.0f, __uint_as_float(rectbits));
+      rec[2] = make_float4(rgb[2], (float)(1.0 / pd.tz), 0.0f, __uint_as_float(rectbits));
+      rec[3] = make_float4(gx_lo, gy_lo, 0.0f, 0.0f);
       g.depths[idx] = pr.tz;
       g.rects[idx * 2 + 0] = (uint32_t)pr.minx | ((uint32_t)pr.miny << 16);
       g.rects[idx * 2 + 1] = (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16);
@@ -193,8 +225,6 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
                                                                    hgs_raster_grads out) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   if (idx >= a.P) return;
-  const int gx = (a.width + kTile - 1) / kTile;
-  const int gy = (a.height + kTile - 1) / kTile;
   const uint32_t n = g.tiles_touched[idx];
 
   float d_mean[3] = {0.f, 0.f, 0.f};
@@ -204,21 +234,23 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   float d_rot[4] = {0.f, 0.f, 0.f, 0.f};
   float d_c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float d_col[3] = {0.f, 0.f, 0.f};
-  const int M3 = a.M * 3;
+  float sums5 = 0.f, sums6 = 0.f, sums7 = 0.f, sums8 = 0.f;
 
   if (n == 0) {
     // culled: all-zero gradients
     if (out.dL_dshs) {
-      float* dst = out.dL_dshs + (size_t)idx * M3;
-      for (int i = 0; i < M3; ++i) dst[i] = 0.f;
+      float dsh[48];
+#pragma unroll
+      for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
+      store_sh(out.dL_dshs, idx, a.M, dsh);
     }
   } else {
     CamLds cam;
     load_camera(a, cam);
     // ---- sum the instance partials (contiguous run: emission order) ----------
-    float s[10];
+    double s[10];
 #pragma unroll
-    for (int i = 0; i < 10; ++i) s[i] = 0.f;
+    for (int i = 0; i < 10; ++i) s[i] = 0.0;
     const float4* ip = reinterpret_cast<const float4*>(inst) + (size_t)g.offsets[idx] * 3;
     for (uint32_t k = 0; k < n; ++k) {
       const float4 v0 = ip[k * 3 + 0], v1 = ip[k * 3 + 1], v2 = ip[k * 3 + 2];
@@ -226,117 +258,123 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       s[4] += v1.x; s[5] += v1.y; s[6] += v1.z; s[7] += v1.w;
       s[8] += v2.x; s[9] += v2.y;
     }
-    // ---- recompute the forward projection -------------------------------------
-    Proj pr;
+    sums5 = (float)s[5]; sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
+    // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
+    const uint32_t flags = g.flags[idx];
     const float p[3] = {a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]};
-    float R[9], sv[3], q[4] = {1.f, 0.f, 0.f, 0.f};
+    float q[4] = {1.f, 0.f, 0.f, 0.f};
+    ProjD pd;
     if (a.cov3D_precomp) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
+      for (int i = 0; i < 6; ++i) pd.c3[i] = (double)a.cov3D_precomp[(size_t)idx * 6 + i];
     } else {
       const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
       const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
       q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
-      cov3d_from_scale_rot(sc, a.scale_modifier, q, pr.c3, R, sv);
+      cov3d_from_scale_rot_d(sc, a.scale_modifier, q, pd);
     }
-    project_gaussian(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, gx, gy, pr);
-    const uint32_t flags = g.flags[idx];
+    project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, (flags & 8u) != 0,
+                       (flags & 16u) != 0, pd);
 
-    const float A = pr.conA, B = pr.conB, C = pr.conC;
-    const float gA = -0.5f * s[2], gB = -s[3], gC = -0.5f * s[4];
-    const float ggx = -(A * s[0] + B * s[1]);
-    const float ggy = -(C * s[1] + B * s[0]);
-    d_m2[0] = ggx * 0.5f * (float)a.width;
-    d_m2[1] = ggy * 0.5f * (float)a.height;
+    const double A = pd.conA, B = pd.conB, C = pd.conC;
+    const double gA = -0.5 * s[2], gB = -s[3], gC = -0.5 * s[4];
+    const double ggx = -(A * s[0] + B * s[1]);
+    const double ggy = -(C * s[1] + B * s[0]);
+    const double dm2x = ggx * 0.5 * (double)a.width, dm2y = ggy * 0.5 * (double)a.height;
+    d_m2[0] = (float)dm2x;
+    d_m2[1] = (float)dm2y;
+    double dmean[3] = {0.0, 0.0, 0.0};
 
     // screen position -> clip space -> world
-    const float dndcx = d_m2[0], dndcy = d_m2[1];
-    const float dhx = dndcx * pr.pw, dhy = dndcy * pr.pw;
-    const float dhw = -(dndcx * pr.hx + dndcy * pr.hy) * pr.pw * pr.pw;
+    const double dhx = dm2x * pd.pw, dhy = dm2y * pd.pw;
+    const double dhw = -(dm2x * pd.hx + dm2y * pd.hy) * pd.pw * pd.pw;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      d_mean[j] += cam.pm[j * 4 + 0] * dhx + cam.pm[j * 4 + 1] * dhy + cam.pm[j * 4 + 3] * dhw;
+      dmean[j] += (double)cam.pm[j * 4 + 0] * dhx + (double)cam.pm[j * 4 + 1] * dhy + (double)cam.pm[j * 4 + 3] * dhw;
 
     // conic -> 2D covariance
-    const float a2 = pr.a, b2 = pr.b, c2 = pr.c;
-    const float di2 = 1.0f / (pr.det * pr.det);
-    const float ga = (-c2 * c2 * gA + b2 * c2 * gB - b2 * b2 * gC) * di2;
-    const float gb = (2.f * b2 * c2 * gA - (a2 * c2 + b2 * b2) * gB + 2.f * a2 * b2 * gC) * di2;
-    const float gc = (-b2 * b2 * gA + a2 * b2 * gB - a2 * a2 * gC) * di2;
-    const float hb = 0.5f * gb;
+    const double a2 = pd.a, b2 = pd.b, c2 = pd.c;
+    const double di2 = 1.0 / (pd.det * pd.det);
+    const double ga = (-c2 * c2 * gA + b2 * c2 * gB - b2 * b2 * gC) * di2;
+    const double gb = (2.0 * b2 * c2 * gA - (a2 * c2 + b2 * b2) * gB + 2.0 * a2 * b2 * gC) * di2;
+    const double gc = (-b2 * b2 * gA + a2 * b2 * gB - a2 * a2 * gC) * di2;
+    const double hb = 0.5 * gb;
     // dL/dSigma (full symmetric matrix) = T^T G2 T
-    float Gs[3][3];
+    double Gs[3][3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
       for (int j = 0; j < 3; ++j)
-        Gs[i][j] = pr.T0[i] * (ga * pr.T0[j] + hb * pr.T1[j]) + pr.T1[i] * (hb * pr.T0[j] + gc * pr.T1[j]);
-    d_c3[0] = Gs[0][0];
-    d_c3[1] = 2.f * Gs[0][1];
-    d_c3[2] = 2.f * Gs[0][2];
-    d_c3[3] = Gs[1][1];
-    d_c3[4] = 2.f * Gs[1][2];
-    d_c3[5] = Gs[2][2];
+        Gs[i][j] = pd.T0[i] * (ga * pd.T0[j] + hb * pd.T1[j]) + pd.T1[i] * (hb * pd.T0[j] + gc * pd.T1[j]);
+    d_c3[0] = (float)Gs[0][0];
+    d_c3[1] = (float)(2.0 * Gs[0][1]);
+    d_c3[2] = (float)(2.0 * Gs[0][2]);
+    d_c3[3] = (float)Gs[1][1];
+    d_c3[4] = (float)(2.0 * Gs[1][2]);
+    d_c3[5] = (float)Gs[2][2];
     // dL/dT = 2 G2 T Sigma = 2 G2 U
-    float dT0[3], dT1[3];
+    double dT0[3], dT1[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      dT0[j] = 2.f * ga * pr.U0[j] + gb * pr.U1[j];
-      dT1[j] = gb * pr.U0[j] + 2.f * gc * pr.U1[j];
+      dT0[j] = 2.0 * ga * pd.U0[j] + gb * pd.U1[j];
+      dT1[j] = gb * pd.U0[j] + 2.0 * gc * pd.U1[j];
     }
-    float gJ00 = 0.f, gJ02 = 0.f, gJ11 = 0.f, gJ12 = 0.f;
+    double gJ00 = 0.0, gJ02 = 0.0, gJ11 = 0.0, gJ12 = 0.0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      gJ00 += dT0[j] * cam.vm[j * 4 + 0];
-      gJ02 += dT0[j] * cam.vm[j * 4 + 2];
-      gJ11 += dT1[j] * cam.vm[j * 4 + 1];
-      gJ12 += dT1[j] * cam.vm[j * 4 + 2];
+      gJ00 += dT0[j] * (double)cam.vm[j * 4 + 0];
+      gJ02 += dT0[j] * (double)cam.vm[j * 4 + 2];
+      gJ11 += dT1[j] * (double)cam.vm[j * 4 + 1];
+      gJ12 += dT1[j] * (double)cam.vm[j * 4 + 2];
     }
-    const float itz = 1.0f / pr.tz, itz2 = itz * itz, itz3 = itz2 * itz;
-    const float g_txc = -pr.fx * itz2 * gJ02;
-    const float g_tyc = -pr.fy * itz2 * gJ12;
-    float g_tz = -pr.fx * itz2 * gJ00 + 2.f * pr.fx * pr.txc * itz3 * gJ02 - pr.fy * itz2 * gJ11 +
-                 2.f * pr.fy * pr.tyc * itz3 * gJ12;
-    float g_tx = 0.f, g_ty = 0.f;
-    if (flags & 8u) g_tz += g_txc * (pr.txc * itz); else g_tx = g_txc;
-    if (flags & 16u) g_tz += g_tyc * (pr.tyc * itz); else g_ty = g_tyc;
+    const double itz = 1.0 / pd.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    const double g_txc = -pd.fx * itz2 * gJ02;
+    const double g_tyc = -pd.fy * itz2 * gJ12;
+    double g_tz = -pd.fx * itz2 * gJ00 + 2.0 * pd.fx * pd.txc * itz3 * gJ02 - pd.fy * itz2 * gJ11 +
+                  2.0 * pd.fy * pd.tyc * itz3 * gJ12;
+    double g_tx = 0.0, g_ty = 0.0;
+    if (flags & 8u) g_tz += g_txc * (pd.txc * itz); else g_tx = g_txc;
+    if (flags & 16u) g_tz += g_tyc * (pd.tyc * itz); else g_ty = g_tyc;
     // inverse depth
     g_tz += -s[9] * itz2;
 #pragma unroll
     for (int j = 0; j < 3; ++j)
-      d_mean[j] += cam.vm[j * 4 + 0] * g_tx + cam.vm[j * 4 + 1] * g_ty + cam.vm[j * 4 + 2] * g_tz;
+      dmean[j] += (double)cam.vm[j * 4 + 0] * g_tx + (double)cam.vm[j * 4 + 1] * g_ty + (double)cam.vm[j * 4 + 2] * g_tz;
+    d_mean[0] = (float)dmean[0]; d_mean[1] = (float)dmean[1]; d_mean[2] = (float)dmean[2];
 
     // Sigma -> scale / rotation
     if (!a.cov3D_precomp) {
-      float dM[3][3];   // dL/dM, M_ik = R_ik s_k ; dL/dM = 2 Gs M
+      const double* R = pd.R;
+      const double* sv = pd.s;
+      double dM[3][3];   // dL/dM, M_ik = R_ik s_k ; dL/dM = 2 Gs M
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-          float acc = 0.f;
+          double acc = 0.0;
 #pragma unroll
           for (int j = 0; j < 3; ++j) acc += Gs[i][j] * (R[j * 3 + k] * sv[k]);
-          dM[i][k] = 2.f * acc;
+          dM[i][k] = 2.0 * acc;
         }
-      float gR[3][3];
+      double gR[3][3];
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        float acc = 0.f;
+        double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
           acc += R[i * 3 + k] * dM[i][k];
           gR[i][k] = dM[i][k] * sv[k];
         }
-        d_scale[k] = a.scale_modifier * acc;
+        d_scale[k] = (float)((double)a.scale_modifier * acc);
       }
-      const float r = q[0], x = q[1], y = q[2], z = q[3];
-      d_rot[0] = 2.f * (-z * gR[0][1] + y * gR[0][2] + z * gR[1][0] - x * gR[1][2] - y * gR[2][0] + x * gR[2][1]);
-      d_rot[1] = 2.f * (y * gR[0][1] + z * gR[0][2] + y * gR[1][0] - 2.f * x * gR[1][1] - r * gR[1][2] +
-                        z * gR[2][0] + r * gR[2][1] - 2.f * x * gR[2][2]);
-      d_rot[2] = 2.f * (-2.f * y * gR[0][0] + x * gR[0][1] + r * gR[0][2] + x * gR[1][0] + z * gR[1][2] -
-                        r * gR[2][0] + z * gR[2][1] - 2.f * y * gR[2][2]);
-      d_rot[3] = 2.f * (-2.f * z * gR[0][0] - r * gR[0][1] + x * gR[0][2] + r * gR[1][0] - 2.f * z * gR[1][1] +
-                        y * gR[1][2] + x * gR[2][0] + y * gR[2][1]);
+      const double r = q[0], x = q[1], y = q[2], z = q[3];
+      d_rot[0] = (float)(2.0 * (-z * gR[0][1] + y * gR[0][2] + z * gR[1][0] - x * gR[1][2] - y * gR[2][0] + x * gR[2][1]));
+      d_rot[1] = (float)(2.0 * (y * gR[0][1] + z * gR[0][2] + y * gR[1][0] - 2.0 * x * gR[1][1] - r * gR[1][2] +
+                                z * gR[2][0] + r * gR[2][1] - 2.0 * x * gR[2][2]));
+      d_rot[2] = (float)(2.0 * (-2.0 * y * gR[0][0] + x * gR[0][1] + r * gR[0][2] + x * gR[1][0] + z * gR[1][2] -
+                                r * gR[2][0] + z * gR[2][1] - 2.0 * y * gR[2][2]));
+      d_rot[3] = (float)(2.0 * (-2.0 * z * gR[0][0] - r * gR[0][1] + x * gR[0][2] + r * gR[1][0] - 2.0 * z * gR[1][1] +
+                                y * gR[1][2] + x * gR[2][0] + y * gR[2][1]));
     }
 
     // opacity (through the LOD remap)
@@ -344,11 +382,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       float dod = 1.0f;
       if (a.interpolation_weights && a.num_node_kids)
         (void)lod_opacity(a.opacities[idx], a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
-      d_op = s[5] * dod;
+      d_op = sums5 * dod;
     }
 
     // colour
-    float gr[3] = {s[6], s[7], s[8]};
+    float gr[3] = {sums6, sums7, sums8};
     if (a.colors_precomp) {
       d_col[0] = gr[0]; d_col[1] = gr[1]; d_col[2] = gr[2];
     } else {
@@ -365,20 +403,18 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
       const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
       float gdx = 0.f, gdy = 0.f, gdz = 0.f;
-      float* dst = out.dL_dshs + (size_t)idx * M3;
+      float dsh[48];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        if (k < a.M) {
-          float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-          if (k < nb) {
-            o0 = b[k] * gr[0]; o1 = b[k] * gr[1]; o2 = b[k] * gr[2];
-            const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
-            gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
-          }
-          dst[k * 3 + 0] = o0; dst[k * 3 + 1] = o1; dst[k * 3 + 2] = o2;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+        if (k < nb) {
+          o0 = b[k] * gr[0]; o1 = b[k] * gr[1]; o2 = b[k] * gr[2];
+          const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
+          gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
         }
+        dsh[k * 3 + 0] = o0; dsh[k * 3 + 1] = o1; dsh[k * 3 + 2] = o2;
       }
-      for (int k = 16; k < a.M; ++k) { dst[k * 3 + 0] = 0.f; dst[k * 3 + 1] = 0.f; dst[k * 3 + 2] = 0.f; }
+      store_sh(out.dL_dshs, idx, a.M, dsh);
       // through the normalisation dir = d/|d|
       const float dot = ux * gdx + uy * gdy + uz * gdz;
       d_mean[0] += (gdx - ux * dot) * inv;

@@ -207,7 +207,7 @@ def raster_views(call):
         "offsets": view(call.geom, v.offsets, torch.int32, P),
         "depths": view(call.geom, v.depths, torch.float32, P),
         "rects": view(call.geom, v.rects, torch.int32, P * 2).view(P, 2),
-        "records": view(call.geom, v.records, torch.float32, P * 12).view(P, 12),
+        "records": view(call.geom, v.records, torch.float32, P * 16).view(P, 16),
         "final_T": view(call.img, v.final_T, torch.float32, H * W).view(H, W),
         "n_contrib": view(call.img, v.n_contrib, torch.int32, H * W).view(H, W),
     }

@@ -135,7 +135,7 @@ typedef struct hgs_raster_views {
   const uint32_t* offsets;       /* [P] exclusive scan of tiles_touched */
   const float* depths;           /* [P] view-space z */
   const uint32_t* rects;         /* [P,2] packed (x | y<<16) min, max in tile units */
-  const float* records;          /* [P,12] per-Gaussian 2D record */
+  const float* records;          /* [P,16] per-Gaussian 2D record, 64 bytes */
   const float* final_T;          /* [H*W] */
   const uint32_t* n_contrib;     /* [H*W] */
 } hgs_raster_views;

@@ -318,12 +318,17 @@ class OracleOut:
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
               *, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
               projmatrix, sh_degree, campos, interpolation_weights=None, num_node_kids=None,
-              dtype=torch.float64, tiles=None, fragile_tol=1e-5) -> OracleOut:
+              dtype=torch.float64, tiles=None, fragile_tol=1e-5, geom_dtype=None) -> OracleOut:
     """Dense per-tile oracle.  All tensor arguments are CPU torch tensors; the
     differentiable ones may require grad.  ``tiles``: optional iterable of tile
     ids to restrict the blend to (bench cpu_baseline sampling); other pixels
-    are left at zero."""
+    are left at zero.  ``geom_dtype`` (default: ``dtype``): precision of the per-Gaussian
+    continuous stage (projection, conic, colour); the blend runs in ``dtype`` on tile-relative
+    coordinates -- ``dtype=float32, geom_dtype=float64`` mirrors the HIP kernels' precision split."""
     H, W = int(image_height), int(image_width)
+    # the op receives tanfov / scale_modifier as C floats (GaussianRasterizationSettings -> float32)
+    tanfovx, tanfovy = float(np.float32(tanfovx)), float(np.float32(tanfovy))
+    scale_modifier = float(np.float32(scale_modifier))
     npf = lambda t: None if t is None else t.detach().to(torch.float32).cpu().numpy()
     geom = geometry_spec(npf(means3D), npf(scales), npf(rotations), npf(cov3D_precomp),
                          npf(viewmatrix), npf(projmatrix), W, H, tanfovx, tanfovy, scale_modifier)
@@ -338,6 +343,9 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
     remap = np.full(P, -1, dtype=np.int64)
     remap[vis_np] = np.arange(vis_np.shape[0])
     V = vidx.shape[0]
+    gdt = dtype if geom_dtype is None else geom_dtype
+    blend_dtype = dtype
+    dtype = gdt
     cv = lambda t: None if t is None else t.to(dtype)
     sel = lambda t: None if t is None else cv(t)[vidx]
     p = sel(means3D)
@@ -394,6 +402,10 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         opac = lod_opacity(opac, cv(interpolation_weights.detach()).reshape(-1)[:P][vidx],
                            num_node_kids.detach().reshape(-1)[:P][vidx])
     invz = 1.0 / tz
+    # hand the per-Gaussian values to the blend precision (pixel centres stay in geom precision
+    # until they have been made tile-relative)
+    dtype = blend_dtype
+    A, B, C, rgb, opac, invz, bgc = (t.to(dtype) for t in (A, B, C, rgb, opac, invz, bgc))
 
     color = torch.zeros(3, H, W, dtype=dtype)
     invd = torch.zeros(1, H, W, dtype=dtype)
@@ -416,8 +428,8 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
             dt = torch.zeros(npx, dtype=dtype)
         else:
             ids = torch.from_numpy(remap[binning.point_list[s:e]])
-            dx = gxp[ids][None, :] - pxs[:, None]
-            dy = gyp[ids][None, :] - pys[:, None]
+            dx = (gxp[ids] - tx0).to(dtype)[None, :] - (pxs - tx0)[:, None]
+            dy = (gyp[ids] - ty0).to(dtype)[None, :] - (pys - ty0)[:, None]
             power = -0.5 * (A[ids][None] * dx * dx + C[ids][None] * dy * dy) - B[ids][None] * dx * dy
             G = torch.exp(power)
             araw = opac[ids][None] * G

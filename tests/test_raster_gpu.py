@@ -42,11 +42,10 @@ def _assert_case(name, hip, oo, og, do_depth=True):
         assert v["l2"] <= pa.REL_TOL, f"{name}: {k} rel-L2 error {v['l2']:.3e} > {pa.REL_TOL}"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 5, 6, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_config1_1k_128(gpu, variant):
-    """BASELINE.json configs[0]: 1k random Gaussians, 128x128, fwd + bwd, every kernel variant
-    (0 = default: one wave per tile, skip-tested forward + back-to-front backward; 1-3 / 5-7 = the
-    1/2/4-strips-per-wave layouts with the front-to-back backward, kept for A/B profiling)."""
+    """BASELINE.json configs[0]: 1k random Gaussians, 128x128, fwd + bwd; forward strip layouts
+    0 = one wave per tile (default), 1 / 2 = four / two waves per tile (A/B profiling variants)."""
     cam, scene, gc, gd = pa.default_case(1000, 128, 128)
     bg = torch.tensor([0.1, 0.2, 0.3])
     oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
