@@ -163,7 +163,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       rec[0] = make_float4(gx_hi, gy_hi, A2, B2);
       rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
       rec[2] = make_float4(rgb[2], (float)(1.0 / pd.tz), 0.0f, __uint_as_float(rectbits));
-      rec[3] = make_float4(gx_lo, gy_lo, 0.0f, 0.0f);
+      // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
+      // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
+      // never a candidate, exactly like the exact test)
+      const float thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
+      rec[3] = make_float4(gx_lo, gy_lo, thr, 0.0f);
       g.depths[idx] = pr.tz;
       g.rects[idx * 2 + 0] = (uint32_t)pr.minx | ((uint32_t)pr.miny << 16);
       g.rects[idx * 2 + 1] = (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16);

@@ -37,8 +37,7 @@ namespace {
 constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kAlphaMax = 0.99f;
 constexpr float kTEps = 0.0001f;
-constexpr float kLog2AlphaMin = -7.994353436858858f;   // log2(1/255)
-constexpr float kSkipGuard = 1.0e-3f;
+constexpr float kBig = 1.0e18f;   // y coordinate of a finished / outside pixel: its power is -inf-ish, never a candidate
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(64 * (4 / S)) void render_fwd_kernel(
         const float dx = gxt - flx;
         const float ax = q0.z * dx * dx;
         const float bx = q0.w * dx;
-        const float thr = (kLog2AlphaMin - kSkipGuard) - __builtin_amdgcn_logf(q1.y);
+        const float thr = q3.z;
         bool any = false;
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -276,7 +275,7 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
       const float dx = gxt - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const float thr = (kLog2AlphaMin - kSkipGuard) - __builtin_amdgcn_logf(q1.y);
+      const float thr = q3.z;
       float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, s5 = 0.f, s6 = 0.f, s7 = 0.f, s8 = 0.f, s9 = 0.f;
       uint64_t any_blend = 0;
 #pragma unroll
@@ -338,6 +337,338 @@ __global__ __launch_bounds__(64) void render_bwd_kernel(
   }
 }
 
+
+// ================================================================================
+// Default kernels: one wave per tile, the four strips processed as two PACKED pairs.
+//
+// gfx950's fp32 vector peak (157 TFLOP/s) is a packed-math figure: a wave64 VALU instruction
+// occupies its SIMD for 4 cycles and v_pk_{fma,mul,add}_f32 does two floats per lane in that
+// time.  rocprof (profiles/r01_run3_pmc_sq.json) shows both compositing kernels VALU-issue-bound
+// (SQ_ACTIVE_INST_VALU x waves/SIMD ~ kernel time), so the lever is instruction count: the two
+// strips of a pair (same lane, y and y+4) go through one instruction stream as float2 values.
+// Non-live lanes are handled by zeroing alpha (an alpha = 0 Gaussian is the identity for every
+// recurrence used here), not by select-updating the state.  A finished pixel is moved to
+// y = 1e18: its power is hugely negative, so the candidate test needs no separate "done" flag.
+// ================================================================================
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+
+template <bool DEPTH>
+struct FwdPair {
+  f2 fly, T, Cr, Cg, Cb, Dd;
+  uint32_t last0, last1;
+};
+
+template <bool DEPTH>
+__device__ __forceinline__ bool fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, bool c0, bool c1, const float4& q1,
+                                              const float4& q2, uint32_t idx1) {
+  const f2 G = {fast_exp2(pw.x), fast_exp2(pw.y)};
+  const f2 araw = q1.y * G;
+  const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
+  const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);
+  const bool live1 = c1 && (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
+  const f2 Tn = p.T * (1.0f - alpha);
+  const bool stop0 = live0 && (Tn.x < kTEps), stop1 = live1 && (Tn.y < kTEps);
+  const bool blend0 = live0 && !stop0, blend1 = live1 && !stop1;
+  const f2 ae = {blend0 ? alpha.x : 0.0f, blend1 ? alpha.y : 0.0f};
+  const f2 w = ae * p.T;
+  p.Cr = fma2(w, splat(q1.z), p.Cr);
+  p.Cg = fma2(w, splat(q1.w), p.Cg);
+  p.Cb = fma2(w, splat(q2.x), p.Cb);
+  if (DEPTH) p.Dd = fma2(w, splat(q2.y), p.Dd);
+  p.T = p.T * (1.0f - ae);
+  p.last0 = blend0 ? idx1 : p.last0;
+  p.last1 = blend1 ? idx1 : p.last1;
+  const bool anystop = __ballot(stop0 || stop1) != 0;
+  if (anystop) {
+    p.fly.x = stop0 ? kBig : p.fly.x;
+    p.fly.y = stop1 ? kBig : p.fly.y;
+  }
+  return anystop;
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(64) void render_fwd_packed_kernel(
+    const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
+    float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
+    uint32_t* __restrict__ n_contrib) {
+  constexpr int BATCH = 64;
+  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
+  __shared__ float4 lrec[BATCH * kLds];
+
+  TileGeom tg;
+  if (!block_to_tile(T, gx, tg)) return;
+  const int lane = threadIdx.x;
+  const int lx = lane & 15, ly0 = lane >> 4;
+  const int px = tg.tx * kTile + lx;
+  const int py0 = tg.ty * kTile + ly0;
+  const float flx = (float)lx;
+  const float tile_x0 = (float)(tg.tx * kTile), tile_y0 = (float)(tg.ty * kTile);
+
+  bool inside[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) inside[s] = (px < W) && (py0 + 4 * s < H);
+  FwdPair<DEPTH> P0, P1;
+  P0.fly = f2{inside[0] ? (float)ly0 : kBig, inside[1] ? (float)(ly0 + 4) : kBig};
+  P1.fly = f2{inside[2] ? (float)(ly0 + 8) : kBig, inside[3] ? (float)(ly0 + 12) : kBig};
+  P0.T = P1.T = splat(1.0f);
+  P0.Cr = P0.Cg = P0.Cb = P0.Dd = P1.Cr = P1.Cg = P1.Cb = P1.Dd = splat(0.0f);
+  P0.last0 = P0.last1 = P1.last0 = P1.last1 = 0;
+
+  const uint32_t r0 = ranges[tg.tile * 2 + 0], r1 = ranges[tg.tile * 2 + 1];
+  bool wave_done = (__ballot(inside[0] || inside[1] || inside[2] || inside[3]) == 0);
+
+  for (uint32_t base = r0; base < r1 && !wave_done; base += BATCH) {
+    const uint32_t n = min((uint32_t)BATCH, r1 - base);
+    __syncthreads();
+    if ((uint32_t)lane < n) {
+      const uint32_t gid = point_list[base + lane];
+      const float4* r = records + (size_t)gid * kRecVec;
+      float4 a0 = r[0], a2 = r[2];
+      const float4 a3 = r[3];
+      a0.x = (a0.x - tile_x0) + a3.x;       // tile-relative pixel centre, once per (tile, Gaussian)
+      a0.y = (a0.y - tile_y0) + a3.y;
+      a2.z = a3.z;                           // skip threshold
+      lrec[lane * kLds + 0] = a0;
+      lrec[lane * kLds + 1] = r[1];
+      lrec[lane * kLds + 2] = a2;
+    }
+    __syncthreads();
+    for (uint32_t j = 0; j < n; ++j) {
+      const float4 q0 = lrec[j * kLds + 0];
+      const float4 q1 = lrec[j * kLds + 1];
+      const float4 q2 = lrec[j * kLds + 2];
+      const float gyt = q0.y;
+      const float dx = q0.x - flx;
+      const float ax = q0.z * dx * dx;
+      const float bx = q0.w * dx;
+      const float thr = q2.z;
+      const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
+      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      const bool c0 = pw0.x >= thr, c1 = pw0.y >= thr, c2 = pw1.x >= thr, c3 = pw1.y >= thr;
+      const uint32_t idx1 = base - r0 + j + 1;
+      bool stopped = false;
+      if (__ballot(c0 || c1) != 0) stopped = fwd_pair_live<DEPTH>(P0, pw0, c0, c1, q1, q2, idx1);
+      if (__ballot(c2 || c3) != 0) stopped = fwd_pair_live<DEPTH>(P1, pw1, c2, c3, q1, q2, idx1) || stopped;
+      if (stopped) {   // wave-uniform, rare: some pixel saturated -> is the whole tile finished?
+        const bool any = (P0.fly.x < kBig) || (P0.fly.y < kBig) || (P1.fly.x < kBig) || (P1.fly.y < kBig);
+        if (__ballot(any) == 0) {
+          wave_done = true;
+          break;
+        }
+      }
+    }
+  }
+
+  const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+  const size_t plane = (size_t)W * H;
+  const float Tf[4] = {P0.T.x, P0.T.y, P1.T.x, P1.T.y};
+  const float cr[4] = {P0.Cr.x, P0.Cr.y, P1.Cr.x, P1.Cr.y};
+  const float cg[4] = {P0.Cg.x, P0.Cg.y, P1.Cg.x, P1.Cg.y};
+  const float cb[4] = {P0.Cb.x, P0.Cb.y, P1.Cb.x, P1.Cb.y};
+  const float dd[4] = {P0.Dd.x, P0.Dd.y, P1.Dd.x, P1.Dd.y};
+  const uint32_t la[4] = {P0.last0, P0.last1, P1.last0, P1.last1};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    if (inside[s]) {
+      const size_t pix = (size_t)(py0 + 4 * s) * W + px;
+      out_color[pix] = cr[s] + Tf[s] * b0;
+      out_color[plane + pix] = cg[s] + Tf[s] * b1;
+      out_color[2 * plane + pix] = cb[s] + Tf[s] * b2;
+      if (DEPTH) out_invdepth[pix] = dd[s];
+      final_T[pix] = Tf[s];
+      n_contrib[pix] = la[s];
+    }
+  }
+}
+
+// ---- packed backward ------------------------------------------------------------------
+struct BwdPair {
+  f2 fly, T, A, la, lq, bgd, g0, g1, g2, gd;
+  uint32_t nc0, nc1;
+};
+struct BwdSums {
+  f2 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
+};
+
+template <bool DEPTH>
+__device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
+                                                  const float4& q1, const float4& q2) {
+  // min(pw, 0): identical for live lanes (they require pw <= 0) and keeps G finite on the others,
+  // whose contributions are multiplied by an exact 0 below
+  const f2 G = {fast_exp2(fminf(pw.x, 0.0f)), fast_exp2(fminf(pw.y, 0.0f))};
+  const f2 araw = q1.y * G;
+  const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
+  const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);   // = blended by the forward
+  const bool live1 = c1 && (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
+  const uint64_t lm = __ballot(live0 || live1);
+  if (lm == 0) return 0;
+  // non-live lanes take part with alpha = 0: identity for T, for the A recurrence and for every sum
+  const f2 ae = {live0 ? alpha.x : 0.0f, live1 ? alpha.y : 0.0f};
+  const f2 oma = 1.0f - ae;
+  const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
+  const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
+  const f2 An = fma2(p.la, p.lq - p.A, p.A);                    // value blended behind it, per unit T
+  f2 q = fma2(p.g2, splat(q2.x), fma2(p.g1, splat(q1.w), p.g0 * q1.z));
+  if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
+  const f2 dfull = fma2(q - An, Tcur, -(p.bgd * rinv));
+  const f2 dLda = {live0 ? dfull.x : 0.0f, live1 ? dfull.y : 0.0f};
+  const f2 w = ae * Tcur;
+  const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
+  const f2 Xdx = X * dx, Xdy = X * dy;
+  S.s0 += Xdx;
+  S.s1 += Xdy;
+  S.s2 = fma2(Xdx, splat(dx), S.s2);
+  S.s3 = fma2(Xdx, dy, S.s3);
+  S.s4 = fma2(Xdy, dy, S.s4);
+  S.s5 = fma2(G, dLda, S.s5);
+  S.s6 = fma2(w, p.g0, S.s6);
+  S.s7 = fma2(w, p.g1, S.s7);
+  S.s8 = fma2(w, p.g2, S.s8);
+  if (DEPTH) S.s9 = fma2(w, p.gd, S.s9);
+  p.T = Tcur;
+  p.A = An;
+  p.la = ae;
+  p.lq = q;
+  return lm;
+}
+
+__device__ __forceinline__ float swap32_add(float a, float b) {   // [a.lo+a.hi | b.lo+b.hi]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float a, float b) {   // rows: [a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(64) void render_bwd_packed_kernel(
+    const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
+    const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
+    const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
+    const float* __restrict__ dL_dinvdepth, float* __restrict__ inst) {
+  constexpr int BATCH = 64;
+  __shared__ float4 lrec[BATCH * kRecVec];
+
+  TileGeom tg;
+  if (!block_to_tile(T, gx, tg)) return;
+  const int lane = threadIdx.x;
+  const int lx = lane & 15, ly0 = lane >> 4;
+  const int px = tg.tx * kTile + lx;
+  const int py0 = tg.ty * kTile + ly0;
+  const float flx = (float)lx;
+  const float tile_x0 = (float)(tg.tx * kTile), tile_y0 = (float)(tg.ty * kTile);
+  const size_t plane = (size_t)W * H;
+  const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+
+  float fly[4], Tr[4], bgd[4], g0[4], g1[4], g2[4], gd[4];
+  uint32_t nc[4];
+  uint32_t maxnc = 0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int py = py0 + 4 * s;
+    fly[s] = kBig; Tr[s] = 1.0f; bgd[s] = 0.f; g0[s] = g1[s] = g2[s] = gd[s] = 0.f; nc[s] = 0;
+    if (px < W && py < H) {
+      const size_t pix = (size_t)py * W + px;
+      fly[s] = (float)(ly0 + 4 * s);
+      g0[s] = dL_dcolor[pix];
+      g1[s] = dL_dcolor[plane + pix];
+      g2[s] = dL_dcolor[2 * plane + pix];
+      if (DEPTH) gd[s] = dL_dinvdepth[pix];
+      Tr[s] = final_T[pix];
+      bgd[s] = Tr[s] * (g0[s] * b0 + g1[s] * b1 + g2[s] * b2);
+      nc[s] = n_contrib[pix];
+    }
+    maxnc = max(maxnc, nc[s]);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
+  if (maxnc == 0) return;
+  BwdPair P0, P1;
+  P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
+  P0.T = f2{Tr[0], Tr[1]};     P1.T = f2{Tr[2], Tr[3]};
+  P0.bgd = f2{bgd[0], bgd[1]}; P1.bgd = f2{bgd[2], bgd[3]};
+  P0.g0 = f2{g0[0], g0[1]};    P1.g0 = f2{g0[2], g0[3]};
+  P0.g1 = f2{g1[0], g1[1]};    P1.g1 = f2{g1[2], g1[3]};
+  P0.g2 = f2{g2[0], g2[1]};    P1.g2 = f2{g2[2], g2[3]};
+  P0.gd = f2{gd[0], gd[1]};    P1.gd = f2{gd[2], gd[3]};
+  P0.A = P0.la = P0.lq = P1.A = P1.la = P1.lq = splat(0.0f);
+  P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
+  const uint32_t r0 = ranges[tg.tile * 2 + 0];
+  // value index held by this lane's row after the swap reduction (see below): row r -> {0,2,1,3}[r]
+  const int row = lane >> 4;
+  const int slot = ((row & 1) << 1) | (row >> 1);
+
+  for (int bstart = (int)((maxnc - 1) / BATCH) * BATCH; bstart >= 0; bstart -= BATCH) {
+    const int n = min(BATCH, (int)maxnc - bstart);
+    __syncthreads();
+    if (lane < n) {
+      const uint32_t gid = point_list[r0 + bstart + lane];
+      const float4* r = records + (size_t)gid * kRecVec;
+      float4 a0 = r[0], a2 = r[2];
+      const float4 a3 = r[3];
+      a0.x = (a0.x - tile_x0) + a3.x;           // tile-relative pixel centre, once per (tile, Gaussian)
+      a0.y = (a0.y - tile_y0) + a3.y;
+      a2.z = __uint_as_float(offsets[gid]);     // emission offset of this Gaussian's instance run
+      lrec[lane * kRecVec + 0] = a0;
+      lrec[lane * kRecVec + 1] = r[1];
+      lrec[lane * kRecVec + 2] = a2;
+      lrec[lane * kRecVec + 3] = a3;
+    }
+    __syncthreads();
+    for (int j = n - 1; j >= 0; --j) {
+      const uint32_t rel = (uint32_t)(bstart + j);
+      const float4 q0 = lrec[j * kRecVec + 0];
+      const float4 q1 = lrec[j * kRecVec + 1];
+      const float4 q2 = lrec[j * kRecVec + 2];
+      const float4 q3 = lrec[j * kRecVec + 3];
+      const float gyt = q0.y;
+      const float dx = q0.x - flx;
+      const float ax = q0.z * dx * dx;
+      const float bx = q0.w * dx;
+      const float thr = q3.z;
+      const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
+      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      const bool c0 = (pw0.x >= thr) && (rel < P0.nc0), c1 = (pw0.y >= thr) && (rel < P0.nc1);
+      const bool c2 = (pw1.x >= thr) && (rel < P1.nc0), c3 = (pw1.y >= thr) && (rel < P1.nc1);
+      BwdSums S;
+      S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
+      uint64_t any_blend = 0;
+      if (__ballot(c0 || c1) != 0) any_blend |= bwd_pair_live<DEPTH>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
+      if (__ballot(c2 || c3) != 0) any_blend |= bwd_pair_live<DEPTH>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
+      if (any_blend != 0) {   // wave-uniform
+        // 10 sums x 64 lanes -> 12 slots in 28 VALU: fold the two strips of each pair, then halve the
+        // lane count twice with permlane32/16 swaps (two values share a register afterwards), then
+        // DPP row reductions.  v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7), v2 rows = (s8,-,s9,-).
+        const float u0 = swap32_add(S.s0.x + S.s0.y, S.s1.x + S.s1.y);
+        const float u1 = swap32_add(S.s2.x + S.s2.y, S.s3.x + S.s3.y);
+        const float u2 = swap32_add(S.s4.x + S.s4.y, S.s5.x + S.s5.y);
+        const float u3 = swap32_add(S.s6.x + S.s6.y, S.s7.x + S.s7.y);
+        const float u4 = swap32_add(S.s8.x + S.s8.y, DEPTH ? (S.s9.x + S.s9.y) : 0.0f);
+        const float v0 = row_sum16(swap16_add(u0, u1));
+        const float v1 = row_sum16(swap16_add(u2, u3));
+        const float v2 = row_sum16(swap16_add(u4, 0.0f));
+        if ((lane & 15) == 0) {
+          const uint32_t off = __float_as_uint(q2.z);
+          const uint32_t rb = __float_as_uint(q2.w);
+          const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
+          const uint32_t e = off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
+          float* dst = inst + (size_t)e * kInstStride + slot;
+          dst[0] = v0;
+          dst[4] = v1;
+          dst[8] = v2;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
 
 template <int S>
@@ -355,15 +686,25 @@ static int launch_fwd_s(const hgs_raster_args& a, const GeomWs& g, const BinWs& 
   return HGS_OK;
 }
 
-// variant: 0 (default) = one wave per tile (S=4); 1 / 2 = four / two waves per tile (S=1 / S=2),
-// kept for A/B profiling of the strip layout.  The backward has a single implementation.
+// variant: 0 (default) = one wave per tile, packed strip pairs; 1 / 2 / 3 = the generic kernels with
+// four / two / one wave(s) per tile (S = 1 / 2 / 4), kept for A/B profiling.
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, hipStream_t s) {
   switch (a.variant) {
     case 1: return launch_fwd_s<1>(a, g, b, im, out_color, out_invdepth, s);
     case 2: return launch_fwd_s<2>(a, g, b, im, out_color, out_invdepth, s);
-    default: return launch_fwd_s<4>(a, g, b, im, out_color, out_invdepth, s);
+    case 3: return launch_fwd_s<4>(a, g, b, im, out_color, out_invdepth, s);
+    default: break;
   }
+  const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
+  const int nblk = ((T + 7) / 8) * 8;
+  const bool depth = a.do_depth && out_invdepth;
+  auto kern = depth ? render_fwd_packed_kernel<true> : render_fwd_packed_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
+                     reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
+                     out_invdepth, im.final_T, im.n_contrib);
+  HGS_LAUNCH_CHECK("render_fwd_packed", s, a.debug);
+  return HGS_OK;
 }
 
 int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
@@ -373,11 +714,19 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = ((T + 7) / 8) * 8;
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
-  auto kern = depth ? render_bwd_kernel<true> : render_bwd_kernel<false>;
+  if (a.variant == 3) {   // generic (unpacked) backward, A/B only
+    auto kern = depth ? render_bwd_kernel<true> : render_bwd_kernel<false>;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
+                       reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
+                       im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
+    HGS_LAUNCH_CHECK("render_bwd", s, a.debug);
+    return HGS_OK;
+  }
+  auto kern = depth ? render_bwd_packed_kernel<true> : render_bwd_packed_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
-                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, reinterpret_cast<float4*>(inst_grads));
-  HGS_LAUNCH_CHECK("render_bwd", s, a.debug);
+                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads);
+  HGS_LAUNCH_CHECK("render_bwd_packed", s, a.debug);
   return HGS_OK;
 }
 
