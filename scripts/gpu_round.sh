@@ -11,7 +11,7 @@ echo "== smoke"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit $?"; tail -5 gpurun_out/smoke.log
 echo "== bench"
 timeout 900 python bench.py --steps 30 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench exit $?"; cat gpurun_out/bench.json; tail -5 gpurun_out/bench.err
-for v in ${VARIANTS:-1 2}; do
+for v in ${VARIANTS:-3 2}; do
   timeout 300 python bench.py --steps 20 --warmup 5 --variant $v --no-cpu-baseline > gpurun_out/bench_v$v.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_v$v.json
 done
 echo "== rocprof"

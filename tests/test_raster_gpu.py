@@ -42,7 +42,7 @@ def _assert_case(name, hip, oo, og, do_depth=True):
         assert v["l2"] <= pa.REL_TOL, f"{name}: {k} rel-L2 error {v['l2']:.3e} > {pa.REL_TOL}"
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_config1_1k_128(gpu, variant):
     """BASELINE.json configs[0]: 1k random Gaussians, 128x128, fwd + bwd; forward strip layouts
     0 = one wave per tile (default), 1 / 2 = four / two waves per tile (A/B profiling variants)."""
