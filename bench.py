@@ -40,9 +40,10 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     b = {}
     b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P
     b["scan"] = 8 * (P // 256 + 1)
-    b["duplicate_keys"] = 16 * P + 12 * L
-    b["radix_sort"] = 24 * L
-    b["tile_ranges"] = 8 * L + 8 * T
+    b["sort_depth"] = 16 * P + 8 * P            # one pass over (depth key, id) pairs + the emission-offset scan inputs
+    b["duplicate_keys"] = 16 * P + 8 * L
+    b["radix_sort"] = 16 * L                     # one pass over (tile id, Gaussian id) pairs
+    b["tile_ranges"] = 4 * L + 8 * T
     b["render_fwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N + 8 * N
     b["memset_bwd"] = inst * L
     b["render_bwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N * 2 + inst * L

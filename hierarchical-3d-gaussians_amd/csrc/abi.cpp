@@ -10,10 +10,11 @@
 namespace hgs {
 
 // ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
-enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_SORT_DEPTH, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
              ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
-                                            "render_fwd", "memset_bwd", "render_bwd", "preprocess_bwd"};
+static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "sort_depth", "duplicate_keys", "radix_sort",
+                                            "tile_ranges", "render_fwd", "memset_bwd", "render_bwd",
+                                            "preprocess_bwd"};
 struct Pending { int stage; hipEvent_t a, b; };
 static bool g_timing = false;
 static std::mutex g_tmu;
@@ -54,8 +55,8 @@ void set_error(const char* fmt, ...) {
 size_t GeomWs::bytes(int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
   const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
-  return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
-         align_up((nblk + 1) * 4) + kAlign;
+  return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 5 * align_up(p * 4) +
+         2 * align_up((nblk + 1) * 4) + sort_tmp_bytes((uint32_t)p) + kAlign;
 }
 GeomWs GeomWs::carve_from(void* base, int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -69,20 +70,24 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
   g.offsets = carve<uint32_t>(c, p);
   g.flags = carve<uint32_t>(c, p);
   g.block_sums = carve<uint32_t>(c, nblk + 1);
+  g.depth_keys = carve<uint32_t>(c, p);
+  g.perm = carve<uint32_t>(c, p);
+  g.sorted_block_sums = carve<uint32_t>(c, nblk + 1);
+  g.sort_tmp = c;
   return g;
 }
 
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
-  return 2 * align_up(l * 8) + 2 * align_up(l * 4) + align_up((size_t)T * 8) + sort_tmp_bytes(L ? L : 1) + kAlign;
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + sort_tmp_bytes(L ? L : 1) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
   char* c = static_cast<char*>(base);
   BinWs b;
-  b.keys_in = carve<uint64_t>(c, l);
+  b.keys_in = carve<uint32_t>(c, l);
   b.vals_in = carve<uint32_t>(c, l);
-  b.keys_out = carve<uint64_t>(c, l);
+  b.keys_out = carve<uint32_t>(c, l);
   b.vals_out = carve<uint32_t>(c, l);
   b.ranges = carve<uint32_t>(c, (size_t)T * 2);
   b.sort_tmp = c;
@@ -156,11 +161,28 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
   *L_out_host = 0;
   if (a->P == 0) return HGS_OK;
   if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
-  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   HGS_HIP(hipMemcpyAsync(L_out_host, g.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HGS_HIP(hipStreamSynchronize(s));
-  return HGS_OK;
+  // The host only waits for L (to size the binning workspace); the depth sort that follows keeps the
+  // GPU busy meanwhile.
+  hipEvent_t ev;
+  HGS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, s);
+  if (e == hipSuccess) {
+    rc = HGS_TIMED(ST_SORT_DEPTH, s, [&]() {
+      // stable sort of the Gaussian ids by view depth (float bits of positive depths order like integers)
+      int r = sort_pairs32(reinterpret_cast<const uint32_t*>(g.depths), nullptr, g.depth_keys, g.perm, g.sort_tmp,
+                           (uint32_t)a->P, 32, s, a->debug);
+      if (r) return r;
+      if ((r = launch_sorted_block_sums(*a, g, s))) return r;
+      return launch_scan_block_sums(g.sorted_block_sums, a->P, s, a->debug);
+    }());
+    e = hipEventSynchronize(ev);
+  }
+  (void)hipEventDestroy(ev);
+  if (e != hipSuccess) { set_error("stage1 sync failed: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
+  return rc;
 }
 
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
@@ -175,8 +197,8 @@ int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws,
   const BinWs b = BinWs::carve_from(bin_ws, L, T);
   const ImgWs im = ImgWs::carve_from(img_ws, a->width, a->height);
   if (L > 0) {
-    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_keys(*a, g, b, L, s)))) return rc;
-    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, key_end_bit(T), s, a->debug)))) return rc;
+    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;
+    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, tile_bits(T), s, a->debug)))) return rc;
   }
   if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, T, s, a->debug)))) return rc;
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
@@ -227,7 +249,7 @@ int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, c
   const GeomWs g = GeomWs::carve_from(const_cast<void*>(geom_ws), P);
   const BinWs b = BinWs::carve_from(const_cast<void*>(bin_ws), L, T);
   const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), width, height);
-  out->keys_sorted = b.keys_out;
+  out->tile_ids_sorted = b.keys_out;
   out->point_list = b.vals_out;
   out->ranges = b.ranges;
   out->tiles_touched = g.tiles_touched;

@@ -1,24 +1,52 @@
 // K3 (duplicateWithKeys) and K5 (identifyTileRanges).
 //
-// K3 is a load-balanced expansion: a workgroup owns 256 consecutive Gaussians, scans
-// their tile counts in LDS and then assigns OUTPUT slots (not Gaussians) to lanes, so
-// a Gaussian covering hundreds of tiles does not serialise one lane and the key /
-// value stores are fully coalesced.  Emission order = ascending Gaussian index, then
-// row-major tiles inside the Gaussian's rectangle -- the order
-// the stable sort's tie-breaking is defined on.
+// The (tile | depth) sort is split: the P Gaussians are sorted by depth first (32-bit keys,
+// 4 passes over P elements), K3 then emits the L (tile, Gaussian) instances in that order, and a
+// stable sort by the tile id alone (13 bits at 1080p: 2 passes over L) finishes the job -- the
+// result is identical to one stable 45-bit sort of L 64-bit keys (6 passes over L), at less than
+// half the traffic.
+//
+// K3 is a load-balanced expansion: a workgroup owns 256 consecutive (depth-ordered) Gaussians,
+// scans their tile counts in LDS and then assigns OUTPUT slots (not Gaussians) to lanes, so a
+// Gaussian covering hundreds of tiles does not serialise one lane and the stores are coalesced.
 #include "common.h"
 
 namespace hgs {
 namespace {
 
-__global__ __launch_bounds__(kPreBlock) void duplicate_keys_kernel(int P, int gx, GeomWs g,
-                                                                   uint64_t* __restrict__ keys,
-                                                                   uint32_t* __restrict__ vals) {
+// Per-workgroup instance counts in DEPTH-SORTED Gaussian order (feeds the emission-offset scan).
+__global__ __launch_bounds__(kPreBlock) void sorted_block_sums_kernel(int P, const uint32_t* __restrict__ perm,
+                                                                      const uint32_t* __restrict__ tiles_touched,
+                                                                      uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[kPreBlock / 64];
+  const int i = blockIdx.x * kPreBlock + threadIdx.x;
+  uint32_t v = (i < P) ? tiles_touched[perm[i]] : 0u;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < kPreBlock / 64; ++w) t += wave_tot[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+// Emits (tile id, Gaussian id) for every tile of every visible Gaussian, walking the Gaussians in
+// depth order (perm), row-major tiles inside a rectangle.  A stable sort of the result by tile id
+// alone then equals the reference's stable sort by (tile | depth): depth ties keep ascending
+// Gaussian index because the depth sort that produced perm is stable as well.
+__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int gx, GeomWs g,
+                                                                    uint32_t* __restrict__ tile_keys,
+                                                                    uint32_t* __restrict__ vals) {
   __shared__ uint32_t excl[kPreBlock + 1];
+  __shared__ uint32_t gids[kPreBlock];
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int idx = blockIdx.x * kPreBlock + tid;
-  const uint32_t cnt = (idx < P) ? g.tiles_touched[idx] : 0u;
+  const int i = blockIdx.x * kPreBlock + tid;
+  const uint32_t gid = (i < P) ? g.perm[i] : 0u;
+  const uint32_t cnt = (i < P) ? g.tiles_touched[gid] : 0u;
   uint32_t inc = cnt;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -31,41 +59,41 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_keys_kernel(int P, int gx
   for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
   const uint32_t my_excl = wbase + inc - cnt;
   excl[tid] = my_excl;
+  gids[tid] = gid;
   if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
-  const uint32_t block_base = g.block_sums[blockIdx.x];
-  if (idx < P) g.offsets[idx] = block_base + my_excl;
+  const uint32_t block_base = g.sorted_block_sums[blockIdx.x];
+  if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run
   __syncthreads();
   const uint32_t total = excl[kPreBlock];
   for (uint32_t s = tid; s < total; s += kPreBlock) {
-    // largest j with excl[j] <= s  (excl is non-decreasing; zero-count entries are skipped
-    // because the search lands on the LAST index whose start is <= s)
+    // largest j with excl[j] <= s (zero-count entries are skipped: the search lands on the LAST
+    // index whose start is <= s)
     int lo = 0, hi = kPreBlock;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int mid = (lo + hi) >> 1;
       if (excl[mid] <= s) lo = mid; else hi = mid;
     }
-    const int gid = blockIdx.x * kPreBlock + lo;
+    const uint32_t gg = gids[lo];
     const uint32_t k = s - excl[lo];
-    const uint32_t rmin = g.rects[gid * 2 + 0], rmax = g.rects[gid * 2 + 1];
+    const uint32_t rmin = g.rects[gg * 2 + 0], rmax = g.rects[gg * 2 + 1];
     const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16;
     const uint32_t w = (rmax & 0xffffu) - minx;
     const uint32_t ty = miny + k / w, tx = minx + k % w;
-    const uint64_t tile = (uint64_t)(ty * (uint32_t)gx + tx);
-    keys[block_base + s] = (tile << 32) | (uint64_t)__float_as_uint(g.depths[gid]);
-    vals[block_base + s] = (uint32_t)gid;
+    tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
+    vals[block_base + s] = gg;
   }
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __restrict__ keys, uint32_t L,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t L,
                                                           uint32_t* __restrict__ ranges) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i >= L) return;
-  const uint32_t t = (uint32_t)(keys[i] >> 32);
+  const uint32_t t = keys[i];
   if (i == 0) {
     ranges[t * 2 + 0] = 0;
   } else {
-    const uint32_t tp = (uint32_t)(keys[i - 1] >> 32);
+    const uint32_t tp = keys[i - 1];
     if (tp != t) {
       ranges[tp * 2 + 1] = i;
       ranges[t * 2 + 0] = i;
@@ -76,12 +104,22 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint64_t* __rest
 
 }  // namespace
 
-int launch_duplicate_keys(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s) {
+int launch_sorted_block_sums(const hgs_raster_args& a, const GeomWs& g, hipStream_t s) {
+  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
+  if (nblk > 0) {
+    hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.perm, g.tiles_touched,
+                       g.sorted_block_sums);
+    HGS_LAUNCH_CHECK("sorted_block_sums", s, a.debug);
+  }
+  return HGS_OK;
+}
+
+int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0 && L > 0) {
-    hipLaunchKernelGGL(duplicate_keys_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g,
+    hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g,
                        b.keys_in, b.vals_in);
-    HGS_LAUNCH_CHECK("duplicate_keys", s, a.debug);
+    HGS_LAUNCH_CHECK("duplicate_tiles", s, a.debug);
   }
   return HGS_OK;
 }

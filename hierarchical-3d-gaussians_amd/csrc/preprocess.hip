@@ -168,11 +168,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       // never a candidate, exactly like the exact test)
       const float thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
       rec[3] = make_float4(gx_lo, gy_lo, thr, 0.0f);
-      g.depths[idx] = pr.tz;
       g.rects[idx * 2 + 0] = (uint32_t)pr.minx | ((uint32_t)pr.miny << 16);
       g.rects[idx * 2 + 1] = (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16);
     }
     radii[idx] = rad;
+    g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
     g.tiles_touched[idx] = touched;
     g.flags[idx] = flags;
   }
@@ -460,9 +460,9 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   return HGS_OK;
 }
 
-int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug) {
+int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, g.block_sums, nblk);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblk);
   HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
   return HGS_OK;
 }

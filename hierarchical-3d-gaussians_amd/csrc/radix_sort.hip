@@ -19,11 +19,13 @@ constexpr int kRsItems = 16;                       // keys per lane
 constexpr int kRsChunk = kRsThreads * kRsItems;    // keys per workgroup
 constexpr int kRadix = 256;
 
-__device__ __forceinline__ uint32_t digit_of(uint64_t k, int shift, uint32_t mask) {
+template <typename K>
+__device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
   return (uint32_t)(k >> shift) & mask;
 }
 
-__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const uint64_t* __restrict__ keys, uint32_t n,
+template <typename K>
+__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const K* __restrict__ keys, uint32_t n,
                                                                   int shift, uint32_t mask, uint32_t nblk,
                                                                   uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[kRadix];
@@ -70,9 +72,11 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ cou
   if (tid == 0) totals[blockIdx.x] = carry_s;
 }
 
-__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint64_t* __restrict__ keys_in,
+// vals_in == nullptr means "values are the input positions" (iota), saving a pass over an index array.
+template <typename K>
+__global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
-                                                                uint64_t* __restrict__ keys_out,
+                                                                K* __restrict__ keys_out,
                                                                 uint32_t* __restrict__ vals_out, uint32_t n,
                                                                 int shift, uint32_t mask, uint32_t nblk,
                                                                 const uint32_t* __restrict__ counts,
@@ -103,14 +107,14 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint64_t* 
 
   // each wave owns a contiguous run of 64*kRsItems keys; item i of lane l sits at run + i*64 + l
   const uint32_t run = blockIdx.x * (uint32_t)kRsChunk + wave * (64u * kRsItems);
-  uint64_t key[kRsItems];
+  K key[kRsItems];
   uint32_t rank[kRsItems];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int i = 0; i < kRsItems; ++i) {
     const uint32_t idx = run + i * 64 + lane;
     const bool valid = idx < n;
-    key[i] = valid ? keys_in[idx] : ~0ull;
+    key[i] = valid ? keys_in[idx] : (K)~(K)0;
     const uint32_t d = digit_of(key[i], shift, mask);
     // lanes holding the same digit (invalid lanes never match a valid one)
     uint64_t same = __ballot(valid);
@@ -147,13 +151,14 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const uint64_t* 
       const uint32_t d = digit_of(key[i], shift, mask);
       const uint32_t pos = wave_hist[wave][d] + rank[i];
       keys_out[pos] = key[i];
-      vals_out[pos] = vals_in[idx];
+      vals_out[pos] = vals_in ? vals_in[idx] : idx;
     }
   }
 }
 
+template <typename K>
 struct SortTmp {
-  uint64_t* keys_alt;
+  K* keys_alt;
   uint32_t* vals_alt;
   uint32_t* counts;
   uint32_t* totals;
@@ -161,52 +166,66 @@ struct SortTmp {
 
 inline uint32_t rs_blocks(uint32_t n) { return (n + kRsChunk - 1) / kRsChunk; }
 
-inline SortTmp carve_sort_tmp(void* tmp, uint32_t n) {
+template <typename K>
+inline SortTmp<K> carve_sort_tmp(void* tmp, uint32_t n) {
   char* p = static_cast<char*>(tmp);
-  SortTmp t;
-  t.keys_alt = carve<uint64_t>(p, n);
+  SortTmp<K> t;
+  t.keys_alt = carve<K>(p, n);
   t.vals_alt = carve<uint32_t>(p, n);
   t.counts = carve<uint32_t>(p, (size_t)kRadix * rs_blocks(n));
   t.totals = carve<uint32_t>(p, kRadix);
   return t;
 }
 
+template <typename K>
+int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_t* vals_out, void* tmp, uint32_t n,
+                 int end_bit, hipStream_t s, bool debug) {
+  if (n == 0) return HGS_OK;
+  const int maxbit = (int)sizeof(K) * 8;
+  if (end_bit < 1) end_bit = 1;
+  if (end_bit > maxbit) end_bit = maxbit;
+  const int passes = (end_bit + 7) / 8;
+  const SortTmp<K> t = carve_sort_tmp<K>(tmp, n);
+  const uint32_t nblk = rs_blocks(n);
+  // ping-pong between (out) and (alt) such that the LAST pass writes (out); pass 0 reads (in).
+  const K* src_k = keys_in;
+  const uint32_t* src_v = vals_in;
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) % 2) == 0;
+    K* dst_k = to_out ? keys_out : t.keys_alt;
+    uint32_t* dst_v = to_out ? vals_out : t.vals_alt;
+    const int shift = p * 8;
+    const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
+    const uint32_t mask = (1u << bits) - 1u;
+    hipLaunchKernelGGL(rs_histogram_kernel<K>, dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, shift, mask, nblk,
+                       t.counts);
+    HGS_LAUNCH_CHECK("rs_histogram", s, debug);
+    hipLaunchKernelGGL(rs_scan_kernel, dim3(kRadix), dim3(256), 0, s, t.counts, nblk, t.totals);
+    HGS_LAUNCH_CHECK("rs_scan", s, debug);
+    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(nblk), dim3(kRsThreads), 0, s, src_k, src_v, dst_k, dst_v, n,
+                       shift, mask, nblk, t.counts, t.totals);
+    HGS_LAUNCH_CHECK("rs_scatter", s, debug);
+    src_k = dst_k;
+    src_v = dst_v;
+  }
+  return HGS_OK;
+}
+
 }  // namespace
 
-size_t sort_tmp_bytes(uint32_t n) {
+size_t sort_tmp_bytes(uint32_t n) {   // sized for 64-bit keys (covers the 32-bit sorts too)
   return align_up((size_t)n * 8) + align_up((size_t)n * 4) + align_up((size_t)kRadix * rs_blocks(n) * 4) +
          align_up(kRadix * 4) + kAlign;
 }
 
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
-  if (n == 0) return HGS_OK;
-  if (end_bit < 1) end_bit = 1;
-  if (end_bit > 64) end_bit = 64;
-  const int passes = (end_bit + 7) / 8;
-  const SortTmp t = carve_sort_tmp(tmp, n);
-  const uint32_t nblk = rs_blocks(n);
-  // ping-pong between (out) and (alt) such that the LAST pass writes (out); pass 0 reads (in).
-  const uint64_t* src_k = keys_in;
-  const uint32_t* src_v = vals_in;
-  for (int p = 0; p < passes; ++p) {
-    const bool to_out = ((passes - 1 - p) % 2) == 0;
-    uint64_t* dst_k = to_out ? keys_out : t.keys_alt;
-    uint32_t* dst_v = to_out ? vals_out : t.vals_alt;
-    const int shift = p * 8;
-    const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
-    const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(rs_histogram_kernel, dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, shift, mask, nblk, t.counts);
-    HGS_LAUNCH_CHECK("rs_histogram", s, debug);
-    hipLaunchKernelGGL(rs_scan_kernel, dim3(kRadix), dim3(256), 0, s, t.counts, nblk, t.totals);
-    HGS_LAUNCH_CHECK("rs_scan", s, debug);
-    hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblk), dim3(kRsThreads), 0, s, src_k, src_v, dst_k, dst_v, n, shift,
-                       mask, nblk, t.counts, t.totals);
-    HGS_LAUNCH_CHECK("rs_scatter", s, debug);
-    src_k = dst_k;
-    src_v = dst_v;
-  }
-  return HGS_OK;
+  return sort_pairs_t<uint64_t>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
+}
+
+int sort_pairs32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
+                 void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
+  return sort_pairs_t<uint32_t>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
 }
 
 }  // namespace hgs

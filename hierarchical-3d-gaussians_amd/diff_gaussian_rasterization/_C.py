@@ -200,7 +200,7 @@ def raster_views(call):
     P, L, W, H = call.P, call.L, call.W, call.H
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
-        "keys_sorted": view(call.binb, v.keys_sorted, torch.int64, L),
+        "tile_ids_sorted": view(call.binb, v.tile_ids_sorted, torch.int32, L),
         "point_list": view(call.binb, v.point_list, torch.int32, L),
         "ranges": view(call.binb, v.ranges, torch.int32, T * 2).view(T, 2),
         "tiles_touched": view(call.geom, v.tiles_touched, torch.int32, P),

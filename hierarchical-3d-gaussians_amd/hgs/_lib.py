@@ -37,7 +37,7 @@ class RasterGrads(C.Structure):
 
 class RasterViews(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
-        "keys_sorted", "point_list", "ranges", "tiles_touched", "offsets", "depths", "rects",
+        "tile_ids_sorted", "point_list", "ranges", "tiles_touched", "offsets", "depths", "rects",
         "records", "final_T", "n_contrib")]
 
 

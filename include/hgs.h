@@ -128,7 +128,8 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
 /* Introspection for the parity tests ("bit-exact on tile/sort indices"):
  * device pointers into the workspaces after stage 2. */
 typedef struct hgs_raster_views {
-  const uint64_t* keys_sorted;   /* [L] (tile<<32 | depth bits) */
+  const uint32_t* tile_ids_sorted; /* [L] tile id per sorted instance; with depths[point_list[i]] this is the
+                                     (tile<<32 | depth bits) key sequence of the reference's sort */
   const uint32_t* point_list;    /* [L] Gaussian id per sorted instance */
   const uint32_t* ranges;        /* [T,2] start,end per tile */
   const uint32_t* tiles_touched; /* [P] */

@@ -124,7 +124,10 @@ def check_indices(hip, oracle_out):
     if res["num_rendered"] == 0:
         excl = np.cumsum(geom.tiles_touched.astype(np.int64)) - geom.tiles_touched
         res["offsets"] = int((v["offsets"].numpy().astype(np.int64)[vis] != excl[vis]).sum())
-        res["keys_sorted"] = int((v["keys_sorted"].numpy().view(np.uint64) != binning.keys_sorted).sum())
+        # the op sorts by depth first and by tile second; its (tile | depth) key sequence is rebuilt here
+        keys = (v["tile_ids_sorted"].numpy().astype(np.uint64) << np.uint64(32)) | \
+            v["depths"].numpy().view(np.uint32)[v["point_list"].numpy()].astype(np.uint64)
+        res["keys_sorted"] = int((keys != binning.keys_sorted).sum())
         res["point_list"] = int((v["point_list"].numpy() != binning.point_list).sum())
         res["ranges"] = int((v["ranges"].numpy() != binning.ranges).sum())
     return res

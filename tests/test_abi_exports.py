@@ -45,7 +45,7 @@ def test_workspace_size_queries_need_no_gpu():
     g, b, i, w = (C.c_size_t() for _ in range(4))
     assert lib.hgs_raster_ws_sizes(1_000_000, 1920, 1080, 2_667_604, C.byref(g), C.byref(b), C.byref(i), C.byref(w)) == 0
     assert g.value >= 1_000_000 * (64 + 4 + 8 + 12)
-    assert b.value >= 2_667_604 * (12 + 12 + 12)
+    assert b.value >= 2_667_604 * (16 + 12)
     assert i.value >= 1920 * 1080 * 8
     assert w.value >= 2_667_604 * 48
     assert lib.hgs_raster_ws_sizes(-1, 10, 10, 0, None, None, None, None) != 0

@@ -226,7 +226,9 @@ def test_full_size_properties(gpu):
     bg = torch.zeros(3)
     a = pa.run_hip(scene, cam, bg, gc, gd, gpu, debug=False)
     b = pa.run_hip(scene, cam, bg, gc, gd, gpu, debug=False)
-    keys = a["views"]["keys_sorted"].numpy().view(np.uint64)
+    pl0 = a["views"]["point_list"].numpy()
+    keys = (a["views"]["tile_ids_sorted"].numpy().astype(np.uint64) << np.uint64(32)) | \
+        a["views"]["depths"].numpy().view(np.uint32)[pl0].astype(np.uint64)
     assert a["L"] == int(a["views"]["tiles_touched"].numpy().astype(np.int64).sum())
     assert np.all(keys[1:] >= keys[:-1])
     tiles = (keys >> np.uint64(32)).astype(np.int64)
