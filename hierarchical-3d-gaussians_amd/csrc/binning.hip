@@ -15,12 +15,16 @@ namespace hgs {
 namespace {
 
 // Per-workgroup instance counts in DEPTH-SORTED Gaussian order (feeds the emission-offset scan).
+__device__ __forceinline__ uint32_t rect_count(uint2 r) {     // rects are zero for culled Gaussians
+  return ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
+}
+
 __global__ __launch_bounds__(kPreBlock) void sorted_block_sums_kernel(int P, const uint32_t* __restrict__ perm,
-                                                                      const uint32_t* __restrict__ tiles_touched,
+                                                                      const uint2* __restrict__ rects,
                                                                       uint32_t* __restrict__ block_sums) {
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   const int i = blockIdx.x * kPreBlock + threadIdx.x;
-  uint32_t v = (i < P) ? tiles_touched[perm[i]] : 0u;
+  uint32_t v = (i < P) ? rect_count(rects[perm[i]]) : 0u;   // one 8-byte gather per Gaussian
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
@@ -42,11 +46,14 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
                                                                     uint32_t* __restrict__ vals) {
   __shared__ uint32_t excl[kPreBlock + 1];
   __shared__ uint32_t gids[kPreBlock];
+  __shared__ uint2 lrect[kPreBlock];
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blockIdx.x * kPreBlock + tid;
   const uint32_t gid = (i < P) ? g.perm[i] : 0u;
-  const uint32_t cnt = (i < P) ? g.tiles_touched[gid] : 0u;
+  const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
+  const uint32_t cnt = rect_count(myrect);
+  lrect[tid] = myrect;
   uint32_t inc = cnt;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -76,9 +83,9 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
     }
     const uint32_t gg = gids[lo];
     const uint32_t k = s - excl[lo];
-    const uint32_t rmin = g.rects[gg * 2 + 0], rmax = g.rects[gg * 2 + 1];
-    const uint32_t minx = rmin & 0xffffu, miny = rmin >> 16;
-    const uint32_t w = (rmax & 0xffffu) - minx;
+    const uint2 rc = lrect[lo];
+    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
+    const uint32_t w = (rc.y & 0xffffu) - minx;
     const uint32_t ty = miny + k / w, tx = minx + k % w;
     tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
     vals[block_base + s] = gg;
@@ -107,8 +114,8 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 int launch_sorted_block_sums(const hgs_raster_args& a, const GeomWs& g, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
-    hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.perm, g.tiles_touched,
-                       g.sorted_block_sums);
+    hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.perm,
+                       reinterpret_cast<const uint2*>(g.rects), g.sorted_block_sums);
     HGS_LAUNCH_CHECK("sorted_block_sums", s, a.debug);
   }
   return HGS_OK;

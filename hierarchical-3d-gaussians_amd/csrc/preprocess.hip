@@ -168,9 +168,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       // never a candidate, exactly like the exact test)
       const float thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
       rec[3] = make_float4(gx_lo, gy_lo, thr, 0.0f);
-      g.rects[idx * 2 + 0] = (uint32_t)pr.minx | ((uint32_t)pr.miny << 16);
-      g.rects[idx * 2 + 1] = (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16);
     }
+    // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
+    reinterpret_cast<uint2*>(g.rects)[idx] =
+        pr.visible ? make_uint2((uint32_t)pr.minx | ((uint32_t)pr.miny << 16), (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16))
+                   : make_uint2(0u, 0u);
     radii[idx] = rad;
     g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
     g.tiles_touched[idx] = touched;

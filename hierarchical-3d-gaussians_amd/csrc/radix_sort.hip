@@ -15,25 +15,32 @@ namespace {
 
 constexpr int kRsThreads = 256;
 constexpr int kRsWaves = kRsThreads / 64;
-constexpr int kRsItems = 16;                       // keys per lane
-constexpr int kRsChunk = kRsThreads * kRsItems;    // keys per workgroup
 constexpr int kRadix = 256;
+// Keys per lane.  The scatter kernel is a chain of latency-bound phases (offset loads, key loads,
+// ranking, scattered stores), so what matters below ~10 M keys is how many workgroups overlap on a
+// CU, not work per workgroup: 4 keys per lane (1024 per workgroup) keeps ~10 workgroups per CU in
+// flight at the 1-3 M keys of a 1080p frame; 16 per lane amortises the per-workgroup offset loads
+// once there are enough keys to fill the chip anyway.
+constexpr int kRsItemsSmall = 4;
+constexpr int kRsItemsLarge = 16;
+constexpr uint32_t kRsLargeThreshold = 8u << 20;
+inline int rs_items(uint32_t n) { return n >= kRsLargeThreshold ? kRsItemsLarge : kRsItemsSmall; }
 
 template <typename K>
 __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
   return (uint32_t)(k >> shift) & mask;
 }
 
-template <typename K>
+template <typename K, int ITEMS>
 __global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const K* __restrict__ keys, uint32_t n,
                                                                   int shift, uint32_t mask, uint32_t nblk,
                                                                   uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[kRadix];
   hist[threadIdx.x] = 0;
   __syncthreads();
-  const uint32_t base = blockIdx.x * (uint32_t)kRsChunk;
+  const uint32_t base = blockIdx.x * (uint32_t)(kRsThreads * ITEMS);
 #pragma unroll
-  for (int i = 0; i < kRsItems; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t idx = base + i * kRsThreads + threadIdx.x;
     if (idx < n) atomicAdd(&hist[digit_of(keys[idx], shift, mask)], 1u);
   }
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void rs_scan_kernel(uint32_t* __restrict__ cou
 }
 
 // vals_in == nullptr means "values are the input positions" (iota), saving a pass over an index array.
-template <typename K>
+template <typename K, int ITEMS>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 K* __restrict__ keys_out,
@@ -105,13 +112,13 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K* __restr
   }
   __syncthreads();
 
-  // each wave owns a contiguous run of 64*kRsItems keys; item i of lane l sits at run + i*64 + l
-  const uint32_t run = blockIdx.x * (uint32_t)kRsChunk + wave * (64u * kRsItems);
-  K key[kRsItems];
-  uint32_t rank[kRsItems];
+  // each wave owns a contiguous run of 64*ITEMS keys; item i of lane l sits at run + i*64 + l
+  const uint32_t run = blockIdx.x * (uint32_t)(kRsThreads * ITEMS) + wave * (64u * ITEMS);
+  K key[ITEMS];
+  uint32_t rank[ITEMS];
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-  for (int i = 0; i < kRsItems; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t idx = run + i * 64 + lane;
     const bool valid = idx < n;
     key[i] = valid ? keys_in[idx] : (K)~(K)0;
@@ -145,7 +152,7 @@ __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K* __restr
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < kRsItems; ++i) {
+  for (int i = 0; i < ITEMS; ++i) {
     const uint32_t idx = run + i * 64 + lane;
     if (idx < n) {
       const uint32_t d = digit_of(key[i], shift, mask);
@@ -164,7 +171,7 @@ struct SortTmp {
   uint32_t* totals;
 };
 
-inline uint32_t rs_blocks(uint32_t n) { return (n + kRsChunk - 1) / kRsChunk; }
+inline uint32_t rs_blocks(uint32_t n, int items) { return (n + kRsThreads * items - 1) / (kRsThreads * items); }
 
 template <typename K>
 inline SortTmp<K> carve_sort_tmp(void* tmp, uint32_t n) {
@@ -172,12 +179,12 @@ inline SortTmp<K> carve_sort_tmp(void* tmp, uint32_t n) {
   SortTmp<K> t;
   t.keys_alt = carve<K>(p, n);
   t.vals_alt = carve<uint32_t>(p, n);
-  t.counts = carve<uint32_t>(p, (size_t)kRadix * rs_blocks(n));
+  t.counts = carve<uint32_t>(p, (size_t)kRadix * rs_blocks(n, rs_items(n)));
   t.totals = carve<uint32_t>(p, kRadix);
   return t;
 }
 
-template <typename K>
+template <typename K, int ITEMS>
 int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_t* vals_out, void* tmp, uint32_t n,
                  int end_bit, hipStream_t s, bool debug) {
   if (n == 0) return HGS_OK;
@@ -186,7 +193,7 @@ int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_
   if (end_bit > maxbit) end_bit = maxbit;
   const int passes = (end_bit + 7) / 8;
   const SortTmp<K> t = carve_sort_tmp<K>(tmp, n);
-  const uint32_t nblk = rs_blocks(n);
+  const uint32_t nblk = rs_blocks(n, ITEMS);
   // ping-pong between (out) and (alt) such that the LAST pass writes (out); pass 0 reads (in).
   const K* src_k = keys_in;
   const uint32_t* src_v = vals_in;
@@ -197,12 +204,12 @@ int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_
     const int shift = p * 8;
     const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL(rs_histogram_kernel<K>, dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, shift, mask, nblk,
+    hipLaunchKernelGGL((rs_histogram_kernel<K, ITEMS>), dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, shift, mask, nblk,
                        t.counts);
     HGS_LAUNCH_CHECK("rs_histogram", s, debug);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(kRadix), dim3(256), 0, s, t.counts, nblk, t.totals);
     HGS_LAUNCH_CHECK("rs_scan", s, debug);
-    hipLaunchKernelGGL(rs_scatter_kernel<K>, dim3(nblk), dim3(kRsThreads), 0, s, src_k, src_v, dst_k, dst_v, n,
+    hipLaunchKernelGGL((rs_scatter_kernel<K, ITEMS>), dim3(nblk), dim3(kRsThreads), 0, s, src_k, src_v, dst_k, dst_v, n,
                        shift, mask, nblk, t.counts, t.totals);
     HGS_LAUNCH_CHECK("rs_scatter", s, debug);
     src_k = dst_k;
@@ -214,18 +221,22 @@ int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_
 }  // namespace
 
 size_t sort_tmp_bytes(uint32_t n) {   // sized for 64-bit keys (covers the 32-bit sorts too)
-  return align_up((size_t)n * 8) + align_up((size_t)n * 4) + align_up((size_t)kRadix * rs_blocks(n) * 4) +
-         align_up(kRadix * 4) + kAlign;
+  return align_up((size_t)n * 8) + align_up((size_t)n * 4) +
+         align_up((size_t)kRadix * rs_blocks(n, rs_items(n)) * 4) + align_up(kRadix * 4) + kAlign;
 }
 
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
-  return sort_pairs_t<uint64_t>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
+  return rs_items(n) == kRsItemsLarge
+             ? sort_pairs_t<uint64_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug)
+             : sort_pairs_t<uint64_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
 }
 
 int sort_pairs32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
                  void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
-  return sort_pairs_t<uint32_t>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
+  return rs_items(n) == kRsItemsLarge
+             ? sort_pairs_t<uint32_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug)
+             : sort_pairs_t<uint32_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
 }
 
 }  // namespace hgs
