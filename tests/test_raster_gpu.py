@@ -190,7 +190,8 @@ def test_rejects_bad_inputs(gpu):
           rotations=z(4, 4))                                                                         # CPU tensor
 
 
-@pytest.mark.parametrize("n,end_bit", [(1, 8), (63, 13), (4097, 38), (100000, 45), (1 << 20, 47), (300001, 64)])
+@pytest.mark.parametrize("n,end_bit", [(1, 8), (63, 13), (4097, 38), (100000, 45), (1 << 20, 47), (300001, 64),
+                                       (9_000_001, 40)])   # last case: the 16-keys-per-lane path (>= 8 Mi keys)
 def test_sort_pairs_is_a_stable_sort(gpu, n, end_bit):
     """K4 alone: bit-exact against numpy's stable argsort, with many duplicate keys."""
     import ctypes as C
@@ -248,3 +249,50 @@ def test_full_size_properties(gpu):
     d = a["views"]["depths"].numpy()[pl]
     same_tile = tiles[1:] == tiles[:-1]
     assert np.all(d[1:][same_tile] >= d[:-1][same_tile])
+
+
+def test_4k_8m_gaussians_forward_backward(gpu):
+    """Scale / capacity case in the direction of BASELINE config 5 (4K frame, many Gaussians): 8 M Gaussians
+    at 3840x2160 (L ~ 21 M tile instances).  Pixel parity against the oracle on a random sample of tiles,
+    index invariants on the whole frame, finite deterministic gradients."""
+    from oracle import raster_oracle as ro
+    W, H, P = 3840, 2160, 8_000_000
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(P, cam, seed=0, sh_degree=3)
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    a = pa.run_hip(scene, cam, bg, gc, gd, gpu, debug=False)
+    assert a["L"] > 2 * P
+    tiles_sorted = a["views"]["tile_ids_sorted"].numpy()
+    assert np.all(tiles_sorted[1:] >= tiles_sorted[:-1])
+    rng_ = a["views"]["ranges"].numpy().astype(np.int64)
+    assert np.array_equal(rng_[:, 1] - rng_[:, 0], np.bincount(tiles_sorted, minlength=rng_.shape[0]))
+    pl = a["views"]["point_list"].numpy()
+    d = a["views"]["depths"].numpy()[pl]
+    same = tiles_sorted[1:] == tiles_sorted[:-1]
+    assert np.all(d[1:][same] >= d[:-1][same])
+    for k, g in a["grads"].items():
+        assert torch.isfinite(g).all(), k
+    # pixel parity on 24 random tiles (the oracle renders only those)
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    tiles = sorted(np.random.default_rng(7).choice(T, size=24, replace=False).tolist())
+    oo = ro.rasterize(scene.means3D, None, scene.shs, None, scene.opacities, scene.scales, scene.rotations, None,
+                      image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+                      scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                      sh_degree=3, campos=cam.camera_center, tiles=tiles)
+    assert int((a["radii"].numpy() != oo.geom.radii).sum()) == 0
+    assert a["L"] == oo.binning.num_rendered
+    assert np.array_equal(pl, oo.binning.point_list), "sorted instance list must be bit-exact at scale too"
+    gx = (W + 15) // 16
+    worst = 0.0
+    for t in tiles:
+        y0, x0 = (t // gx) * 16, (t % gx) * 16
+        ok = torch.from_numpy(~oo.fragile[y0:y0 + 16, x0:x0 + 16])
+        hip_t = a["color"][:, y0:y0 + 16, x0:x0 + 16][:, ok]
+        ref_t = oo.color[:, y0:y0 + 16, x0:x0 + 16][:, ok]
+        worst = max(worst, float((hip_t.double() - ref_t).abs().max()))
+        hd = a["invdepth"][:, y0:y0 + 16, x0:x0 + 16][:, ok]
+        rd = oo.invdepth[:, y0:y0 + 16, x0:x0 + 16][:, ok]
+        worst = max(worst, float((hd.double() - rd).abs().max()))
+    print("4k sample max abs pixel error", worst)
+    assert worst <= 1e-5
