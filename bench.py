@@ -151,6 +151,8 @@ def main():
         t.requires_grad_(True)
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
     bucket = dp.GradBucket({k: tuple(v.shape) for k, v in params.items()}, dev) if world > 1 else None
+    if bucket is not None:
+        dgr._RasterizeGaussians.grad_buffers = bucket.views     # the backward writes straight into the bucket
     info = {}
 
     def step():
@@ -161,7 +163,6 @@ def main():
         info["radii"] = radii
         grads = torch.autograd.grad([color, invd], [params[k] for k in params] + [means2D], [gc, gd])
         if bucket is not None:
-            bucket.fill(dict(zip(params.keys(), grads)))
             bucket.all_reduce()
         return grads
 

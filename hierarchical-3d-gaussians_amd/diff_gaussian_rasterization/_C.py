@@ -151,9 +151,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
-def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth):
+def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None):
     """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-    dL_dscales, dL_drotations); entries for absent inputs are None."""
+    dL_dscales, dL_drotations); entries for absent inputs are None.  ``out``: optional dict of
+    preallocated float32 GPU tensors (keys means3D, shs, colors_precomp, opacities, scales, rotations,
+    cov3D_precomp) the gradients are written into -- e.g. the views of a data-parallel flat bucket."""
     lib = _lib.lib()
     a, P, dev = call.args, call.P, call.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -163,14 +165,23 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth)
     if use_depth:
         dL_dinvdepth = dL_dinvdepth.to(torch.float32).contiguous()
     g = _lib.RasterGrads()
-    d_m3 = torch.empty(P, 3, **f32)
+
+    def buf(name, shape):
+        t = None if out is None else out.get(name)
+        if t is not None:
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != int(torch.Size(shape).numel()):
+                raise RuntimeError(f"gradient buffer for {name} must be a contiguous float32 GPU tensor of shape {tuple(shape)}")
+            return t.view(*shape)
+        return torch.empty(*shape, **f32)
+
+    d_m3 = buf("means3D", (P, 3))
     d_m2 = torch.empty(P, 3, **f32)
-    d_op = torch.empty(P, 1, **f32)
-    d_sh = torch.empty_like(sh) if sh is not None else None
-    d_col = torch.empty(P, 3, **f32) if colors is not None else None
-    d_sc = torch.empty(P, 3, **f32) if scales is not None else None
-    d_rot = torch.empty(P, 4, **f32) if rotations is not None else None
-    d_cov = torch.empty(P, 6, **f32) if cov3D is not None else None
+    d_op = buf("opacities", (P, 1))
+    d_sh = buf("shs", tuple(sh.shape)) if sh is not None else None
+    d_col = buf("colors_precomp", (P, 3)) if colors is not None else None
+    d_sc = buf("scales", (P, 3)) if scales is not None else None
+    d_rot = buf("rotations", (P, 4)) if rotations is not None else None
+    d_cov = buf("cov3D_precomp", (P, 6)) if cov3D is not None else None
     p = _lib.ptr
     g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)

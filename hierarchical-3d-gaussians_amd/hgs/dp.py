@@ -29,7 +29,9 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # HGS_DP_BACKEND=gloo lets several ranks share one GPU (functional test of the N>1 path on a
+            # single-GPU box); production is "nccl" = RCCL over xGMI, one rank per GPU.
+            backend = os.environ.get("HGS_DP_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
