@@ -40,9 +40,9 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     b = {}
     b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P
     b["scan"] = 8 * (P // 256 + 1)
-    b["sort_depth"] = 16 * P + 8 * P            # one pass over (depth key, id) pairs + the emission-offset scan inputs
-    b["duplicate_keys"] = 16 * P + 8 * L
+    b["duplicate_keys"] = 12 * P + 8 * L
     b["radix_sort"] = 16 * L                     # one pass over (tile id, Gaussian id) pairs
+    b["tile_depth_sort"] = 8 * T + 4 * L + 4 * L + 4 * L   # ids in, depth gather, ids out
     b["tile_ranges"] = 4 * L + 8 * T
     b["render_fwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N + 8 * N
     b["memset_bwd"] = inst * L

@@ -10,10 +10,10 @@
 namespace hgs {
 
 // ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
-enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_SORT_DEPTH, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_RENDER_FWD,
+enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SORT_DEPTH, ST_RENDER_FWD,
              ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "sort_depth", "duplicate_keys", "radix_sort",
-                                            "tile_ranges", "render_fwd", "memset_bwd", "render_bwd",
+static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
+                                            "tile_depth_sort", "render_fwd", "memset_bwd", "render_bwd",
                                             "preprocess_bwd"};
 struct Pending { int stage; hipEvent_t a, b; };
 static bool g_timing = false;
@@ -55,8 +55,8 @@ void set_error(const char* fmt, ...) {
 size_t GeomWs::bytes(int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
   const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
-  return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 5 * align_up(p * 4) +
-         2 * align_up((nblk + 1) * 4) + sort_tmp_bytes((uint32_t)p) + kAlign;
+  return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
+         align_up((nblk + 1) * 4) + kAlign;
 }
 GeomWs GeomWs::carve_from(void* base, int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -70,10 +70,6 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
   g.offsets = carve<uint32_t>(c, p);
   g.flags = carve<uint32_t>(c, p);
   g.block_sums = carve<uint32_t>(c, nblk + 1);
-  g.depth_keys = carve<uint32_t>(c, p);
-  g.perm = carve<uint32_t>(c, p);
-  g.sorted_block_sums = carve<uint32_t>(c, nblk + 1);
-  g.sort_tmp = c;
   return g;
 }
 
@@ -164,25 +160,8 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
   if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   HGS_HIP(hipMemcpyAsync(L_out_host, g.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  // The host only waits for L (to size the binning workspace); the depth sort that follows keeps the
-  // GPU busy meanwhile.
-  hipEvent_t ev;
-  HGS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-  hipError_t e = hipEventRecord(ev, s);
-  if (e == hipSuccess) {
-    rc = HGS_TIMED(ST_SORT_DEPTH, s, [&]() {
-      // stable sort of the Gaussian ids by view depth (float bits of positive depths order like integers)
-      int r = sort_pairs32(reinterpret_cast<const uint32_t*>(g.depths), nullptr, g.depth_keys, g.perm, g.sort_tmp,
-                           (uint32_t)a->P, 32, s, a->debug);
-      if (r) return r;
-      if ((r = launch_sorted_block_sums(*a, g, s))) return r;
-      return launch_scan_block_sums(g.sorted_block_sums, a->P, s, a->debug);
-    }());
-    e = hipEventSynchronize(ev);
-  }
-  (void)hipEventDestroy(ev);
-  if (e != hipSuccess) { set_error("stage1 sync failed: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
-  return rc;
+  HGS_HIP(hipStreamSynchronize(s));
+  return HGS_OK;
 }
 
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
@@ -201,6 +180,7 @@ int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws,
     if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, tile_bits(T), s, a->debug)))) return rc;
   }
   if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, T, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, s)))) return rc;
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
 }
 

@@ -1,14 +1,20 @@
-// K3 (duplicateWithKeys) and K5 (identifyTileRanges).
+// K3 (duplicateWithKeys), the per-tile depth sort, and K5 (identifyTileRanges).
 //
-// The (tile | depth) sort is split: the P Gaussians are sorted by depth first (32-bit keys,
-// 4 passes over P elements), K3 then emits the L (tile, Gaussian) instances in that order, and a
-// stable sort by the tile id alone (13 bits at 1080p: 2 passes over L) finishes the job -- the
-// result is identical to one stable 45-bit sort of L 64-bit keys (6 passes over L), at less than
-// half the traffic.
+// The reference sorts L 64-bit (tile | depth) keys in one global radix sort.  Here the two key
+// halves are handled where they are cheap:
+//   1. K3 emits (tile id, Gaussian id) per instance in ascending Gaussian index;
+//   2. a STABLE global radix sort by the tile id alone (13 bits at 1080p: 2 passes of 32-bit keys)
+//      groups the instances per tile, each group still in ascending Gaussian index;
+//   3. every tile's group (327 instances on average in the benchmark) is sorted by (depth bits,
+//      Gaussian id) inside LDS by one workgroup -- bitonic network on 64-bit composite keys; groups
+//      above 16 Ki instances fall back to a single-workgroup stable LSD radix sort through global
+//      scratch.
+// The result is bit-identical to the reference's stable 64-bit sort (depth ties keep ascending
+// Gaussian index) with 2 instead of 6 passes over L and no 64-bit keys in HBM at all.
 //
-// K3 is a load-balanced expansion: a workgroup owns 256 consecutive (depth-ordered) Gaussians,
-// scans their tile counts in LDS and then assigns OUTPUT slots (not Gaussians) to lanes, so a
-// Gaussian covering hundreds of tiles does not serialise one lane and the stores are coalesced.
+// K3 is a load-balanced expansion: a workgroup owns 256 consecutive Gaussians, scans their tile
+// counts in LDS and then assigns OUTPUT slots (not Gaussians) to lanes, so a Gaussian covering
+// hundreds of tiles does not serialise one lane and the stores are coalesced.
 #include "common.h"
 
 namespace hgs {
@@ -19,38 +25,17 @@ __device__ __forceinline__ uint32_t rect_count(uint2 r) {     // rects are zero 
   return ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
 }
 
-__global__ __launch_bounds__(kPreBlock) void sorted_block_sums_kernel(int P, const uint32_t* __restrict__ perm,
-                                                                      const uint2* __restrict__ rects,
-                                                                      uint32_t* __restrict__ block_sums) {
-  __shared__ uint32_t wave_tot[kPreBlock / 64];
-  const int i = blockIdx.x * kPreBlock + threadIdx.x;
-  uint32_t v = (i < P) ? rect_count(rects[perm[i]]) : 0u;   // one 8-byte gather per Gaussian
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < kPreBlock / 64; ++w) t += wave_tot[w];
-    block_sums[blockIdx.x] = t;
-  }
-}
-
-// Emits (tile id, Gaussian id) for every tile of every visible Gaussian, walking the Gaussians in
-// depth order (perm), row-major tiles inside a rectangle.  A stable sort of the result by tile id
-// alone then equals the reference's stable sort by (tile | depth): depth ties keep ascending
-// Gaussian index because the depth sort that produced perm is stable as well.
+// Emits (tile id, Gaussian id) for every tile of every visible Gaussian: ascending Gaussian index,
+// row-major tiles inside a rectangle (SURVEY.md App. A.7 emission order).
 __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int gx, GeomWs g,
                                                                     uint32_t* __restrict__ tile_keys,
                                                                     uint32_t* __restrict__ vals) {
   __shared__ uint32_t excl[kPreBlock + 1];
-  __shared__ uint32_t gids[kPreBlock];
   __shared__ uint2 lrect[kPreBlock];
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blockIdx.x * kPreBlock + tid;
-  const uint32_t gid = (i < P) ? g.perm[i] : 0u;
+  const uint32_t gid = (uint32_t)i;
   const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
   const uint32_t cnt = rect_count(myrect);
   lrect[tid] = myrect;
@@ -66,9 +51,8 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
   for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
   const uint32_t my_excl = wbase + inc - cnt;
   excl[tid] = my_excl;
-  gids[tid] = gid;
   if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
-  const uint32_t block_base = g.sorted_block_sums[blockIdx.x];
+  const uint32_t block_base = g.block_sums[blockIdx.x];
   if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run
   __syncthreads();
   const uint32_t total = excl[kPreBlock];
@@ -81,7 +65,7 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
       const int mid = (lo + hi) >> 1;
       if (excl[mid] <= s) lo = mid; else hi = mid;
     }
-    const uint32_t gg = gids[lo];
+    const uint32_t gg = blockIdx.x * kPreBlock + lo;
     const uint32_t k = s - excl[lo];
     const uint2 rc = lrect[lo];
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
@@ -89,6 +73,126 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
     const uint32_t ty = miny + k / w, tx = minx + k % w;
     tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
     vals[block_base + s] = gg;
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Per-tile depth sort.  vals[r0..r1) holds a tile's Gaussian ids in ascending order; afterwards it
+// holds them ordered by (depth bits, id).
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kSmallCap = 2048;    // 256-thread workgroup, 16 KiB LDS
+constexpr uint32_t kLargeCap = 16384;   // 1024-thread workgroup, 128 KiB LDS
+
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t m) {
+  for (uint32_t k = 2; k <= m; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      for (uint32_t t = threadIdx.x; t < (m >> 1); t += THREADS) {
+        // t-th compare-exchange of this stage: i has bit j clear
+        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const uint32_t ixj = i | j;
+        const uint64_t a = keys[i], b = keys[ixj];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int THREADS, uint32_t LO, uint32_t HI>
+__global__ __launch_bounds__(THREADS) void tile_depth_sort_kernel(const uint32_t* __restrict__ ranges,
+                                                                  const float* __restrict__ depths,
+                                                                  uint32_t* __restrict__ vals) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
+  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
+  const uint32_t n = r1 - r0;
+  if (n <= LO || n > HI) return;          // other size classes are handled by the other launches
+  uint32_t m = 2;
+  while (m < n) m <<= 1;
+  for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
+    uint64_t k = ~0ull;
+    if (i < n) {
+      const uint32_t gid = vals[r0 + i];
+      k = ((uint64_t)__float_as_uint(depths[gid]) << 32) | gid;
+    }
+    keys[i] = k;
+  }
+  __syncthreads();
+  bitonic_sort_lds<THREADS>(keys, m);
+  for (uint32_t i = threadIdx.x; i < n; i += THREADS) vals[r0 + i] = (uint32_t)keys[i];
+}
+
+// Fallback for tiles above kLargeCap instances: one 1024-thread workgroup runs a stable LSD radix
+// sort (4 x 8 bits of the depth key, id as payload) through the tile's own slice of two global
+// scratch arrays.  Slow (one CU per such tile) but size-unbounded; ids start ascending, so a stable
+// sort by depth alone yields the (depth, id) order.
+__global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32_t* __restrict__ ranges,
+                                                                    const float* __restrict__ depths,
+                                                                    uint32_t* __restrict__ vals,
+                                                                    uint32_t* __restrict__ scratch_k,
+                                                                    uint32_t* __restrict__ scratch_v,
+                                                                    uint32_t* __restrict__ scratch_k2) {
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t base[256];
+  __shared__ uint32_t wave_cnt[16][256];
+  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
+  const uint32_t n = r1 - r0;
+  if (n <= kLargeCap) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t* kA = scratch_k + r0;    // keys ping
+  uint32_t* kB = scratch_k2 + r0;   // keys pong
+  uint32_t* vA = vals + r0;         // values ping (final result lands here: 4 passes = even)
+  uint32_t* vB = scratch_v + r0;    // values pong
+  for (uint32_t i = tid; i < n; i += 1024) kA[i] = __float_as_uint(depths[vA[i]]);
+  __syncthreads();
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = pass * 8;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&hist[(kA[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int d = 0; d < 256; ++d) { base[d] = acc; acc += hist[d]; }
+    }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += 1024) {
+      const uint32_t i = c0 + tid;
+      const bool valid = i < n;
+      const uint32_t key = valid ? kA[i] : 0u;
+      const uint32_t val = valid ? vA[i] : 0u;
+      const uint32_t d = (key >> shift) & 255u;
+      uint64_t same = __ballot(valid);
+      if (!valid) same = 0;
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const uint64_t bal = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? bal : ~bal;
+      }
+      for (int t = tid; t < 16 * 256; t += 1024) (&wave_cnt[0][0])[t] = 0;
+      __syncthreads();
+      if (valid && (same & lt_mask) == 0) wave_cnt[wave][d] = (uint32_t)__popcll(same);
+      __syncthreads();
+      uint32_t before = 0;                       // same digit in earlier waves of this chunk
+      if (valid) for (int w = 0; w < wave; ++w) before += wave_cnt[w][d];
+      const uint32_t pos = valid ? base[d] + before + (uint32_t)__popcll(same & lt_mask) : 0u;
+      __syncthreads();
+      if (tid < 256) {                           // advance the digit bases by this chunk's counts
+        uint32_t add = 0;
+        for (int w = 0; w < 16; ++w) add += wave_cnt[w][tid];
+        base[tid] += add;
+      }
+      if (valid) { kB[pos] = key; vB[pos] = val; }
+      __syncthreads();
+    }
+    uint32_t* t;
+    t = kA; kA = kB; kB = t;
+    t = vA; vA = vB; vB = t;
+    __syncthreads();
   }
 }
 
@@ -111,16 +215,6 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 }  // namespace
 
-int launch_sorted_block_sums(const hgs_raster_args& a, const GeomWs& g, hipStream_t s) {
-  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
-  if (nblk > 0) {
-    hipLaunchKernelGGL(sorted_block_sums_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.perm,
-                       reinterpret_cast<const uint2*>(g.rects), g.sorted_block_sums);
-    HGS_LAUNCH_CHECK("sorted_block_sums", s, a.debug);
-  }
-  return HGS_OK;
-}
-
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0 && L > 0) {
@@ -137,6 +231,28 @@ int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, boo
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, s, b.keys_out, L, b.ranges);
     HGS_LAUNCH_CHECK("tile_ranges", s, debug);
   }
+  return HGS_OK;
+}
+
+int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
+                           hipStream_t s) {
+  if (L == 0) return HGS_OK;
+  static bool attr_set = false;
+  if (!attr_set) {   // 128 KiB of dynamic LDS needs an explicit opt-in
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_kernel<1024, kSmallCap, kLargeCap>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tile_depth_sort_kernel<256, 1, kSmallCap>), dim3(T), dim3(256), kSmallCap * 8, s, b.ranges,
+                     g.depths, b.vals_out);
+  HGS_LAUNCH_CHECK("tile_depth_sort_small", s, a.debug);
+  hipLaunchKernelGGL((tile_depth_sort_kernel<1024, kSmallCap, kLargeCap>), dim3(T), dim3(1024), kLargeCap * 8, s,
+                     b.ranges, g.depths, b.vals_out);
+  HGS_LAUNCH_CHECK("tile_depth_sort_large", s, a.debug);
+  // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
+  hipLaunchKernelGGL(tile_depth_sort_huge_kernel, dim3(T), dim3(1024), 0, s, b.ranges, g.depths, b.vals_out,
+                     b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp));
+  HGS_LAUNCH_CHECK("tile_depth_sort_huge", s, a.debug);
   return HGS_OK;
 }
 

@@ -58,19 +58,15 @@ struct GeomWs {
   uint32_t* offsets;       // [P] exclusive
   uint32_t* flags;         // [P] bit0..2 colour clamp, bit3 tx clamped, bit4 ty clamped
   uint32_t* block_sums;    // [nblk+1] exclusive scan of per-workgroup instance counts (index order); [nblk] = L
-  uint32_t* depth_keys;    // [P] depth bits sorted ascending (by-product of the depth sort)
-  uint32_t* perm;          // [P] Gaussian ids in stable depth order
-  uint32_t* sorted_block_sums;  // [nblk+1] exclusive scan of per-workgroup instance counts in depth order
-  void* sort_tmp;          // scratch of the depth sort
   static size_t bytes(int32_t P);
   static GeomWs carve_from(void* base, int32_t P);
 };
 
 struct BinWs {
-  uint32_t* keys_in;   // [L] tile id per emitted instance (depth order)
+  uint32_t* keys_in;   // [L] tile id per emitted instance (index order)
   uint32_t* vals_in;   // [L] Gaussian id
   uint32_t* keys_out;  // [L] tile ids, stable-sorted
-  uint32_t* vals_out;  // [L] sorted = point_list
+  uint32_t* vals_out;  // [L] per tile ascending id after the tile sort; point_list after the per-tile depth sort
   uint32_t* ranges;    // [T,2]
   void* sort_tmp;
   static size_t bytes(uint32_t L, int32_t T);
@@ -95,9 +91,10 @@ inline int tile_bits(int T) {
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
 int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug);
-int launch_sorted_block_sums(const hgs_raster_args& a, const GeomWs& g, hipStream_t s);
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s);
 int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, bool debug);
+int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
+                           hipStream_t s);
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, hipStream_t s);
 int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,

@@ -122,13 +122,9 @@ def check_indices(hip, oracle_out):
     rmax = (geom.rect_max[:, 0].astype(np.uint32) | (geom.rect_max[:, 1].astype(np.uint32) << 16))
     res["rects"] = int(((rects[:, 0] != rmin) | (rects[:, 1] != rmax))[vis].sum())
     if res["num_rendered"] == 0:
-        # emission order = stable depth order of ALL Gaussians (culled ones emit nothing)
-        perm = np.argsort(v["depths"].numpy().view(np.uint32), kind="stable")
-        tt = geom.tiles_touched.astype(np.int64)
-        excl = np.empty_like(tt)
-        excl[perm] = np.cumsum(tt[perm]) - tt[perm]
+        excl = np.cumsum(geom.tiles_touched.astype(np.int64)) - geom.tiles_touched
         res["offsets"] = int((v["offsets"].numpy().astype(np.int64)[vis] != excl[vis]).sum())
-        # the op sorts by depth first and by tile second; its (tile | depth) key sequence is rebuilt here
+        # the op sorts by tile globally and by depth per tile; its (tile | depth) key sequence is rebuilt here
         keys = (v["tile_ids_sorted"].numpy().astype(np.uint64) << np.uint64(32)) | \
             v["depths"].numpy().view(np.uint32)[v["point_list"].numpy()].astype(np.uint64)
         res["keys_sorted"] = int((keys != binning.keys_sorted).sum())
