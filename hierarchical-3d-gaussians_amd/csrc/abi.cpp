@@ -75,7 +75,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
 
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
-  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + sort_tmp_bytes(L ? L : 1) + kAlign;
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 2 + 2) * 4) + sort_tmp_bytes(L ? L : 1) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
@@ -86,6 +86,7 @@ BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   b.keys_out = carve<uint32_t>(c, l);
   b.vals_out = carve<uint32_t>(c, l);
   b.ranges = carve<uint32_t>(c, (size_t)T * 2);
+  b.big_tiles = carve<uint32_t>(c, (size_t)T * 2 + 2);
   b.sort_tmp = c;
   return b;
 }
@@ -142,7 +143,7 @@ int hgs_raster_ws_sizes(int32_t P, int32_t width, int32_t height, uint32_t L, si
   if (geom_bytes) *geom_bytes = GeomWs::bytes(P);
   if (bin_bytes) *bin_bytes = BinWs::bytes(L, T);
   if (img_bytes) *img_bytes = ImgWs::bytes(width, height);
-  if (bwd_bytes) *bwd_bytes = align_up((size_t)(L ? L : 1) * kInstStride * 4) + kAlign;
+  if (bwd_bytes) *bwd_bytes = align_up((size_t)(L ? L : 1) * kInstStride * 4) + align_up((size_t)(P > 0 ? P : 1) * 3 * 4) + kAlign;
   return HGS_OK;
 }
 
@@ -207,6 +208,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   const BinWs b = BinWs::carve_from(const_cast<void*>(bin_ws), L, T);
   const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), a->width, a->height);
   float* inst = static_cast<float*>(bwd_ws);
+  float* drgb = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + align_up((size_t)(L ? L : 1) * kInstStride * 4));
   if (L > 0) {
     {
       StageTimer _t(ST_MEMSET_BWD, s);
@@ -219,7 +221,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   if (!a->colors_precomp) gr.dL_dcolors = nullptr;
   if (!a->scales) { gr.dL_dscales = nullptr; gr.dL_drotations = nullptr; }
   if (!a->cov3D_precomp) gr.dL_dcov3D = nullptr;
-  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, gr, s));
+  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, gr, s));
 }
 
 int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, const void* geom_ws,

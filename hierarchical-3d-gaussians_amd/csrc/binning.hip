@@ -101,15 +101,12 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t m) {
   }
 }
 
-template <int THREADS, uint32_t LO, uint32_t HI>
-__global__ __launch_bounds__(THREADS) void tile_depth_sort_kernel(const uint32_t* __restrict__ ranges,
-                                                                  const float* __restrict__ depths,
-                                                                  uint32_t* __restrict__ vals) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  uint64_t* keys = reinterpret_cast<uint64_t*>(smem);
-  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
-  const uint32_t n = r1 - r0;
-  if (n <= LO || n > HI) return;          // other size classes are handled by the other launches
+// big[0] / big[1]: number of tiles in the large / huge class; big + 2: large list [T], then huge list [T].
+// The small-class launch (one workgroup per tile) files oversized tiles into these lists, so the large
+// and huge launches need only a small grid that walks them (usually empty).
+template <int THREADS>
+__device__ __forceinline__ void sort_tile_in_lds(uint64_t* keys, const float* __restrict__ depths,
+                                                 uint32_t* __restrict__ vals, uint32_t r0, uint32_t n) {
   uint32_t m = 2;
   while (m < n) m <<= 1;
   for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
@@ -125,6 +122,38 @@ __global__ __launch_bounds__(THREADS) void tile_depth_sort_kernel(const uint32_t
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) vals[r0 + i] = (uint32_t)keys[i];
 }
 
+__global__ __launch_bounds__(256) void tile_depth_sort_small_kernel(const uint32_t* __restrict__ ranges,
+                                                                    const float* __restrict__ depths,
+                                                                    uint32_t* __restrict__ vals, uint32_t* big, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
+  const uint32_t n = r1 - r0;
+  if (n <= 1) return;
+  if (n > kSmallCap) {
+    if (threadIdx.x == 0) {
+      const int cls = n > kLargeCap ? 1 : 0;
+      const uint32_t slot = atomicAdd(&big[cls], 1u);
+      big[2 + cls * T + slot] = blockIdx.x;
+    }
+    return;
+  }
+  sort_tile_in_lds<256>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, n);
+}
+
+__global__ __launch_bounds__(1024) void tile_depth_sort_large_kernel(const uint32_t* __restrict__ ranges,
+                                                                     const float* __restrict__ depths,
+                                                                     uint32_t* __restrict__ vals,
+                                                                     const uint32_t* __restrict__ big, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t count = big[0];
+  for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+    const uint32_t tile = big[2 + e];
+    const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+    __syncthreads();
+    sort_tile_in_lds<1024>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
+  }
+}
+
 // Fallback for tiles above kLargeCap instances: one 1024-thread workgroup runs a stable LSD radix
 // sort (4 x 8 bits of the depth key, id as payload) through the tile's own slice of two global
 // scratch arrays.  Slow (one CU per such tile) but size-unbounded; ids start ascending, so a stable
@@ -134,14 +163,18 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32
                                                                     uint32_t* __restrict__ vals,
                                                                     uint32_t* __restrict__ scratch_k,
                                                                     uint32_t* __restrict__ scratch_v,
-                                                                    uint32_t* __restrict__ scratch_k2) {
+                                                                    uint32_t* __restrict__ scratch_k2,
+                                                                    const uint32_t* __restrict__ big, int T) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t base[256];
   __shared__ uint32_t wave_cnt[16][256];
-  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
-  const uint32_t n = r1 - r0;
-  if (n <= kLargeCap) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t count = big[1];
+  for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+  const uint32_t tile = big[2 + T + e];
+  const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+  const uint32_t n = r1 - r0;
+  __syncthreads();
   uint32_t* kA = scratch_k + r0;    // keys ping
   uint32_t* kB = scratch_k2 + r0;   // keys pong
   uint32_t* vA = vals + r0;         // values ping (final result lands here: 4 passes = even)
@@ -194,11 +227,13 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32
     t = vA; vA = vB; vB = t;
     __syncthreads();
   }
+  }   // tile loop
 }
 
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t L,
-                                                          uint32_t* __restrict__ ranges) {
+                                                          uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) { big[0] = 0; big[1] = 0; }   // big-tile lists of the depth sort that follows
   if (i >= L) return;
   const uint32_t t = keys[i];
   if (i == 0) {
@@ -228,7 +263,7 @@ int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinW
 int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, bool debug) {
   HGS_HIP(hipMemsetAsync(b.ranges, 0, (size_t)T * 2 * sizeof(uint32_t), s));
   if (L > 0) {
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, s, b.keys_out, L, b.ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, s, b.keys_out, L, b.ranges, b.big_tiles);
     HGS_LAUNCH_CHECK("tile_ranges", s, debug);
   }
   return HGS_OK;
@@ -239,19 +274,20 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   if (L == 0) return HGS_OK;
   static bool attr_set = false;
   if (!attr_set) {   // 128 KiB of dynamic LDS needs an explicit opt-in
-    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_kernel<1024, kSmallCap, kLargeCap>),
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_large_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
     attr_set = true;
   }
-  hipLaunchKernelGGL((tile_depth_sort_kernel<256, 1, kSmallCap>), dim3(T), dim3(256), kSmallCap * 8, s, b.ranges,
-                     g.depths, b.vals_out);
+  hipLaunchKernelGGL(tile_depth_sort_small_kernel, dim3(T), dim3(256), kSmallCap * 8, s, b.ranges, g.depths,
+                     b.vals_out, b.big_tiles, T);
   HGS_LAUNCH_CHECK("tile_depth_sort_small", s, a.debug);
-  hipLaunchKernelGGL((tile_depth_sort_kernel<1024, kSmallCap, kLargeCap>), dim3(T), dim3(1024), kLargeCap * 8, s,
-                     b.ranges, g.depths, b.vals_out);
+  const int big_grid = T < 256 ? T : 256;
+  hipLaunchKernelGGL(tile_depth_sort_large_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,
+                     b.vals_out, b.big_tiles, T);
   HGS_LAUNCH_CHECK("tile_depth_sort_large", s, a.debug);
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
-  hipLaunchKernelGGL(tile_depth_sort_huge_kernel, dim3(T), dim3(1024), 0, s, b.ranges, g.depths, b.vals_out,
-                     b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp));
+  hipLaunchKernelGGL(tile_depth_sort_huge_kernel, dim3(big_grid), dim3(1024), 0, s, b.ranges, g.depths, b.vals_out,
+                     b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T);
   HGS_LAUNCH_CHECK("tile_depth_sort_huge", s, a.debug);
   return HGS_OK;
 }

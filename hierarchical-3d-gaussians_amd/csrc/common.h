@@ -68,6 +68,7 @@ struct BinWs {
   uint32_t* keys_out;  // [L] tile ids, stable-sorted
   uint32_t* vals_out;  // [L] per tile ascending id after the tile sort; point_list after the per-tile depth sort
   uint32_t* ranges;    // [T,2]
+  uint32_t* big_tiles; // [2 + 2T] counters + lists of tiles too crowded for the 256-lane LDS sort
   void* sort_tmp;
   static size_t bytes(uint32_t L, int32_t T);
   static BinWs carve_from(void* base, uint32_t L, int32_t T);
@@ -100,7 +101,7 @@ int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
 int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
-int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads,
+int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           const hgs_raster_grads& out, hipStream_t s);
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,

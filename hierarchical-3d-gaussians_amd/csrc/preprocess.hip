@@ -228,6 +228,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
+                                                                   float* __restrict__ drgb,
                                                                    hgs_raster_grads out) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   if (idx >= a.P) return;
@@ -243,13 +244,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   float sums5 = 0.f, sums6 = 0.f, sums7 = 0.f, sums8 = 0.f;
 
   if (n == 0) {
-    // culled: all-zero gradients
-    if (out.dL_dshs) {
-      float dsh[48];
-#pragma unroll
-      for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
-      store_sh(out.dL_dshs, idx, a.M, dsh);
-    }
+    // culled: all-zero gradients (K8b zero-fills dL/dSH)
   } else {
     CamLds cam;
     load_camera(a, cam);
@@ -391,7 +386,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       d_op = sums5 * dod;
     }
 
-    // colour
+    // colour: precomputed colours get their gradient here; SH colours hand the clamp-masked dL/drgb to K8b
     float gr[3] = {sums6, sums7, sums8};
     if (a.colors_precomp) {
       d_col[0] = gr[0]; d_col[1] = gr[1]; d_col[2] = gr[2];
@@ -399,33 +394,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       if (flags & 1u) gr[0] = 0.f;
       if (flags & 2u) gr[1] = 0.f;
       if (flags & 4u) gr[2] = 0.f;
-      float sh[48];
-      load_sh(a.shs, idx, a.M, sh);
-      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
-      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-      const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-      float b[16], dbx[16], dby[16], dbz[16];
-      sh_basis(a.sh_degree, ux, uy, uz, b);
-      sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
-      const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-      float gdx = 0.f, gdy = 0.f, gdz = 0.f;
-      float dsh[48];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        float o0 = 0.f, o1 = 0.f, o2 = 0.f;
-        if (k < nb) {
-          o0 = b[k] * gr[0]; o1 = b[k] * gr[1]; o2 = b[k] * gr[2];
-          const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
-          gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
-        }
-        dsh[k * 3 + 0] = o0; dsh[k * 3 + 1] = o1; dsh[k * 3 + 2] = o2;
-      }
-      store_sh(out.dL_dshs, idx, a.M, dsh);
-      // through the normalisation dir = d/|d|
-      const float dot = ux * gdx + uy * gdy + uz * gdz;
-      d_mean[0] += (gdx - ux * dot) * inv;
-      d_mean[1] += (gdy - uy * dot) * inv;
-      d_mean[2] += (gdz - uz * dot) * inv;
+      drgb[idx * 3 + 0] = gr[0];
+      drgb[idx * 3 + 1] = gr[1];
+      drgb[idx * 3 + 2] = gr[2];
     }
   }
 
@@ -451,6 +422,51 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   }
 }
 
+
+// K8b: SH part of the backward.  Pure streaming kernel (192 B of coefficients in, 192 B of gradients out
+// per Gaussian at M = 16), split from the double-precision geometry chain of K8a so that it runs at high
+// occupancy.  Adds the view-direction term to dL/dmeans3D written by K8a.
+__global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, GeomWs g,
+                                                           const float* __restrict__ drgb, hgs_raster_grads out) {
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  if (idx >= a.P) return;
+  float dsh[48];
+  if (g.tiles_touched[idx] == 0) {
+#pragma unroll
+    for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
+    store_sh(out.dL_dshs, idx, a.M, dsh);
+    return;
+  }
+  const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
+  const float px = a.means3D[idx * 3 + 0], py = a.means3D[idx * 3 + 1], pz = a.means3D[idx * 3 + 2];
+  const float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+  const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+  const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+  float b[16], dbx[16], dby[16], dbz[16];
+  sh_basis(a.sh_degree, ux, uy, uz, b);
+  sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
+  const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+  float sh[48];
+  load_sh(a.shs, idx, a.M, sh);
+  float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    float o0 = 0.f, o1 = 0.f, o2 = 0.f;
+    if (k < nb) {
+      o0 = b[k] * gr[0]; o1 = b[k] * gr[1]; o2 = b[k] * gr[2];
+      const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
+      gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
+    }
+    dsh[k * 3 + 0] = o0; dsh[k * 3 + 1] = o1; dsh[k * 3 + 2] = o2;
+  }
+  store_sh(out.dL_dshs, idx, a.M, dsh);
+  // through the normalisation dir = d/|d|
+  const float dot = ux * gdx + uy * gdy + uz * gdz;
+  out.dL_dmeans3D[idx * 3 + 0] += (gdx - ux * dot) * inv;
+  out.dL_dmeans3D[idx * 3 + 1] += (gdy - uy * dot) * inv;
+  out.dL_dmeans3D[idx * 3 + 2] += (gdz - uz * dot) * inv;
+}
+
 }  // namespace
 
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s) {
@@ -469,12 +485,16 @@ int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug)
   return HGS_OK;
 }
 
-int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads,
+int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           const hgs_raster_grads& out, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, out);
+    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
+    if (a.shs && out.dL_dshs) {
+      hipLaunchKernelGGL(sh_bwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, drgb, out);
+      HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);
+    }
   }
   return HGS_OK;
 }

@@ -134,14 +134,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     geom = torch.empty(sz[0].value, **u8)
     img = torch.empty(sz[2].value, **u8)
     radii = torch.empty(P, dtype=torch.int32, device=dev)
+    # outputs are allocated before the stage-1 sync so that only the L-sized workspace sits between the stages
+    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
+    invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev) if do_depth else \
+        torch.zeros(1, H, W, dtype=torch.float32, device=dev)
     L = C.c_uint32(0)
     _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), _lib.ptr(geom), _lib.ptr(radii), C.byref(L),
                                          _stream(dev), dev.index or 0), "hgs_raster_fwd_stage1")
     _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L.value, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
     binb = torch.empty(sz[1].value, **u8)
-    color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
-    invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev) if do_depth else \
-        torch.zeros(1, H, W, dtype=torch.float32, device=dev)
     _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L.value,
                                          _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                          _stream(dev), dev.index or 0), "hgs_raster_fwd_stage2")
