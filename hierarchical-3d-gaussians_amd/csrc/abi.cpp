@@ -165,6 +165,20 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
   return HGS_OK;
 }
 
+// Stage-2 launches.  L is exact when L_dev == nullptr; otherwise it is a capacity and the kernels read the
+// actual instance count from device memory.
+static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
+                          const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
+  int rc;
+  if (L > 0) {
+    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;
+    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
+  }
+  if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, s)))) return rc;
+  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
+}
+
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
                           float* out_color, float* out_invdepth, hgs_stream_t stream, int device) {
   int rc = validate(a);
@@ -176,13 +190,45 @@ int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws,
   const GeomWs g = GeomWs::carve_from(geom_ws, a->P);
   const BinWs b = BinWs::carve_from(bin_ws, L, T);
   const ImgWs im = ImgWs::carve_from(img_ws, a->width, a->height);
-  if (L > 0) {
-    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;
-    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, tile_bits(T), s, a->debug)))) return rc;
+  return enqueue_stage2(a, g, b, im, L, nullptr, T, out_color, out_invdepth, s);
+}
+
+int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L_cap,
+                   int32_t* radii, float* out_color, float* out_invdepth, uint32_t* L_out_host,
+                   hgs_stream_t stream, int device) {
+  int rc = validate(a);
+  if (rc) return rc;
+  if (!geom_ws || !bin_ws || !img_ws || !out_color || !L_out_host || (a->P > 0 && !radii)) {
+    set_error("null workspace/output");
+    return HGS_ERR_INVALID;
   }
-  if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, T, s, a->debug)))) return rc;
-  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, s)))) return rc;
-  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int T = grid_x(a->width) * grid_y(a->height);
+  const GeomWs g = GeomWs::carve_from(geom_ws, a->P);
+  const BinWs b = BinWs::carve_from(bin_ws, L_cap, T);
+  const ImgWs im = ImgWs::carve_from(img_ws, a->width, a->height);
+  *L_out_host = 0;
+  if (a->P == 0) return enqueue_stage2(a, g, b, im, 0, nullptr, T, out_color, out_invdepth, s);
+  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
+  const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
+  const uint32_t* L_dev = g.block_sums + nblk;
+  HGS_HIP(hipMemcpyAsync(L_out_host, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  hipEvent_t ev;
+  HGS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  hipError_t e = hipEventRecord(ev, s);
+  // everything else is enqueued before the host looks at L: the GPU never waits for the host
+  if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);
+  if (e == hipSuccess) e = hipEventSynchronize(ev);
+  (void)hipEventDestroy(ev);
+  if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
+  if (rc) return rc;
+  if (*L_out_host > L_cap) {
+    set_error("instance count %u exceeds the capacity %u given to hgs_raster_fwd", *L_out_host, L_cap);
+    return HGS_ERR_CAPACITY;
+  }
+  return HGS_OK;
 }
 
 int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bin_ws, const void* img_ws,

@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t rect_count(uint2 r) {     // rects are zero 
 
 // Emits (tile id, Gaussian id) for every tile of every visible Gaussian: ascending Gaussian index,
 // row-major tiles inside a rectangle (SURVEY.md App. A.7 emission order).
-__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int gx, GeomWs g,
+__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int gx, GeomWs g, uint32_t cap,
                                                                     uint32_t* __restrict__ tile_keys,
                                                                     uint32_t* __restrict__ vals) {
   __shared__ uint32_t excl[kPreBlock + 1];
@@ -71,8 +71,10 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
     const uint32_t w = (rc.y & 0xffffu) - minx;
     const uint32_t ty = miny + k / w, tx = minx + k % w;
-    tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
-    vals[block_base + s] = gg;
+    if (block_base + s < cap) {     // cap < L only when a speculative capacity was too small (caller retries)
+      tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
+      vals[block_base + s] = gg;
+    }
   }
 }
 
@@ -230,9 +232,11 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32
   }   // tile loop
 }
 
-__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t L,
+__global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t L_cap,
+                                                          const uint32_t* __restrict__ L_dev,
                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t L = L_dev ? min(*L_dev, L_cap) : L_cap;
   if (i == 0) { big[0] = 0; big[1] = 0; }   // big-tile lists of the depth sort that follows
   if (i >= L) return;
   const uint32_t t = keys[i];
@@ -250,20 +254,21 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 }  // namespace
 
-int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s) {
+int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
-  if (nblk > 0 && L > 0) {
-    hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g,
+  if (nblk > 0 && L_cap > 0) {
+    hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
                        b.keys_in, b.vals_in);
     HGS_LAUNCH_CHECK("duplicate_tiles", s, a.debug);
   }
   return HGS_OK;
 }
 
-int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, bool debug) {
+int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug) {
   HGS_HIP(hipMemsetAsync(b.ranges, 0, (size_t)T * 2 * sizeof(uint32_t), s));
-  if (L > 0) {
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((L + 255) / 256), dim3(256), 0, s, b.keys_out, L, b.ranges, b.big_tiles);
+  if (L_cap > 0) {
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((L_cap + 255) / 256), dim3(256), 0, s, b.keys_out, L_cap, L_dev, b.ranges,
+                       b.big_tiles);
     HGS_LAUNCH_CHECK("tile_ranges", s, debug);
   }
   return HGS_OK;

@@ -92,8 +92,8 @@ inline int tile_bits(int T) {
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
 int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug);
-int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, hipStream_t s);
-int launch_tile_ranges(const BinWs& b, uint32_t L, int32_t T, hipStream_t s, bool debug);
+int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s);
+int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug);
 int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
                            hipStream_t s);
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
@@ -106,8 +106,9 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);
-// 32-bit keys; vals_in may be nullptr (values = input positions)
+// 32-bit keys; vals_in may be nullptr (values = input positions); n_dev (optional) = actual count on the
+// device, n then being a capacity
 int sort_pairs32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                 void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);
+                 void* tmp, uint32_t n, const uint32_t* n_dev, int end_bit, hipStream_t s, bool debug);
 
 }  // namespace hgs

@@ -31,11 +31,20 @@ __device__ __forceinline__ uint32_t digit_of(K k, int shift, uint32_t mask) {
   return (uint32_t)(k >> shift) & mask;
 }
 
+// n_dev (optional): actual element count in device memory, clamped to the launch-time capacity n.  Lets a
+// caller that only knows an upper bound enqueue the sort without a host round trip; workgroups beyond the
+// actual count contribute empty histograms.
+__device__ __forceinline__ uint32_t actual_n(uint32_t n_cap, const uint32_t* __restrict__ n_dev) {
+  return n_dev ? min(*n_dev, n_cap) : n_cap;
+}
+
 template <typename K, int ITEMS>
-__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const K* __restrict__ keys, uint32_t n,
+__global__ __launch_bounds__(kRsThreads) void rs_histogram_kernel(const K* __restrict__ keys, uint32_t n_cap,
+                                                                  const uint32_t* __restrict__ n_dev,
                                                                   int shift, uint32_t mask, uint32_t nblk,
                                                                   uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[kRadix];
+  const uint32_t n = actual_n(n_cap, n_dev);
   hist[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = blockIdx.x * (uint32_t)(kRsThreads * ITEMS);
@@ -84,10 +93,12 @@ template <typename K, int ITEMS>
 __global__ __launch_bounds__(kRsThreads) void rs_scatter_kernel(const K* __restrict__ keys_in,
                                                                 const uint32_t* __restrict__ vals_in,
                                                                 K* __restrict__ keys_out,
-                                                                uint32_t* __restrict__ vals_out, uint32_t n,
+                                                                uint32_t* __restrict__ vals_out, uint32_t n_cap,
+                                                                const uint32_t* __restrict__ n_dev,
                                                                 int shift, uint32_t mask, uint32_t nblk,
                                                                 const uint32_t* __restrict__ counts,
                                                                 const uint32_t* __restrict__ totals) {
+  const uint32_t n = actual_n(n_cap, n_dev);
   __shared__ uint32_t wave_hist[kRsWaves][kRadix];   // running per-wave digit counts, then offsets
   __shared__ uint32_t digit_base[kRadix];
   __shared__ uint32_t scan_tmp[4];
@@ -186,7 +197,7 @@ inline SortTmp<K> carve_sort_tmp(void* tmp, uint32_t n) {
 
 template <typename K, int ITEMS>
 int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_t* vals_out, void* tmp, uint32_t n,
-                 int end_bit, hipStream_t s, bool debug) {
+                 const uint32_t* n_dev, int end_bit, hipStream_t s, bool debug) {
   if (n == 0) return HGS_OK;
   const int maxbit = (int)sizeof(K) * 8;
   if (end_bit < 1) end_bit = 1;
@@ -204,13 +215,13 @@ int sort_pairs_t(const K* keys_in, const uint32_t* vals_in, K* keys_out, uint32_
     const int shift = p * 8;
     const int bits = (end_bit - shift) < 8 ? (end_bit - shift) : 8;
     const uint32_t mask = (1u << bits) - 1u;
-    hipLaunchKernelGGL((rs_histogram_kernel<K, ITEMS>), dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, shift, mask, nblk,
+    hipLaunchKernelGGL((rs_histogram_kernel<K, ITEMS>), dim3(nblk), dim3(kRsThreads), 0, s, src_k, n, n_dev, shift, mask, nblk,
                        t.counts);
     HGS_LAUNCH_CHECK("rs_histogram", s, debug);
     hipLaunchKernelGGL(rs_scan_kernel, dim3(kRadix), dim3(256), 0, s, t.counts, nblk, t.totals);
     HGS_LAUNCH_CHECK("rs_scan", s, debug);
     hipLaunchKernelGGL((rs_scatter_kernel<K, ITEMS>), dim3(nblk), dim3(kRsThreads), 0, s, src_k, src_v, dst_k, dst_v, n,
-                       shift, mask, nblk, t.counts, t.totals);
+                       n_dev, shift, mask, nblk, t.counts, t.totals);
     HGS_LAUNCH_CHECK("rs_scatter", s, debug);
     src_k = dst_k;
     src_v = dst_v;
@@ -228,15 +239,15 @@ size_t sort_tmp_bytes(uint32_t n) {   // sized for 64-bit keys (covers the 32-bi
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
   return rs_items(n) == kRsItemsLarge
-             ? sort_pairs_t<uint64_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug)
-             : sort_pairs_t<uint64_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
+             ? sort_pairs_t<uint64_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, nullptr, end_bit, s, debug)
+             : sort_pairs_t<uint64_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, nullptr, end_bit, s, debug);
 }
 
 int sort_pairs32(const uint32_t* keys_in, const uint32_t* vals_in, uint32_t* keys_out, uint32_t* vals_out,
-                 void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug) {
+                 void* tmp, uint32_t n, const uint32_t* n_dev, int end_bit, hipStream_t s, bool debug) {
   return rs_items(n) == kRsItemsLarge
-             ? sort_pairs_t<uint32_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug)
-             : sort_pairs_t<uint32_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, end_bit, s, debug);
+             ? sort_pairs_t<uint32_t, kRsItemsLarge>(keys_in, vals_in, keys_out, vals_out, tmp, n, n_dev, end_bit, s, debug)
+             : sort_pairs_t<uint32_t, kRsItemsSmall>(keys_in, vals_in, keys_out, vals_out, tmp, n, n_dev, end_bit, s, debug);
 }
 
 }  // namespace hgs

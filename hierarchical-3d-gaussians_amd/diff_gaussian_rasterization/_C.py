@@ -56,8 +56,15 @@ def _lod(weights, kids, P):
 
 
 class _Call:
-    """Everything one forward needs to hand back to the backward."""
-    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "P", "W", "H", "device")
+    """Everything one forward needs to hand back to the backward.  ``L`` = instances rendered; ``L_ws`` = the
+    instance capacity the binning workspace was carved with (== L on the two-stage path)."""
+    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device")
+
+
+# Instance count of the previous forward per device: lets the next forward size its binning workspace
+# speculatively (1.25 x) and enqueue the whole pipeline without waiting for the host (hgs_raster_fwd).
+_last_L = {}
+SPECULATIVE = True
 
 
 def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -139,16 +146,36 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     invdepth = torch.empty(1, H, W, dtype=torch.float32, device=dev) if do_depth else \
         torch.zeros(1, H, W, dtype=torch.float32, device=dev)
     L = C.c_uint32(0)
-    _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), _lib.ptr(geom), _lib.ptr(radii), C.byref(L),
-                                         _stream(dev), dev.index or 0), "hgs_raster_fwd_stage1")
-    _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L.value, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
-    binb = torch.empty(sz[1].value, **u8)
-    _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L.value,
-                                         _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
-                                         _stream(dev), dev.index or 0), "hgs_raster_fwd_stage2")
+    devi = dev.index or 0
+    binb = None
+    L_ws = 0
+    prev = _last_L.get(devi) if SPECULATIVE else None
+    if prev is not None and P > 0:
+        # no-bubble path: everything is enqueued before the host learns L
+        L_ws = int(prev * 1.25) + 65536
+        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
+        binb = torch.empty(sz[1].value, **u8)
+        rc = lib.hgs_raster_fwd(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws, _lib.ptr(radii),
+                                _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None, C.byref(L),
+                                _stream(dev), devi)
+        if rc == _lib.ERR_CAPACITY:
+            binb = None             # the scene grew by more than 25 %: finish on the exact two-stage path
+        else:
+            _lib.check(rc, "hgs_raster_fwd")
+    else:
+        _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), _lib.ptr(geom), _lib.ptr(radii), C.byref(L),
+                                             _stream(dev), devi), "hgs_raster_fwd_stage1")
+    if binb is None:
+        L_ws = L.value
+        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
+        binb = torch.empty(sz[1].value, **u8)
+        _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
+                                             _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
+                                             _stream(dev), devi), "hgs_raster_fwd_stage2")
+    _last_L[devi] = L.value
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
-    call.L, call.P, call.W, call.H, call.device = L.value, P, W, H, dev
+    call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
@@ -187,10 +214,10 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
     bwd_bytes = C.c_size_t()
-    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L, None, None, None, C.byref(bwd_bytes)),
+    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
                "hgs_raster_ws_sizes")
     scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
-    _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L,
+    _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L_ws,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),
                                   dev.index or 0), "hgs_raster_bwd")
@@ -201,7 +228,7 @@ def raster_views(call):
     """Test/introspection helper: typed torch views of the sorted keys, point list, tile ranges, ..."""
     lib = _lib.lib()
     v = _lib.RasterViews()
-    _lib.check(lib.hgs_raster_views_get(call.P, call.W, call.H, call.L, _lib.ptr(call.geom), _lib.ptr(call.binb),
+    _lib.check(lib.hgs_raster_views_get(call.P, call.W, call.H, call.L_ws, _lib.ptr(call.geom), _lib.ptr(call.binb),
                                         _lib.ptr(call.img), C.byref(v)), "hgs_raster_views_get")
 
     def view(buf, addr, dtype, count):

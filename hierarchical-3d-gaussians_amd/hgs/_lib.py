@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
 ABI_VERSION = 1
 INST_GRAD_STRIDE = 12
+ERR_CAPACITY = 5
 
 
 class RasterArgs(C.Structure):
@@ -59,6 +60,8 @@ SIGNATURES = {
                                       C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hgs_raster_fwd_stage1": (C.c_int, [C.POINTER(RasterArgs), _P, _P, C.POINTER(C.c_uint32), _P, C.c_int]),
     "hgs_raster_fwd_stage2": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, C.c_uint32, _P, _P, _P, C.c_int]),
+    "hgs_raster_fwd": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32), _P,
+                                 C.c_int]),
     "hgs_raster_bwd": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P,
                                  C.POINTER(RasterGrads), _P, C.c_int]),
     "hgs_raster_views_get": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, _P,

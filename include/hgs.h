@@ -45,7 +45,8 @@ enum {
   HGS_ERR_INVALID = 1, /* bad argument */
   HGS_ERR_HIP = 2,     /* a HIP runtime call or kernel failed */
   HGS_ERR_IO = 3,      /* file I/O */
-  HGS_ERR_NOMEM = 4
+  HGS_ERR_NOMEM = 4,
+  HGS_ERR_CAPACITY = 5 /* hgs_raster_fwd: L exceeded the caller's capacity; redo with stage1/stage2 */
 };
 
 typedef void* hgs_stream_t; /* hipStream_t */
@@ -105,6 +106,16 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws,
                           uint32_t L, float* out_color, float* out_invdepth,
                           hgs_stream_t stream, int device);
+
+/* Single-call forward for callers that can bound L in advance (the Python host uses 1.25 x the previous
+ * frame's count): bin_ws / bwd scratch are sized with L_cap, every kernel is enqueued before the host reads
+ * L, so the GPU never idles between the stages (the two-stage path leaves a ~50 us bubble).  The call still
+ * returns the exact L (it waits only for the early 4-byte copy).  If L > L_cap it returns HGS_ERR_CAPACITY,
+ * the outputs are invalid and the caller continues with hgs_raster_fwd_stage2 on an exactly sized bin_ws
+ * (geom_ws / radii from this call stay valid).  Later calls (backward, views) must pass the same L_cap as L. */
+int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L_cap,
+                   int32_t* radii, float* out_color, float* out_invdepth, uint32_t* L_out_host,
+                   hgs_stream_t stream, int device);
 
 typedef struct hgs_raster_grads {
   float* dL_dmeans3D;   /* [P,3] */
