@@ -45,6 +45,15 @@ struct StageTimer {
 
 static thread_local char g_err[512] = "";
 
+// 4 bytes of pinned host memory per calling thread: a D2H copy into pageable memory blocks the host until
+// the copy has run, which would defeat enqueue-ahead in hgs_raster_fwd.
+static thread_local uint32_t* g_pinned_L = nullptr;
+static uint32_t* pinned_L() {
+  if (!g_pinned_L && hipHostMalloc(reinterpret_cast<void**>(&g_pinned_L), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess)
+    g_pinned_L = nullptr;
+  return g_pinned_L;
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -214,7 +223,9 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   const uint32_t* L_dev = g.block_sums + nblk;
-  HGS_HIP(hipMemcpyAsync(L_out_host, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  uint32_t* stage = pinned_L();
+  if (!stage) { set_error("cannot allocate pinned host memory"); return HGS_ERR_NOMEM; }
+  HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   hipEvent_t ev;
   HGS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, s);
@@ -223,6 +234,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   if (e == hipSuccess) e = hipEventSynchronize(ev);
   (void)hipEventDestroy(ev);
   if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
+  *L_out_host = *stage;
   if (rc) return rc;
   if (*L_out_host > L_cap) {
     set_error("instance count %u exceeds the capacity %u given to hgs_raster_fwd", *L_out_host, L_cap);
