@@ -6,11 +6,14 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one view: GaussianRasterizer forward + backward through the C ABI (preprocess, key
-generation, radix sort, tile ranges, compositing, compositing backward, preprocess backward),
-inputs resident in HBM.  With N > 1 every rank renders a different view of the same replicated
-Gaussians and the step ends with one RCCL all-reduce of the flat 59*P-float gradient bucket
-(per-view data parallelism); value = N views / max-over-ranks step time.
+A step = one optimizer step's worth of rasterizer work on every rank: `--views-per-step` (default 4)
+views, each a full GaussianRasterizer forward + backward through the C ABI (preprocess, binning, sorts,
+compositing, compositing backward, preprocess backward) with inputs resident in HBM, their gradients
+accumulated in place into one flat 59*P-float bucket; with N > 1 every rank renders different views of
+the same replicated Gaussians and the step ends with ONE RCCL all-reduce of that bucket (per-view data
+parallelism with gradient accumulation).  The per-rank work is the same for every N
+(weak scaling); value = N * views_per_step * steps / max-over-ranks time.  The 236 MB all-reduce costs
+about as much as one view's compute on xGMI, hence the accumulation window (k = 1 is available).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -103,6 +106,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
+    ap.add_argument("--views-per-step", type=int, default=4,
+                    help="views rendered (fwd+bwd) per rank between two gradient all-reduces")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="L",
@@ -131,40 +136,49 @@ def main():
 
     base_cam = synth.make_camera(W, H)
     scene_cpu = synth.make_scene(P, base_cam, seed=0)            # same Gaussians on every rank
-    cam_cpu = base_cam if world == 1 else synth.orbit_camera(W, H, rank, world)
+    k = max(1, args.views_per_step)
+    # every (rank, slot) gets its own camera: the canonical pose perturbed by a few centimetres / milliradians,
+    # so each view still sees (almost) all of the 1 M Gaussians -- the BASELINE workload -- but no two views agree
+    n_views = world * k
+    cams_cpu = [base_cam if n_views == 1 else synth.orbit_camera(W, H, rank * k + j, n_views, radius=0.05, tilt=0.004)
+                for j in range(k)]
     gc_cpu, gd_cpu = synth.upstream_grads(H, W, seed=1)
     bg_cpu = torch.zeros(3)
-    scene, cam = scene_cpu.to(dev), cam_cpu.to(dev)
+    scene = scene_cpu.to(dev)
     gc, gd, bg = gc_cpu.to(dev), gd_cpu.to(dev), bg_cpu.to(dev)
     e_i = torch.empty(0, dtype=torch.int32, device=dev)
     e_f = torch.empty(0, dtype=torch.float32, device=dev)
-    rs = dgr.GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
-        viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree,
-        campos=cam.camera_center, prefiltered=False, debug=False, do_depth=True, render_indices=e_i,
-        parent_indices=e_i, interpolation_weights=e_f, num_node_kids=e_i)
-    rast = dgr.GaussianRasterizer(rs)
+    rasts = []
+    for cam_c in cams_cpu:
+        cam = cam_c.to(dev)
+        rs = dgr.GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+            viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree,
+            campos=cam.camera_center, prefiltered=False, debug=False, do_depth=True, render_indices=e_i,
+            parent_indices=e_i, interpolation_weights=e_f, num_node_kids=e_i)
+        rasts.append(dgr.GaussianRasterizer(rs))
     dgr._RasterizeGaussians.variant = args.variant
     params = dict(means3D=scene.means3D, shs=scene.shs, opacities=scene.opacities, scales=scene.scales,
                   rotations=scene.rotations)
     for t in params.values():
         t.requires_grad_(True)
     means2D = torch.zeros(P, 3, device=dev, requires_grad=True)
-    bucket = dp.GradBucket({k: tuple(v.shape) for k, v in params.items()}, dev) if world > 1 else None
-    if bucket is not None:
-        dgr._RasterizeGaussians.grad_buffers = bucket.views     # the backward writes straight into the bucket
-    info = {}
+    # the backward writes (first view) / accumulates (later views) straight into the flat bucket
+    bucket = dp.GradBucket({kk: tuple(v.shape) for kk, v in params.items()}, dev)
+    dgr._RasterizeGaussians.grad_buffers = bucket.views
+    info = {"L": 0, "V": 0}
 
     def step():
-        color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
-                                  opacities=params["opacities"], scales=params["scales"],
-                                  rotations=params["rotations"])
-        info["L"] = color.grad_fn.num_rendered
-        info["radii"] = radii
-        grads = torch.autograd.grad([color, invd], [params[k] for k in params] + [means2D], [gc, gd])
-        if bucket is not None:
+        for j, rast in enumerate(rasts):
+            dgr._RasterizeGaussians.grad_accumulate = j > 0
+            color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
+                                      opacities=params["opacities"], scales=params["scales"],
+                                      rotations=params["rotations"])
+            info["L"] = color.grad_fn.num_rendered
+            info["radii"] = radii
+            torch.autograd.grad([color, invd], [params[kk] for kk in params] + [means2D], [gc, gd])
+        if world > 1:
             bucket.all_reduce()
-        return grads
 
     def barrier():
         if world > 1:
@@ -195,7 +209,7 @@ def main():
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * args.steps / elapsed
+        value = world * k * args.steps / elapsed
         L = int(info["L"])
         V = int((info["radii"] > 0).sum().item())
         N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), scene.shs.shape[1]
@@ -209,10 +223,13 @@ def main():
             "config": {"workload": f"{P} frustum-filling synthetic Gaussians (SURVEY §8(d) spec, seed 0), "
                                    f"{W}x{H}, SH degree 3, depth channel on, fwd+bwd through GaussianRasterizer",
                        "gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H,
-                       "parallelism": f"per-view dp{world}" + (" + RCCL all-reduce of the 59P-float grad bucket" if world > 1 else ""),
+                       "views_per_step_per_gpu": k,
+                       "parallelism": f"per-view dp{world}, {k} views per rank per step accumulated in place" +
+                                      (", one RCCL all-reduce of the 59P-float grad bucket per step" if world > 1 else ""),
                        "render_variant": args.variant},
             "algorithmic_bytes_per_frame": total_bytes,
-            "frame_hbm_frac": total_bytes * (args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
+            "ms_per_frame_per_gpu": ms_per_step / k,
+            "frame_hbm_frac": total_bytes * (k * args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
         }
         if stages:
             dom = max(stages, key=stages.get)
@@ -239,6 +256,7 @@ def main():
                                      "--gaussians", str(P), "--width", str(W), "--height", str(H)],
                                     capture_output=True, text=True, timeout=420)
                 result["cpu_baseline"] = json.loads(cp.stdout.strip().splitlines()[-1])
+                result["cpu_baseline"]["sample"] += " (canonical camera)"
             except Exception as e:
                 result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": os.cpu_count() or 1,
                                           "kind": "port", "sample": f"not measured: {e!r}"}

@@ -93,7 +93,7 @@ __device__ __forceinline__ void coop_load_sh(const float* __restrict__ shs, int 
 }
 
 __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int block_first, int P, int n,
-                                              const float* lds) {
+                                              const float* lds, bool accumulate) {
   const int count = min(kPreBlock, P - block_first);
   const int vecs = count * n / 4;
   float4* dst = reinterpret_cast<float4*>(dst_all + (size_t)block_first * n);
@@ -101,7 +101,12 @@ __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int b
   for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
     const int e = v * 4;
     const int gsn = e / n, off = e - gsn * n;
-    dst[v] = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+    float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+    if (accumulate) {
+      const float4 old = dst[v];
+      val.x += old.x; val.y += old.y; val.z += old.z; val.w += old.w;
+    }
+    dst[v] = val;
   }
 }
 
@@ -466,25 +471,32 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     }
   }
 
+  // accumulate_grads: add to what the buffers hold (gradient accumulation over several views of one optimizer
+  // step); dL/dmeans2D is a per-view statistic and is always overwritten
+  const bool acc = a.accumulate_grads != 0;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    out.dL_dmeans3D[idx * 3 + j] = d_mean[j];
+    out.dL_dmeans3D[idx * 3 + j] = d_mean[j] + (acc ? out.dL_dmeans3D[idx * 3 + j] : 0.f);
     out.dL_dmeans2D[idx * 3 + j] = d_m2[j];
   }
-  out.dL_dopacity[idx] = d_op;
+  out.dL_dopacity[idx] = d_op + (acc ? out.dL_dopacity[idx] : 0.f);
   if (out.dL_dcolors) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out.dL_dcolors[idx * 3 + j] = d_col[j];
+    for (int j = 0; j < 3; ++j) out.dL_dcolors[idx * 3 + j] = d_col[j] + (acc ? out.dL_dcolors[idx * 3 + j] : 0.f);
   }
   if (out.dL_dscales) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out.dL_dscales[idx * 3 + j] = d_scale[j];
+    for (int j = 0; j < 3; ++j) out.dL_dscales[idx * 3 + j] = d_scale[j] + (acc ? out.dL_dscales[idx * 3 + j] : 0.f);
   }
-  if (out.dL_drotations)
-    reinterpret_cast<float4*>(out.dL_drotations)[idx] = make_float4(d_rot[0], d_rot[1], d_rot[2], d_rot[3]);
+  if (out.dL_drotations) {
+    float4* dst = reinterpret_cast<float4*>(out.dL_drotations) + idx;
+    float4 v = make_float4(d_rot[0], d_rot[1], d_rot[2], d_rot[3]);
+    if (acc) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    *dst = v;
+  }
   if (out.dL_dcov3D) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) out.dL_dcov3D[(size_t)idx * 6 + j] = d_c3[j];
+    for (int j = 0; j < 6; ++j) out.dL_dcov3D[(size_t)idx * 6 + j] = d_c3[j] + (acc ? out.dL_dcov3D[(size_t)idx * 6 + j] : 0.f);
   }
 }
 
@@ -542,8 +554,12 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (coop) {
     if (valid) lds_row_write(lds, n, dsh);
     __syncthreads();
-    coop_store_sh(out.dL_dshs, block_first, a.P, n, lds);
+    coop_store_sh(out.dL_dshs, block_first, a.P, n, lds, a.accumulate_grads != 0);
   } else if (valid) {
+    if (a.accumulate_grads) {
+      const float* old = out.dL_dshs + (size_t)idx * n;
+      for (int i = 0; i < n; ++i) dsh[i] += old[i];
+    }
     store_sh(out.dL_dshs, idx, a.M, dsh);
   }
 }

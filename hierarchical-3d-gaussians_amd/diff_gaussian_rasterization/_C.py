@@ -103,7 +103,7 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     a.P, a.M, a.sh_degree = P, M, int(degree)
     a.width, a.height = int(image_width), int(image_height)
     a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
-    a.do_depth, a.debug, a.variant, a.reserved = int(bool(do_depth)), int(bool(debug)), int(variant), 0
+    a.do_depth, a.debug, a.variant, a.accumulate_grads = int(bool(do_depth)), int(bool(debug)), int(variant), 0
     p = _lib.ptr
     a.bg, a.viewmatrix, a.projmatrix, a.campos = p(bg), p(vm), p(pm), p(cp)
     a.means3D, a.shs, a.colors_precomp, a.opacities = p(means3D), p(sh), p(colors), p(opacity)
@@ -179,11 +179,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
-def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None):
+def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False):
     """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
     dL_dscales, dL_drotations); entries for absent inputs are None.  ``out``: optional dict of
     preallocated float32 GPU tensors (keys means3D, shs, colors_precomp, opacities, scales, rotations,
-    cov3D_precomp) the gradients are written into -- e.g. the views of a data-parallel flat bucket."""
+    cov3D_precomp) the gradients are written into -- e.g. the views of a data-parallel flat bucket;
+    ``accumulate``: add to their contents (gradient accumulation over the views of one optimizer step)."""
     lib = _lib.lib()
     a, P, dev = call.args, call.P, call.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -213,6 +214,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     p = _lib.ptr
     g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
+    a.accumulate_grads = int(bool(accumulate and out is not None))
     bwd_bytes = C.c_size_t()
     _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
                "hgs_raster_ws_sizes")

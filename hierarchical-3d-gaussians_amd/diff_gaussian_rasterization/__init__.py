@@ -50,6 +50,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     # Optional {input name: preallocated float32 GPU tensor}: when set, the backward writes the gradients of
     # the Gaussian parameters straight into these buffers (hgs.dp.GradBucket views) instead of fresh tensors.
     grad_buffers = None
+    grad_accumulate = False   # with grad_buffers: add to the buffers (accumulation over several views)
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -73,7 +74,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         if grad_color is None:
             grad_color = torch.zeros_like(color)
         d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(
-            call, color, invdepth, grad_color, grad_invdepth, out=_RasterizeGaussians.grad_buffers)
+            call, color, invdepth, grad_color, grad_invdepth, out=_RasterizeGaussians.grad_buffers,
+            accumulate=_RasterizeGaussians.grad_accumulate)
         ctx.call = None
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, None

@@ -78,13 +78,13 @@ def make_camera(width, height, fovy_deg=60.0, R=None, T=None, znear=0.01, zfar=1
     return Camera(width, height, fovx, fovy, wv, full, center, znear, zfar)
 
 
-def orbit_camera(width, height, k, n, radius=0.6, fovy_deg=60.0) -> Camera:
+def orbit_camera(width, height, k, n, radius=0.6, fovy_deg=60.0, tilt=0.05) -> Camera:
     """k-th of n cameras on a small circle around the origin, all looking roughly down +z
     (per-view data-parallel workloads)."""
     ang = 2 * math.pi * k / max(n, 1)
     c = np.array([radius * math.cos(ang), radius * math.sin(ang), 0.0])
-    yaw = 0.05 * math.cos(ang)
-    pitch = 0.05 * math.sin(ang)
+    yaw = tilt * math.cos(ang)
+    pitch = tilt * math.sin(ang)
     Ry = np.array([[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]])
     Rx = np.array([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]])
     Rc2w = Ry @ Rx

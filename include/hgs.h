@@ -72,7 +72,7 @@ typedef struct hgs_raster_args {
   int32_t do_depth;   /* write the inverse-depth channel */
   int32_t debug;      /* synchronise + check after every launch */
   int32_t variant;    /* 0 = library default; >0 selects a render-kernel variant (bench/tuning only) */
-  int32_t reserved;
+  int32_t accumulate_grads; /* backward: add into the gradient buffers instead of overwriting them */
   const float* bg;          /* device [3] */
   const float* viewmatrix;  /* device [16] */
   const float* projmatrix;  /* device [16] */

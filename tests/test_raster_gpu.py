@@ -331,3 +331,40 @@ def test_crowded_tiles_sort_paths(gpu, P, W, H):
     assert np.array_equal(v["ranges"].cpu().numpy(), binning.ranges)
     assert np.array_equal(v["point_list"].cpu().numpy(), binning.point_list)
     assert torch.equal(color, color2)
+
+
+def test_gradient_accumulation_into_caller_buffers(gpu):
+    """Data-parallel host path: the backward writes straight into a flat bucket and ACCUMULATES the second
+    view's gradients in place; the result must equal the sum of the two views' separately computed gradients."""
+    import diff_gaussian_rasterization as dgr
+    from hgs import dp
+    W, H, P = 160, 96, 1200
+    base = synth.make_camera(W, H)
+    scene = synth.make_scene(P, base, seed=3)
+    cams = [synth.orbit_camera(W, H, j, 2, radius=0.3) for j in range(2)]
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.zeros(3)
+    sep = [pa.run_hip(scene, c, bg, gc, gd, gpu)["grads"] for c in cams]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    sc = scene.to(gpu)
+    params = {n: getattr(sc, n).clone().requires_grad_(True) for n in names}
+    bucket = dp.GradBucket({n: tuple(v.shape) for n, v in params.items()}, gpu)
+    bucket.flat.fill_(123.0)                      # stale contents must be overwritten by the first view
+    dgr._RasterizeGaussians.grad_buffers = bucket.views
+    try:
+        for j, c in enumerate(cams):
+            dgr._RasterizeGaussians.grad_accumulate = j > 0
+            rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(c, bg, 3, device=gpu))
+            m2 = torch.zeros(P, 3, device=gpu, requires_grad=True)
+            color, radii, invd = dgr.GaussianRasterizer(rs)(
+                means3D=params["means3D"], means2D=m2, shs=params["shs"], opacities=params["opacities"],
+                scales=params["scales"], rotations=params["rotations"])
+            got = torch.autograd.grad([color, invd], [params[n] for n in names] + [m2], [gc.to(gpu), gd.to(gpu)])
+            assert got[0].data_ptr() == bucket.views["means3D"].data_ptr(), "gradients must alias the bucket"
+            assert torch.allclose(got[-1].cpu(), sep[j]["means2D"], rtol=1e-6, atol=1e-6)   # per-view, never accumulated
+    finally:
+        dgr._RasterizeGaussians.grad_buffers = None
+        dgr._RasterizeGaussians.grad_accumulate = False
+    for n in names:
+        want = sep[0][n] + sep[1][n]
+        assert torch.allclose(bucket.views[n].cpu(), want, rtol=1e-5, atol=1e-6 * float(want.abs().max())), n
