@@ -22,3 +22,5 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -d $GRAFT_REPO_ROOT/gpurun_out/pmc_$c -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timing > $GRAFT_REPO_ROOT/gpurun_out/pmc_$c.log 2>&1; echo "pmc $c exit $?"
 done
 cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof gpurun_out/pmc_* | head -30; nproc; free -g | head -2
+echo "== bench k=1"
+timeout 300 python bench.py --steps 30 --warmup 5 --views-per-step 1 --no-cpu-baseline > gpurun_out/bench_k1.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_k1.json | head -c 400; echo
