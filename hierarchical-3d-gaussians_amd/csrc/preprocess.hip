@@ -92,8 +92,9 @@ __device__ __forceinline__ void coop_load_sh(const float* __restrict__ shs, int 
   }
 }
 
+template <bool ACC>
 __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int block_first, int P, int n,
-                                              const float* lds, bool accumulate) {
+                                              const float* lds) {
   const int count = min(kPreBlock, P - block_first);
   const int vecs = count * n / 4;
   float4* dst = reinterpret_cast<float4*>(dst_all + (size_t)block_first * n);
@@ -102,7 +103,7 @@ __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int b
     const int e = v * 4;
     const int gsn = e / n, off = e - gsn * n;
     float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
-    if (accumulate) {
+    if (ACC) {
       const float4 old = dst[v];
       val.x += old.x; val.y += old.y; val.z += old.z; val.w += old.w;
     }
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 //   5: sum G*dL/dalpha          6..8: sum w*dL/dC_k              9: sum w*dL/dD
 // with X = dL/dpower, w = alpha*T.
 // ---------------------------------------------------------------------------
+template <bool ACC>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
 __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
                                                                    float* __restrict__ drgb,
@@ -473,7 +475,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 
   // accumulate_grads: add to what the buffers hold (gradient accumulation over several views of one optimizer
   // step); dL/dmeans2D is a per-view statistic and is always overwritten
-  const bool acc = a.accumulate_grads != 0;
+  constexpr bool acc = ACC;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     out.dL_dmeans3D[idx * 3 + j] = d_mean[j] + (acc ? out.dL_dmeans3D[idx * 3 + j] : 0.f);
@@ -504,6 +506,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 // K8b: SH part of the backward.  Pure streaming kernel (192 B of coefficients in, 192 B of gradients out
 // per Gaussian at M = 16), split from the double-precision geometry chain of K8a so that it runs at high
 // occupancy.  Adds the view-direction term to dL/dmeans3D written by K8a.
+template <bool ACC>
 __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                            const float* __restrict__ drgb, hgs_raster_grads out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -554,9 +557,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (coop) {
     if (valid) lds_row_write(lds, n, dsh);
     __syncthreads();
-    coop_store_sh(out.dL_dshs, block_first, a.P, n, lds, a.accumulate_grads != 0);
+    coop_store_sh<ACC>(out.dL_dshs, block_first, a.P, n, lds);
   } else if (valid) {
-    if (a.accumulate_grads) {
+    if (ACC) {
       const float* old = out.dL_dshs + (size_t)idx * n;
       for (int i = 0; i < n; ++i) dsh[i] += old[i];
     }
@@ -587,11 +590,13 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
                           const hgs_raster_grads& out, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
+    auto k8a = a.accumulate_grads ? preprocess_bwd_kernel<true> : preprocess_bwd_kernel<false>;
+    hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-      hipLaunchKernelGGL(sh_bwd_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
+      auto k8b = a.accumulate_grads ? sh_bwd_kernel<true> : sh_bwd_kernel<false>;
+      hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
       HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);
     }
   }
