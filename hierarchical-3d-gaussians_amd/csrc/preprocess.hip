@@ -99,15 +99,39 @@ __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int b
   const int vecs = count * n / 4;
   float4* dst = reinterpret_cast<float4*>(dst_all + (size_t)block_first * n);
   const int stride = sh_row_stride(n);
-  for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
-    const int e = v * 4;
-    const int gsn = e / n, off = e - gsn * n;
-    float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
-    if (ACC) {
-      const float4 old = dst[v];
-      val.x += old.x; val.y += old.y; val.z += old.z; val.w += old.w;
+  if (ACC) {
+    // accumulate: issue all the reads of the old gradients first (12 independent loads per lane at M = 16),
+    // then add and store -- a load/add/store chain per 16 bytes would serialise on memory latency
+    constexpr int kMaxIter = 12;
+    float4 old[kMaxIter];
+#pragma unroll
+    for (int it = 0; it < kMaxIter; ++it) {
+      const int v = it * kPreBlock + (int)threadIdx.x;
+      old[it] = v < vecs ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    dst[v] = val;
+#pragma unroll
+    for (int it = 0; it < kMaxIter; ++it) {
+      const int v = it * kPreBlock + (int)threadIdx.x;
+      if (v < vecs) {
+        const int e = v * 4;
+        const int gsn = e / n, off = e - gsn * n;
+        const float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+        dst[v] = make_float4(val.x + old[it].x, val.y + old[it].y, val.z + old[it].z, val.w + old[it].w);
+      }
+    }
+    for (int v = kMaxIter * kPreBlock + threadIdx.x; v < vecs; v += kPreBlock) {   // n > 48 floats: not reached (M <= 16)
+      const int e = v * 4;
+      const int gsn = e / n, off = e - gsn * n;
+      const float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+      const float4 o = dst[v];
+      dst[v] = make_float4(val.x + o.x, val.y + o.y, val.z + o.z, val.w + o.w);
+    }
+  } else {
+    for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
+      const int e = v * 4;
+      const int gsn = e / n, off = e - gsn * n;
+      dst[v] = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+    }
   }
 }
 
