@@ -100,31 +100,26 @@ __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int b
   float4* dst = reinterpret_cast<float4*>(dst_all + (size_t)block_first * n);
   const int stride = sh_row_stride(n);
   if (ACC) {
-    // accumulate: issue all the reads of the old gradients first (12 independent loads per lane at M = 16),
-    // then add and store -- a load/add/store chain per 16 bytes would serialise on memory latency
-    constexpr int kMaxIter = 12;
-    float4 old[kMaxIter];
+    // accumulate: reads of the old gradients are issued four at a time ahead of the adds and stores -- a
+    // load/add/store chain per 16 bytes would serialise on memory latency, twelve in flight spill registers
+    constexpr int kGroup = 4;
+    for (int base = 0; base < vecs; base += kGroup * kPreBlock) {
+      float4 old[kGroup];
 #pragma unroll
-    for (int it = 0; it < kMaxIter; ++it) {
-      const int v = it * kPreBlock + (int)threadIdx.x;
-      old[it] = v < vecs ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int it = 0; it < kMaxIter; ++it) {
-      const int v = it * kPreBlock + (int)threadIdx.x;
-      if (v < vecs) {
-        const int e = v * 4;
-        const int gsn = e / n, off = e - gsn * n;
-        const float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
-        dst[v] = make_float4(val.x + old[it].x, val.y + old[it].y, val.z + old[it].z, val.w + old[it].w);
+      for (int it = 0; it < kGroup; ++it) {
+        const int v = base + it * kPreBlock + (int)threadIdx.x;
+        old[it] = v < vecs ? dst[v] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-    }
-    for (int v = kMaxIter * kPreBlock + threadIdx.x; v < vecs; v += kPreBlock) {   // n > 48 floats: not reached (M <= 16)
-      const int e = v * 4;
-      const int gsn = e / n, off = e - gsn * n;
-      const float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
-      const float4 o = dst[v];
-      dst[v] = make_float4(val.x + o.x, val.y + o.y, val.z + o.z, val.w + o.w);
+#pragma unroll
+      for (int it = 0; it < kGroup; ++it) {
+        const int v = base + it * kPreBlock + (int)threadIdx.x;
+        if (v < vecs) {
+          const int e = v * 4;
+          const int gsn = e / n, off = e - gsn * n;
+          const float4 val = *reinterpret_cast<const float4*>(lds + gsn * stride + off);
+          dst[v] = make_float4(val.x + old[it].x, val.y + old[it].y, val.z + old[it].z, val.w + old[it].w);
+        }
+      }
     }
   } else {
     for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
@@ -585,7 +580,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   } else if (valid) {
     if (ACC) {
       const float* old = out.dL_dshs + (size_t)idx * n;
-      for (int i = 0; i < n; ++i) dsh[i] += old[i];
+#pragma unroll
+      for (int i = 0; i < 48; ++i)       // static indices keep dsh[] in registers
+        if (i < n) dsh[i] += old[i];
     }
     store_sh(out.dL_dshs, idx, a.M, dsh);
   }
