@@ -246,6 +246,22 @@ def main():
                                   "avg_ms": stages[dom], "algorithmic_bytes": ab[dom],
                                   "note": "compositing kernels are VALU/LDS-bound (gather/blend, no MFMA); "
                                           "the HBM fraction is reported because the metric mandates it"}
+            # The compositing kernels are VALU-issue-bound: add the vector-ALU view next to the mandated HBM one.
+            # Peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD at 2.4 GHz (packed
+            # v_pk_*_f32 instructions count once and do two flops-lanes of work).
+            valu_path = os.path.join(ROOT, "profiles", "pmc_valu.json")
+            if os.path.exists(valu_path):
+                try:
+                    pv = json.load(open(valu_path)).get(dom)
+                    if pv:
+                        peak = 256 * 4 * 2.4e9 / 4
+                        rate = pv["valu_insts_per_launch"] / (stages[dom] * 1e-3)
+                        result["roofline"]["valu"] = {
+                            "insts_per_launch": pv["valu_insts_per_launch"], "achieved_ginst_s": rate / 1e9,
+                            "peak_ginst_s": peak / 1e9, "frac": rate / peak,
+                            "source": "SQ_INSTS_VALU from rocprofv3 --pmc (profiles/pmc_valu.json), time from this run"}
+                except Exception:
+                    pass
             result["stages_ms"] = stages
             result["stages_gbs"] = {k: ab[k] / (v * 1e-3) / 1e9 for k, v in stages.items() if k in ab}
         if world == 1 and not args.no_cpu_baseline:

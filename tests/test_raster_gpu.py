@@ -368,3 +368,32 @@ def test_gradient_accumulation_into_caller_buffers(gpu):
     for n in names:
         want = sep[0][n] + sep[1][n]
         assert torch.allclose(bucket.views[n].cpu(), want, rtol=1e-5, atol=1e-6 * float(want.abs().max())), n
+
+
+def test_awkward_inputs(gpu):
+    """Screen-filling Gaussians (rectangle = whole tile grid), zero / tiny opacities, needle-like anisotropy,
+    Gaussians straddling the near plane and the frustum border, off-centre principal point."""
+    import math
+    W, H = 208, 144
+    fovy = math.radians(50.0)
+    fy = H / (2 * math.tan(fovy / 2))
+    fovx = 2 * math.atan(W / (2 * fy))
+    wv = torch.eye(4)
+    proj = synth.projection_matrix(0.01, 100.0, fovx, fovy, primx=0.42, primy=0.58).transpose(0, 1)
+    cam = synth.Camera(W, H, fovx, fovy, wv, (wv @ proj).contiguous(), torch.zeros(3))
+    g = torch.Generator().manual_seed(77)
+    scene = synth.make_scene(400, cam, seed=5, s_px=(0.5, 6.0))
+    P = scene.P
+    scene.scales[:6] = torch.tensor([3.0, 2.0, 2.5])               # fill the whole screen
+    scene.opacities[6:12] = 0.0                                    # never visible in the blend
+    scene.opacities[12:18] = 1.0 / 300.0                           # below 1/255 everywhere
+    scene.scales[18:40] = torch.tensor([0.4, 0.002, 0.002])        # needles
+    scene.means3D[40:50, 2] = torch.linspace(0.15, 0.25, 10)       # around the 0.2 near plane
+    scene.means3D[50:70, 0] = scene.means3D[50:70, 2] * cam.tanfovx * 1.4   # outside the frustum, EWA clamp region
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.tensor([0.3, 0.2, 0.1])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    assert oo.geom.tiles_touched.max() == ((W + 15) // 16) * ((H + 15) // 16)
+    _assert_case("awkward", hip, oo, og)
+    assert float(hip["grads"]["opacities"][12:18].abs().max()) == 0.0
