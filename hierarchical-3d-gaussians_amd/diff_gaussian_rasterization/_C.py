@@ -125,9 +125,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward."""
     if (render_indices is not None and render_indices.numel() > 0) or \
             (parent_indices is not None and parent_indices.numel() > 0):
-        raise NotImplementedError(
-            "in-op LOD gather (non-empty render_indices/parent_indices) is not available; the reference's "
-            "render_post always passes them empty (gaussian_renderer/__init__.py:244-245)")
+        raise RuntimeError("rasterize_gaussians expects already gathered rows; non-empty render_indices / "
+                           "parent_indices are resolved by GaussianRasterizer.forward (lod_gather) before this call")
     lib = _lib.lib()
     a, keep, P, M = _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
@@ -260,3 +259,49 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     vm = viewmatrix.to(torch.float32)
     z = means3D @ vm[:3, 2] + vm[3, 2]
     return z > 0.2
+
+
+def lod_gather(render_indices, parent_indices, weights, means3D, scales, rotations, shs, opacities):
+    """out_i = w_i * attr[render_indices[i]] + (1 - w_i) * attr[parent_indices[i]] for every given attribute
+    (None entries stay None); rotations with the hemisphere flip of gaussian_renderer/__init__.py:212-216."""
+    lib = _lib.lib()
+    n = int(render_indices.numel())
+    dev = render_indices.device
+    if not render_indices.is_cuda or render_indices.dtype != torch.int32 or not parent_indices.is_cuda or \
+            parent_indices.dtype != torch.int32 or parent_indices.numel() < n:
+        raise RuntimeError("render_indices / parent_indices must be int32 GPU tensors (parent_indices at least as long)")
+    if not weights.is_cuda or weights.dtype != torch.float32 or weights.numel() < n:
+        raise RuntimeError("interpolation_weights must be a float32 GPU tensor with one entry per render index")
+    ri, pi, w = render_indices.contiguous(), parent_indices.contiguous(), weights.contiguous()
+    outs, ins = [], []
+    for t, name in ((means3D, "means3D"), (scales, "scales"), (rotations, "rotations"), (shs, "shs"),
+                    (opacities, "opacities")):
+        if t is None:
+            ins.append(None); outs.append(None)
+            continue
+        _require_gpu(t, name)
+        ins.append(t)
+        outs.append(torch.empty((n,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev))
+    M = shs.shape[1] if shs is not None else 0
+    p = _lib.ptr
+    _lib.check(lib.hgs_lod_gather(p(ri), p(pi), p(w), n, M, *[p(t) for t in ins], *[p(t) for t in outs],
+                                  _stream(dev), dev.index or 0), "hgs_lod_gather")
+    return tuple(outs)
+
+
+def lod_gather_backward(render_indices, parent_indices, weights, rotations, grads, shapes):
+    """grads: 5-tuple of gradients of lod_gather's outputs (None allowed); shapes: shapes of the full inputs.
+    Returns the 5 full-size gradients (zeros where nothing was rendered)."""
+    lib = _lib.lib()
+    n = int(render_indices.numel())
+    dev = render_indices.device
+    ri, pi, w = render_indices.contiguous(), parent_indices.contiguous(), weights.contiguous()
+    gs = [None if g is None else g.to(torch.float32).contiguous() for g in grads]
+    ds = [None if (g is None or s is None) else torch.zeros(*s, dtype=torch.float32, device=dev)
+          for g, s in zip(gs, shapes)]
+    M = shapes[3][1] if shapes[3] is not None else 0
+    flag = torch.empty(1, dtype=torch.int32, device=dev)
+    p = _lib.ptr
+    _lib.check(lib.hgs_lod_gather_bwd(p(ri), p(pi), p(w), n, M, p(rotations), *[p(g) for g in gs], *[p(d) for d in ds],
+                                      p(flag), _stream(dev), dev.index or 0), "hgs_lod_gather_bwd")
+    return tuple(ds)

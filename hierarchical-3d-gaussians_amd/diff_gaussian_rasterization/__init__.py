@@ -81,8 +81,38 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, None
 
 
+class _LodGather(torch.autograd.Function):
+    """In-op LOD interpolation: gather + lerp of node and parent attributes, and the matching
+    scatter in the backward -- what gaussian_renderer/__init__.py:199-218 does with ~25 torch kernels."""
+
+    @staticmethod
+    def forward(ctx, render_indices, parent_indices, weights, means3D, scales, rotations, shs, opacities):
+        n = render_indices.numel()
+        ctx.save_for_backward(render_indices, parent_indices[:n], weights[:n], rotations)
+        ctx.shapes = tuple(None if t is None else tuple(t.shape) for t in (means3D, scales, rotations, shs, opacities))
+        return _C.lod_gather(render_indices, parent_indices[:n], weights[:n], means3D, scales, rotations, shs, opacities)
+
+    @staticmethod
+    def backward(ctx, g_means, g_scales, g_rot, g_shs, g_op):
+        ri, pi, w, rotations = ctx.saved_tensors
+        ds = _C.lod_gather_backward(ri, pi, w, rotations, (g_means, g_scales, g_rot, g_shs, g_op), ctx.shapes)
+        return (None, None, None) + ds
+
+
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
                         raster_settings):
+    rs = raster_settings
+    if rs.render_indices is not None and rs.render_indices.numel() > 0:
+        # hierarchy mode with the interpolation done in-op: the attribute tensors hold ALL hierarchy Gaussians,
+        # render_indices / parent_indices / interpolation_weights select and blend the rows to draw
+        if colors_precomp is not None or cov3Ds_precomp is not None:
+            raise RuntimeError("in-op LOD interpolation needs shs and scales/rotations (no precomputed colours/covariances)")
+        n = rs.render_indices.numel()
+        means3D, scales, rotations, sh, opacities = _LodGather.apply(
+            rs.render_indices, rs.parent_indices, rs.interpolation_weights, means3D, scales, rotations, sh, opacities)
+        means2D = means2D[:n]
+        empty = rs.render_indices.new_empty(0)
+        raster_settings = rs._replace(render_indices=empty, parent_indices=empty)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings)
 

@@ -77,6 +77,9 @@ SIGNATURES = {
                                      _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int32), _P, C.c_int]),
     "hgs_interp_weights": (C.c_int, [_P, C.c_int32, C.c_float, _P, _P, C.c_int32, C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), _P, _P, _P, C.c_int]),
+    "hgs_lod_gather": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
+    "hgs_lod_gather_bwd": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
+                                     _P, _P, C.c_int]),
     "hgs_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "hgs_dist2_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int]),
     "hgs_hier_load": (C.c_int, [C.c_char_p, C.POINTER(HierHost)]),

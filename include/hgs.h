@@ -191,6 +191,24 @@ int hgs_interp_weights(const int32_t* node_indices, int32_t n, float size, const
                        float* interpolation_weights, int32_t* num_siblings,
                        hgs_stream_t stream, int device);
 
+/* In-op LOD attribute interpolation: the gather + lerp that render_post does in Python
+ * (gaussian_renderer/__init__.py:199-218), for callers that pass GaussianRasterizationSettings.render_indices /
+ * parent_indices non-empty.  out_i = w_i * attr[render_indices[i]] + (1 - w_i) * attr[parent_indices[i]]; rotations
+ * with the parent quaternion flipped into the node's hemisphere.  Any attribute pointer may be NULL (skipped). */
+int hgs_lod_gather(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n,
+                   int32_t M, const float* means3D, const float* scales, const float* rotations, const float* shs,
+                   const float* opacities, float* o_means3D, float* o_scales, float* o_rotations, float* o_shs,
+                   float* o_opacities, hgs_stream_t stream, int device);
+/* Backward: g_* = gradients of the n interpolated rows; d_* = gradients of the full arrays, ZERO-INITIALISED by
+ * the caller; rotations = the full forward input (sign of the hemisphere flip); flag_tmp = 4 bytes of device
+ * scratch.  Precondition: render_indices are unique and no rendered row is another entry's parent row (true for
+ * any LOD cut). */
+int hgs_lod_gather_bwd(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n,
+                       int32_t M, const float* rotations, const float* g_means3D, const float* g_scales,
+                       const float* g_rotations, const float* g_shs, const float* g_opacities, float* d_means3D,
+                       float* d_scales, float* d_rotations, float* d_shs, float* d_opacities, uint32_t* flag_tmp,
+                       hgs_stream_t stream, int device);
+
 /* ---------------------------------------------------------------------------
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:190): mean squared distance
  * to the 3 nearest neighbours.  tmp_bytes from hgs_knn_tmp_bytes.

@@ -135,3 +135,62 @@ def test_million_leaf_hierarchy_cut_and_render(gpu):
         assert torch.isfinite(color).all() and float(color.max()) > 0.05
         assert int((radii > 0).sum()) > 0.5 * n
         print(f"tau={tau_px}px: cut {n} of {G} nodes, mean colour {float(color.mean()):.4f}")
+
+
+def test_in_op_lod_interpolation_matches_python_glue(gpu):
+    """render_indices / parent_indices passed NON-empty to the op must reproduce exactly what
+    render_post's Python block (gaussian_renderer/__init__.py:199-218, restated here in torch) feeds it,
+    forward and backward (gradients land on node AND parent rows)."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    h, cam, nodes, boxes = _setup(4000, gpu, seed=9)
+    G = h.xyz.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=gpu); ns = torch.zeros(G, dtype=torch.int32, device=gpu)
+    tau = (2 * (4 + 0.5)) * cam.tanfovx / (0.5 * cam.image_width)
+    n = expand_to_size(nodes, boxes, tau, cam.camera_center.to(gpu), torch.zeros(3), ri, pi, ni)
+    assert 0 < n < G
+    get_interpolation_weights(ni[:n], tau, nodes, boxes, cam.camera_center.cpu(), torch.zeros(3), w, ns)
+    gc, gd = synth.upstream_grads(cam.image_height, cam.image_width)
+    gc = gc.to(gpu)
+
+    def leaves():
+        mk = lambda t: t.to(gpu).clone().requires_grad_(True)
+        return dict(xyz=mk(h.xyz), sc=mk(torch.exp(h.log_scales)), rot=mk(torch.nn.functional.normalize(h.rots)),
+                    shs=mk(h.shs), op=mk(h.alpha.abs()))
+
+    def settings(render_indices, parent_indices):
+        kw = pa.settings_kwargs(cam, torch.zeros(3), 3, do_depth=False, device=gpu, interpolation_weights=w, num_node_kids=ns)
+        kw["render_indices"], kw["parent_indices"] = render_indices, parent_indices
+        return dgr.GaussianRasterizationSettings(**kw)
+
+    # (a) python-side lerp exactly as the reference glue, rows handed to the op
+    A = leaves()
+    r, p = ri[:n].long(), pi[:n].long()
+    t = w[:n].unsqueeze(1); ti = 1 - t
+    parents, rots = A["rot"][p], A["rot"][r]
+    dots = torch.bmm(rots.unsqueeze(1), parents.unsqueeze(2)).flatten()
+    parents = torch.where((dots < 0)[:, None], -parents, parents)
+    m2a = torch.zeros(n, 3, device=gpu, requires_grad=True)
+    e = torch.empty(0, dtype=torch.int32, device=gpu)
+    ca, ra, _ = dgr.GaussianRasterizer(settings(e, e))(
+        means3D=(t * A["xyz"][r] + ti * A["xyz"][p]).contiguous(), means2D=m2a,
+        shs=(t.unsqueeze(2) * A["shs"][r] + ti.unsqueeze(2) * A["shs"][p]).contiguous(),
+        opacities=(t * A["op"][r] + ti * A["op"][p]).contiguous(),
+        scales=(t * A["sc"][r] + ti * A["sc"][p]).contiguous(), rotations=(t * rots + ti * parents).contiguous())
+    (ca * gc).sum().backward()
+    # (b) in-op: full arrays + index tensors
+    B = leaves()
+    m2b = torch.zeros(G, 3, device=gpu, requires_grad=True)
+    cb, rb, _ = dgr.GaussianRasterizer(settings(ri[:n].contiguous(), pi))(
+        means3D=B["xyz"], means2D=m2b, shs=B["shs"], opacities=B["op"], scales=B["sc"], rotations=B["rot"])
+    (cb * gc).sum().backward()
+    assert torch.equal(ra, rb)
+    assert float((ca - cb).abs().max()) <= 2e-6
+    for k in A:
+        ga, gb = A[k].grad, B[k].grad
+        scale = float(ga.abs().max())
+        assert float((ga - gb).abs().max()) <= 2e-5 * scale, (k, float((ga - gb).abs().max()), scale)
+        touched = torch.zeros(G, dtype=torch.bool, device=gpu); touched[r] = True; touched[p] = True
+        assert float(gb[~touched].abs().sum()) == 0.0
