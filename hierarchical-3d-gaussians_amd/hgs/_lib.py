@@ -49,6 +49,15 @@ class HierHost(C.Structure):
                 ("boxes", C.c_void_p)]
 
 
+class AdamTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("row_len", C.c_int32), ("step_size", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_correction2_sqrt", C.c_float),
+                ("reserved", C.c_int32)]
+
+
+ADAM_MAX_TENSORS = 8
+
 # symbol -> (restype, argtypes); also the list the export test checks against include/hgs.h
 _P = C.c_void_p
 SIGNATURES = {
@@ -80,6 +89,7 @@ SIGNATURES = {
     "hgs_lod_gather": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "hgs_lod_gather_bwd": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, C.c_int]),
+    "hgs_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_int64, _P, C.c_int64, _P, _P, C.c_int]),
     "hgs_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "hgs_dist2_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int]),
     "hgs_hier_load": (C.c_int, [C.c_char_p, C.POINTER(HierHost)]),

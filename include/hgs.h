@@ -210,6 +210,30 @@ int hgs_lod_gather_bwd(const int32_t* render_indices, const int32_t* parent_indi
                        hgs_stream_t stream, int device);
 
 /* ---------------------------------------------------------------------------
+ * Fused row-sparse Adam.  Replaces the gather / update / scatter chain of
+ * scene/OurAdam.py:249-337 (_single_tensor_adam; dense variant :339-420) for ALL parameter tensors of the model in
+ * one launch.  Every tensor is [P, row_len] contiguous f32; bias corrections and step size are computed by the caller
+ * (step_size = lr / (1 - beta1^t), bias_correction2_sqrt = sqrt(1 - beta2^t), as the Python code does in double).
+ * rows != NULL: update the n_rows listed rows (int64, as `relevant` in train_single.py:171-174);
+ * row_mask_grad != NULL: update row r iff row_mask_grad[r] != 0 (the same selection, evaluated in-kernel);
+ * both NULL: dense update of all P rows.
+ * ------------------------------------------------------------------------- */
+#define HGS_ADAM_MAX_TENSORS 8
+typedef struct hgs_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int32_t row_len;
+  float step_size;
+  float beta1, beta2, eps, weight_decay;
+  float bias_correction2_sqrt;
+  int32_t reserved;
+} hgs_adam_tensor;
+int hgs_adam_step(const hgs_adam_tensor* tensors, int32_t n_tensors, int64_t P, const int64_t* rows, int64_t n_rows,
+                  const float* row_mask_grad, hgs_stream_t stream, int device);
+
+/* ---------------------------------------------------------------------------
  * simple_knn._C.distCUDA2 (scene/gaussian_model.py:190): mean squared distance
  * to the 3 nearest neighbours.  tmp_bytes from hgs_knn_tmp_bytes.
  * ------------------------------------------------------------------------- */
