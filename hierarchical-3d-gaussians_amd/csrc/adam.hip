@@ -43,8 +43,8 @@ __global__ __launch_bounds__(256) void adam_kernel(AdamLaunch L, int n_tensors, 
   float g = T.grad[idx];
   const float p = T.param[idx];
   if (T.weight_decay != 0.0f) g = fmaf(T.weight_decay, p, g);
-  const float m = fmaf(1.0f - T.beta1, g, T.exp_avg[idx] * T.beta1);
-  const float v = fmaf((1.0f - T.beta2) * g, g, T.exp_avg_sq[idx] * T.beta2);
+  const float m = fmaf(T.one_minus_beta1, g, T.exp_avg[idx] * T.beta1);
+  const float v = fmaf(T.one_minus_beta2 * g, g, T.exp_avg_sq[idx] * T.beta2);
   const float denom = sqrtf(v) / T.bias_correction2_sqrt + T.eps;
   T.exp_avg[idx] = m;
   T.exp_avg_sq[idx] = v;

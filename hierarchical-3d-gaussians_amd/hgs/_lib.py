@@ -51,9 +51,9 @@ class HierHost(C.Structure):
 
 class AdamTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
-                ("row_len", C.c_int32), ("step_size", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("weight_decay", C.c_float), ("bias_correction2_sqrt", C.c_float),
-                ("reserved", C.c_int32)]
+                ("row_len", C.c_int32), ("step_size", C.c_float), ("beta1", C.c_float), ("one_minus_beta1", C.c_float),
+                ("beta2", C.c_float), ("one_minus_beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("bias_correction2_sqrt", C.c_float), ("reserved", C.c_int32)]
 
 
 ADAM_MAX_TENSORS = 8

@@ -69,7 +69,8 @@ class Adam(Optimizer):
                 row_len = p.numel() // max(rows, 1)
                 t = _lib.AdamTensor(param=p.data_ptr(), grad=grad.data_ptr(), exp_avg=state["exp_avg"].data_ptr(),
                                     exp_avg_sq=state["exp_avg_sq"].data_ptr(), row_len=row_len,
-                                    step_size=group["lr"] / bc1, beta1=beta1, beta2=beta2, eps=group["eps"],
+                                    step_size=group["lr"] / bc1, beta1=beta1, one_minus_beta1=1 - beta1, beta2=beta2,
+                                    one_minus_beta2=1 - beta2, eps=group["eps"],
                                     weight_decay=group["weight_decay"], bias_correction2_sqrt=math.sqrt(bc2))
                 todo.append((rows, p.device, t, grad))
         return todo

@@ -226,7 +226,9 @@ typedef struct hgs_adam_tensor {
   float* exp_avg_sq;
   int32_t row_len;
   float step_size;
-  float beta1, beta2, eps, weight_decay;
+  float beta1, one_minus_beta1; /* both rounded from double by the caller, as torch does with its scalar arguments */
+  float beta2, one_minus_beta2;
+  float eps, weight_decay;
   float bias_correction2_sqrt;
   int32_t reserved;
 } hgs_adam_tensor;
