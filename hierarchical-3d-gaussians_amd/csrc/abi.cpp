@@ -126,6 +126,9 @@ static int validate(const hgs_raster_args* a) {
       if (a->sh_degree < 0 || a->sh_degree > 3) { set_error("sh_degree %d not in 0..3", a->sh_degree); return HGS_ERR_INVALID; }
       if (a->M < (a->sh_degree + 1) * (a->sh_degree + 1) || a->M > 16) { set_error("M=%d incompatible with sh_degree=%d (max 16 coefficients)", a->M, a->sh_degree); return HGS_ERR_INVALID; }
     }
+    if (a->shs_rest && (!a->shs || a->M < 2)) { set_error("shs_rest needs shs (features_dc) and M >= 2"); return HGS_ERR_INVALID; }
+    if ((a->activations & HGS_ACT_OPACITY_SIGMOID) && (a->activations & HGS_ACT_OPACITY_ABS)) { set_error("choose one opacity activation"); return HGS_ERR_INVALID; }
+    if ((a->activations & (HGS_ACT_SCALE_EXP | HGS_ACT_ROT_NORMALIZE)) && a->cov3D_precomp) { set_error("scale / rotation activations need scales and rotations"); return HGS_ERR_INVALID; }
     if ((a->interpolation_weights != nullptr) != (a->num_node_kids != nullptr)) { set_error("interpolation_weights and num_node_kids must be given together"); return HGS_ERR_INVALID; }
   }
   return HGS_OK;
@@ -252,7 +255,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   if (!geom_ws || !bin_ws || !img_ws || !bwd_ws || !out_color || !dL_dcolor || !grads) { set_error("null workspace/input"); return HGS_ERR_INVALID; }
   if (a->P > 0) {
     if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity) { set_error("missing gradient outputs"); return HGS_ERR_INVALID; }
-    if ((a->shs && !grads->dL_dshs) || (a->colors_precomp && !grads->dL_dcolors) ||
+    if ((a->shs && !grads->dL_dshs) || (a->shs_rest && !grads->dL_dshs_rest) || (a->colors_precomp && !grads->dL_dcolors) ||
         (a->scales && (!grads->dL_dscales || !grads->dL_drotations)) || (a->cov3D_precomp && !grads->dL_dcov3D)) {
       set_error("gradient outputs do not match the inputs that were provided");
       return HGS_ERR_INVALID;
@@ -276,6 +279,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   }
   hgs_raster_grads gr = *grads;
   if (!a->shs) gr.dL_dshs = nullptr;
+  if (!a->shs_rest) gr.dL_dshs_rest = nullptr;
   if (!a->colors_precomp) gr.dL_dcolors = nullptr;
   if (!a->scales) { gr.dL_dscales = nullptr; gr.dL_drotations = nullptr; }
   if (!a->cov3D_precomp) gr.dL_dcov3D = nullptr;

@@ -232,6 +232,46 @@ __device__ __forceinline__ void project_gaussian_d(const float p[3], const float
   o.conC = o.a * di;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Raw-parameter path (hgs_raster_args.activations): the activations of
+// scene/gaussian_model.py:108-128 evaluated in double and rounded ONCE to float32 -- that float32
+// value is what every later stage (discrete float32 chain and continuous double chain) sees, exactly
+// as if the caller had passed it.  nrm receives max(|q_raw|, 1e-12) (1 without normalisation).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx, float sc[3], float q[4],
+                                               double* nrm) {
+  sc[0] = a.scales[idx * 3 + 0]; sc[1] = a.scales[idx * 3 + 1]; sc[2] = a.scales[idx * 3 + 2];
+  if (a.activations & HGS_ACT_SCALE_EXP) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) sc[i] = (float)exp((double)sc[i]);
+  }
+  const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
+  q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+  double n = 1.0;
+  if (a.activations & HGS_ACT_ROT_NORMALIZE) {
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    n = fmax(sqrt(((w * w + x * x) + y * y) + z * z), 1e-12);
+    q[0] = (float)(w / n); q[1] = (float)(x / n); q[2] = (float)(y / n); q[3] = (float)(z / n);
+  }
+  if (nrm) *nrm = n;
+}
+
+// activated opacity; dact (optional) = d(activated)/d(raw)
+__device__ __forceinline__ float load_opacity(const hgs_raster_args& a, int idx, double* dact) {
+  const float raw = a.opacities[idx];
+  if (a.activations & HGS_ACT_OPACITY_SIGMOID) {
+    const double o = 1.0 / (1.0 + exp(-(double)raw));
+    if (dact) *dact = o * (1.0 - o);
+    return (float)o;
+  }
+  if (a.activations & HGS_ACT_OPACITY_ABS) {
+    if (dact) *dact = raw > 0.f ? 1.0 : (raw < 0.f ? -1.0 : 0.0);
+    return fabsf(raw);
+  }
+  if (dact) *dact = 1.0;
+  return raw;
+}
+
 // Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity'; oracle: raster_oracle.lod_opacity).
 __device__ __forceinline__ float lod_opacity(float o, float w, int kids, float* dout_do) {
   if (kids < 2) {

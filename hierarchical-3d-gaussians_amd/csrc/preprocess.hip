@@ -147,6 +147,69 @@ __device__ __forceinline__ void lds_row_write(float* lds, int n, const float v[4
     if (i * 4 < n) *reinterpret_cast<float4*>(row + i * 4) = make_float4(v[i * 4 + 0], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3]);
 }
 
+// ---- split SH storage (hgs_raster_args.shs_rest): features_dc [P,1,3] and features_rest [P,M-1,3] ----------
+// Same LDS row layout as above ([dc | rest], stride 3M + 4), filled from / drained to two contiguous global
+// blocks.  3 and 45 floats per Gaussian are not multiples of 4, so the 16-byte global accesses straddle rows and
+// the LDS side is done per float; a workgroup's block starts 16-byte aligned (256 Gaussians x 12 / 180 bytes).
+__device__ __forceinline__ void coop_load_seg(const float* __restrict__ src_all, int block_first, int P, int nseg,
+                                              int col0, int stride, float* lds) {
+  const int count = min(kPreBlock, P - block_first);
+  const int total = count * nseg;
+  const float* src = src_all + (size_t)block_first * nseg;
+  const int vecs = total >> 2;
+  for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
+    const float4 t = reinterpret_cast<const float4*>(src)[v];
+    const float tv[4] = {t.x, t.y, t.z, t.w};
+    int gsn = (v * 4) / nseg, off = v * 4 - gsn * nseg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      lds[gsn * stride + col0 + off] = tv[c];
+      if (++off == nseg) { off = 0; ++gsn; }
+    }
+  }
+  for (int e = vecs * 4 + threadIdx.x; e < total; e += kPreBlock) {
+    const int gsn = e / nseg, off = e - gsn * nseg;
+    lds[gsn * stride + col0 + off] = src[e];
+  }
+}
+
+template <bool ACC>
+__device__ __forceinline__ void coop_store_seg(float* __restrict__ dst_all, int block_first, int P, int nseg,
+                                               int col0, int stride, const float* lds) {
+  const int count = min(kPreBlock, P - block_first);
+  const int total = count * nseg;
+  float* dst = dst_all + (size_t)block_first * nseg;
+  const int vecs = total >> 2;
+  for (int v = threadIdx.x; v < vecs; v += kPreBlock) {
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACC) o = reinterpret_cast<const float4*>(dst)[v];
+    float tv[4];
+    int gsn = (v * 4) / nseg, off = v * 4 - gsn * nseg;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      tv[c] = lds[gsn * stride + col0 + off];
+      if (++off == nseg) { off = 0; ++gsn; }
+    }
+    reinterpret_cast<float4*>(dst)[v] = make_float4(tv[0] + o.x, tv[1] + o.y, tv[2] + o.z, tv[3] + o.w);
+  }
+  for (int e = vecs * 4 + threadIdx.x; e < total; e += kPreBlock) {
+    const int gsn = e / nseg, off = e - gsn * nseg;
+    const float v = lds[gsn * stride + col0 + off];
+    dst[e] = ACC ? dst[e] + v : v;
+  }
+}
+
+// per-lane access to the split layout (mostly-culled workgroups of K1)
+__device__ __forceinline__ void load_sh_split(const float* __restrict__ dc, const float* __restrict__ rest, int idx,
+                                              int M, float sh[48]) {
+  sh[0] = dc[(size_t)idx * 3 + 0]; sh[1] = dc[(size_t)idx * 3 + 1]; sh[2] = dc[(size_t)idx * 3 + 2];
+  const int nr = (M - 1) * 3;
+  const float* src = rest + (size_t)idx * nr;
+#pragma unroll
+  for (int i = 0; i < 45; ++i)
+    if (i < nr) sh[3 + i] = src[i];
+}
+
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -162,17 +225,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   Proj pr;
   pr.visible = false;
   float p[3] = {0.f, 0.f, 0.f};
+  float sc_act[3] = {0.f, 0.f, 0.f}, q_act[4] = {1.f, 0.f, 0.f, 0.f};   // activated scale / rotation
   if (idx < a.P) {
     p[0] = a.means3D[idx * 3 + 0]; p[1] = a.means3D[idx * 3 + 1]; p[2] = a.means3D[idx * 3 + 2];
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
     } else {
-      const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
-      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
-      const float q[4] = {qv.x, qv.y, qv.z, qv.w};
+      load_scale_rot(a, idx, sc_act, q_act, nullptr);
       float R[9], s[3];
-      cov3d_from_scale_rot(sc, a.scale_modifier, q, pr.c3, R, s);
+      cov3d_from_scale_rot(sc_act, a.scale_modifier, q_act, pr.c3, R, s);
     }
     project_gaussian(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, gx, gy, pr);
   }
@@ -183,7 +245,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   if (a.shs && (shn & 3) == 0) {
     coop = __syncthreads_count(pr.visible) * 2 >= kPreBlock;
     if (coop) {
-      coop_load_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
+      if (a.shs_rest) {
+        coop_load_seg(a.shs, blockIdx.x * kPreBlock, a.P, 3, 0, sh_row_stride(shn), lds_sh);
+        coop_load_seg(a.shs_rest, blockIdx.x * kPreBlock, a.P, shn - 3, 3, sh_row_stride(shn), lds_sh);
+      } else {
+        coop_load_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
+      }
       __syncthreads();
     }
   }
@@ -201,7 +268,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
         rgb[2] = a.colors_precomp[idx * 3 + 2];
       } else {
         float sh[48];
-        if (coop) lds_row_read(lds_sh, shn, sh); else load_sh(a.shs, idx, a.M, sh);
+        if (coop) lds_row_read(lds_sh, shn, sh);
+        else if (a.shs_rest) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
+        else load_sh(a.shs, idx, a.M, sh);
         float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
         const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
         dx *= inv; dy *= inv; dz *= inv;
@@ -225,7 +294,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       }
       if (pr.clampx) flags |= 8u;
       if (pr.clampy) flags |= 16u;
-      float opac = a.opacities[idx];
+      float opac = load_opacity(a, idx, nullptr);
       if (a.interpolation_weights && a.num_node_kids)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
       // continuous quantities from the double-precision chain (see gaussian_math.h)
@@ -234,10 +303,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
 #pragma unroll
         for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
       } else {
-        const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
-        const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
-        const float q[4] = {qv.x, qv.y, qv.z, qv.w};
-        cov3d_from_scale_rot_d(sc, a.scale_modifier, q, pd);
+        cov3d_from_scale_rot_d(sc_act, a.scale_modifier, q_act, pd);
       }
       project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
       // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
@@ -356,14 +422,14 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     const uint32_t flags = g.flags[idx];
     const float p[3] = {a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]};
     float q[4] = {1.f, 0.f, 0.f, 0.f};
+    float sc[3] = {1.f, 1.f, 1.f};
+    double qnorm = 1.0;
     ProjD pd;
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) pd.c3[i] = (double)a.cov3D_precomp[(size_t)idx * 6 + i];
     } else {
-      const float sc[3] = {a.scales[idx * 3 + 0], a.scales[idx * 3 + 1], a.scales[idx * 3 + 2]};
-      const float4 qv = reinterpret_cast<const float4*>(a.rotations)[idx];
-      q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+      load_scale_rot(a, idx, sc, q, &qnorm);
       cov3d_from_scale_rot_d(sc, a.scale_modifier, q, pd);
     }
     project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, (flags & 8u) != 0,
@@ -458,24 +524,36 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
           acc += R[i * 3 + k] * dM[i][k];
           gR[i][k] = dM[i][k] * sv[k];
         }
-        d_scale[k] = (float)((double)a.scale_modifier * acc);
+        double dsk = (double)a.scale_modifier * acc;
+        if (a.activations & HGS_ACT_SCALE_EXP) dsk *= (double)sc[k];          // d exp(raw) / d raw = exp(raw)
+        d_scale[k] = (float)dsk;
       }
       const double r = q[0], x = q[1], y = q[2], z = q[3];
-      d_rot[0] = (float)(2.0 * (-z * gR[0][1] + y * gR[0][2] + z * gR[1][0] - x * gR[1][2] - y * gR[2][0] + x * gR[2][1]));
-      d_rot[1] = (float)(2.0 * (y * gR[0][1] + z * gR[0][2] + y * gR[1][0] - 2.0 * x * gR[1][1] - r * gR[1][2] +
-                                z * gR[2][0] + r * gR[2][1] - 2.0 * x * gR[2][2]));
-      d_rot[2] = (float)(2.0 * (-2.0 * y * gR[0][0] + x * gR[0][1] + r * gR[0][2] + x * gR[1][0] + z * gR[1][2] -
-                                r * gR[2][0] + z * gR[2][1] - 2.0 * y * gR[2][2]));
-      d_rot[3] = (float)(2.0 * (-2.0 * z * gR[0][0] - r * gR[0][1] + x * gR[0][2] + r * gR[1][0] - 2.0 * z * gR[1][1] +
-                                y * gR[1][2] + x * gR[2][0] + y * gR[2][1]));
+      double dq[4];
+      dq[0] = 2.0 * (-z * gR[0][1] + y * gR[0][2] + z * gR[1][0] - x * gR[1][2] - y * gR[2][0] + x * gR[2][1]);
+      dq[1] = 2.0 * (y * gR[0][1] + z * gR[0][2] + y * gR[1][0] - 2.0 * x * gR[1][1] - r * gR[1][2] +
+                     z * gR[2][0] + r * gR[2][1] - 2.0 * x * gR[2][2]);
+      dq[2] = 2.0 * (-2.0 * y * gR[0][0] + x * gR[0][1] + r * gR[0][2] + x * gR[1][0] + z * gR[1][2] -
+                     r * gR[2][0] + z * gR[2][1] - 2.0 * y * gR[2][2]);
+      dq[3] = 2.0 * (-2.0 * z * gR[0][0] - r * gR[0][1] + x * gR[0][2] + r * gR[1][0] - 2.0 * z * gR[1][1] +
+                     y * gR[1][2] + x * gR[2][0] + y * gR[2][1]);
+      if (a.activations & HGS_ACT_ROT_NORMALIZE) {     // through q = raw / |raw|: (I - q q^T) / |raw|
+        const double dot = r * dq[0] + x * dq[1] + y * dq[2] + z * dq[3];
+        const double inv = 1.0 / qnorm;
+        dq[0] = (dq[0] - r * dot) * inv; dq[1] = (dq[1] - x * dot) * inv;
+        dq[2] = (dq[2] - y * dot) * inv; dq[3] = (dq[3] - z * dot) * inv;
+      }
+      d_rot[0] = (float)dq[0]; d_rot[1] = (float)dq[1]; d_rot[2] = (float)dq[2]; d_rot[3] = (float)dq[3];
     }
 
     // opacity (through the LOD remap)
     {
       float dod = 1.0f;
+      double dact = 1.0;
+      const float o_act = load_opacity(a, idx, &dact);
       if (a.interpolation_weights && a.num_node_kids)
-        (void)lod_opacity(a.opacities[idx], a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
-      d_op = sums5 * dod;
+        (void)lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
+      d_op = a.activations ? (float)((double)sums5 * (double)dod * dact) : sums5 * dod;
     }
 
     // colour: precomputed colours get their gradient here; SH colours hand the clamp-masked dL/drgb to K8b
@@ -531,13 +609,19 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int n = a.M * 3;
+  const bool split = a.shs_rest != nullptr;       // features_dc / features_rest as two tensors
   const bool coop = (n & 3) == 0;                 // 16-byte granules (M = 16, 4, ...); else per-lane access
   const int block_first = blockIdx.x * kPreBlock;
   const int idx = block_first + threadIdx.x;
   const bool valid = idx < a.P;
   const bool active = valid && g.tiles_touched[idx] != 0;
   if (coop) {
-    coop_load_sh(a.shs, block_first, a.P, n, lds);
+    if (split) {
+      coop_load_seg(a.shs, block_first, a.P, 3, 0, sh_row_stride(n), lds);
+      coop_load_seg(a.shs_rest, block_first, a.P, n - 3, 3, sh_row_stride(n), lds);
+    } else {
+      coop_load_sh(a.shs, block_first, a.P, n, lds);
+    }
     __syncthreads();
   }
   float dsh[48];
@@ -545,7 +629,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
   float sh[48];
   if (active) {
-    if (coop) lds_row_read(lds, n, sh); else load_sh(a.shs, idx, a.M, sh);
+    if (coop) lds_row_read(lds, n, sh);
+    else if (split) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
+    else load_sh(a.shs, idx, a.M, sh);
   }
   if (coop) __syncthreads();                      // every row has been read: the buffer becomes the output stage
   if (active) {
@@ -576,7 +662,20 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (coop) {
     if (valid) lds_row_write(lds, n, dsh);
     __syncthreads();
-    coop_store_sh<ACC>(out.dL_dshs, block_first, a.P, n, lds);
+    if (split) {
+      coop_store_seg<ACC>(out.dL_dshs, block_first, a.P, 3, 0, sh_row_stride(n), lds);
+      coop_store_seg<ACC>(out.dL_dshs_rest, block_first, a.P, n - 3, 3, sh_row_stride(n), lds);
+    } else {
+      coop_store_sh<ACC>(out.dL_dshs, block_first, a.P, n, lds);
+    }
+  } else if (valid && split) {
+    float* d0 = out.dL_dshs + (size_t)idx * 3;
+    float* d1 = out.dL_dshs_rest + (size_t)idx * (n - 3);
+#pragma unroll
+    for (int i = 0; i < 48; ++i) {       // static indices keep dsh[] in registers
+      if (i < 3) d0[i] = dsh[i] + (ACC ? d0[i] : 0.f);
+      else if (i < n) d1[i - 3] = dsh[i] + (ACC ? d1[i - 3] : 0.f);
+    }
   } else if (valid) {
     if (ACC) {
       const float* old = out.dL_dshs + (size_t)idx * n;

@@ -69,7 +69,7 @@ SPECULATIVE = True
 
 def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                 viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
-                debug, interpolation_weights, num_node_kids, do_depth, variant=0):
+                debug, interpolation_weights, num_node_kids, do_depth, variant=0, sh_rest=None, activations=0):
     _require_gpu(means3D, "means3D")
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
@@ -94,6 +94,14 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
                 ((scales is not None or rotations is not None) and cov3D_precomp is not None):
             raise RuntimeError("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
     M = sh.shape[1] if sh is not None else 0
+    if sh_rest is not None and sh_rest.numel() == 0:
+        sh_rest = None
+    if sh_rest is not None:
+        # raw-parameter path: sh = features_dc [P,1,3], sh_rest = features_rest [P,M-1,3]
+        _require_gpu(sh_rest, "shs_rest")
+        if sh is None or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P or sh_rest.shape[2] != 3:
+            raise RuntimeError("split SH storage needs features_dc (num_points, 1, 3) and features_rest (num_points, M-1, 3)")
+        M = 1 + sh_rest.shape[1]
     bg = _small(background, "bg", 3)
     vm = _small(viewmatrix, "viewmatrix", 16)
     pm = _small(projmatrix, "projmatrix", 16)
@@ -109,7 +117,8 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     a.means3D, a.shs, a.colors_precomp, a.opacities = p(means3D), p(sh), p(colors), p(opacity)
     a.scales, a.rotations, a.cov3D_precomp = p(scales), p(rotations), p(cov3D_precomp)
     a.interpolation_weights, a.num_node_kids = p(w), p(k)
-    keep = (bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, w, k)
+    a.shs_rest, a.activations = p(sh_rest), int(activations)
+    keep = (bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, w, k, sh_rest)
     return a, keep, P, M
 
 
@@ -120,7 +129,7 @@ def _stream(device):
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                        num_node_kids, do_depth, variant=0):
+                        num_node_kids, do_depth, variant=0, sh_rest=None, activations=0):
     """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
     invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward."""
     if (render_indices is not None and render_indices.numel() > 0) or \
@@ -131,7 +140,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a, keep, P, M = _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
                                 image_width, sh, degree, campos, debug, interpolation_weights, num_node_kids,
-                                do_depth, variant)
+                                do_depth, variant, sh_rest, activations)
     dev = means3D.device
     H, W = int(image_height), int(image_width)
     u8 = dict(dtype=torch.uint8, device=dev)
@@ -180,14 +189,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
 
 def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False):
     """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
-    dL_dscales, dL_drotations); entries for absent inputs are None.  ``out``: optional dict of
+    dL_dscales, dL_drotations) -- plus dL_dsh_rest as a 9th entry for a forward with split SH storage; entries
+    for absent inputs are None.  ``out``: optional dict of
     preallocated float32 GPU tensors (keys means3D, shs, colors_precomp, opacities, scales, rotations,
     cov3D_precomp) the gradients are written into -- e.g. the views of a data-parallel flat bucket;
     ``accumulate``: add to their contents (gradient accumulation over the views of one optimizer step)."""
     lib = _lib.lib()
     a, P, dev = call.args, call.P, call.device
     f32 = dict(dtype=torch.float32, device=dev)
-    bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D, w, k = call.keep
+    bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D, w, k, sh_rest = call.keep
     dL_dcolor = dL_dcolor.to(torch.float32).contiguous()
     use_depth = bool(a.do_depth) and dL_dinvdepth is not None
     if use_depth:
@@ -206,6 +216,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     d_m2 = torch.empty(P, 3, **f32)
     d_op = buf("opacities", (P, 1))
     d_sh = buf("shs", tuple(sh.shape)) if sh is not None else None
+    d_shr = buf("shs_rest", tuple(sh_rest.shape)) if sh_rest is not None else None
     d_col = buf("colors_precomp", (P, 3)) if colors is not None else None
     d_sc = buf("scales", (P, 3)) if scales is not None else None
     d_rot = buf("rotations", (P, 4)) if rotations is not None else None
@@ -213,6 +224,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     p = _lib.ptr
     g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
+    g.dL_dshs_rest = p(d_shr)
     a.accumulate_grads = int(bool(accumulate and out is not None))
     bwd_bytes = C.c_size_t()
     _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
@@ -222,6 +234,8 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),
                                   dev.index or 0), "hgs_raster_bwd")
+    if sh_rest is not None:
+        return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot, d_shr
     return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot
 
 

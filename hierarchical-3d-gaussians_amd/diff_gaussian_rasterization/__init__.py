@@ -81,6 +81,57 @@ class _RasterizeGaussians(torch.autograd.Function):
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, None
 
 
+class _RasterizeGaussiansRaw(torch.autograd.Function):
+    """Raw-parameter fast path: takes the optimiser's tensors of scene/gaussian_model.py
+    (_xyz, _features_dc, _features_rest, _opacity, _scaling, _rotation) and applies the activations of
+    scene/gaussian_model.py:108-128 inside the HIP kernels; gradients come back w.r.t. the raw tensors."""
+
+    @staticmethod
+    def forward(ctx, xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                raster_settings, activations):
+        rs = raster_settings
+        num_rendered, color, radii, geom, binb, img, invdepth, call = _C.rasterize_gaussians(
+            rs.bg, xyz, None, opacity_raw, scaling_raw, rotation_raw, rs.scale_modifier, None,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, features_dc,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.render_indices, rs.parent_indices,
+            rs.interpolation_weights, rs.num_node_kids, rs.do_depth, 0, sh_rest=features_rest,
+            activations=activations)
+        ctx.call = call
+        ctx.split = features_rest is not None and features_rest.numel() > 0
+        ctx.save_for_backward(color, invdepth)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, invdepth
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_invdepth):
+        color, invdepth = ctx.saved_tensors
+        if grad_color is None:
+            grad_color = torch.zeros_like(color)
+        res = _C.rasterize_gaussians_backward(ctx.call, color, invdepth, grad_color, grad_invdepth,
+                                              out=_RasterizeGaussians.grad_buffers,
+                                              accumulate=_RasterizeGaussians.grad_accumulate)
+        ctx.call = None
+        d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = res[:8]
+        d_rest = res[8] if ctx.split else None
+        return d_m3, d_m2, d_sh, d_rest, d_op, d_sc, d_rot, None, None
+
+
+def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
+                            raster_settings, opacity_activation="sigmoid"):
+    """opacity_activation: 'sigmoid' (scene/gaussian_model.py:126-127), 'abs' (hierarchy mode, :393) or 'none'."""
+    from hgs import _lib
+    act = _lib.ACT_SCALE_EXP | _lib.ACT_ROT_NORMALIZE
+    try:
+        act |= {"sigmoid": _lib.ACT_OPACITY_SIGMOID, "abs": _lib.ACT_OPACITY_ABS, "none": 0}[opacity_activation]
+    except KeyError:
+        raise RuntimeError(f"unknown opacity_activation {opacity_activation!r}") from None
+    rs = raster_settings
+    if rs.render_indices is not None and rs.render_indices.numel() > 0:
+        raise RuntimeError("the raw-parameter path takes already selected rows (empty render_indices)")
+    return _RasterizeGaussiansRaw.apply(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw,
+                                        rotation_raw, raster_settings, act)
+
+
 class _LodGather(torch.autograd.Function):
     """In-op LOD interpolation: gather + lerp of node and parent attributes, and the matching
     scatter in the backward -- what gaussian_renderer/__init__.py:199-218 does with ~25 torch kernels."""
@@ -137,5 +188,12 @@ class GaussianRasterizer(nn.Module):
         return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
                                    cov3D_precomp, self.raster_settings)
 
+    def forward_raw(self, xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
+                    opacity_activation="sigmoid"):
+        """Extension (not in the reference's API): render from the optimiser's raw tensors, activations fused."""
+        return rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity, scaling, rotation,
+                                       self.raster_settings, opacity_activation)
 
-__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "_C"]
+
+__all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
+           "_C"]

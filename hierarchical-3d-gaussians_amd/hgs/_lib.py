@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 INST_GRAD_STRIDE = 12
 ERR_CAPACITY = 5
 
@@ -27,13 +27,17 @@ class RasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+ACT_SCALE_EXP, ACT_ROT_NORMALIZE, ACT_OPACITY_SIGMOID, ACT_OPACITY_ABS = 1, 2, 4, 8
 
 
 class RasterGrads(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "dL_dmeans3D", "dL_dmeans2D", "dL_dshs", "dL_dcolors", "dL_dopacity",
-        "dL_dscales", "dL_drotations", "dL_dcov3D")]
+        "dL_dscales", "dL_drotations", "dL_dcov3D", "dL_dshs_rest")]
 
 
 class RasterViews(C.Structure):

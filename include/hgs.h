@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 1
+#define HGS_ABI_VERSION 2
 #define HGS_TILE 16
 #define HGS_INST_GRAD_STRIDE 12 /* floats per (tile, Gaussian) instance in the backward scratch */
 
@@ -86,7 +86,23 @@ typedef struct hgs_raster_args {
   const float* cov3D_precomp;   /* [P,6] or NULL (exactly one of scales+rotations / cov3D_precomp) */
   const float* interpolation_weights; /* [>=P] or NULL : hierarchy mode (gaussian_renderer/__init__.py:262) */
   const int32_t* num_node_kids;       /* [>=P] or NULL : hierarchy mode (gaussian_renderer/__init__.py:263) */
+  /* Raw-parameter fast path: the op applies the activations of
+   * scene/gaussian_model.py:108-128 itself, so the caller passes the optimiser's raw tensors and gets gradients
+   * w.r.t. them -- no exp / normalize / sigmoid / cat kernels (and their backward) around the op. */
+  const float* shs_rest;    /* NULL: shs is [P,M,3].  Else shs = features_dc [P,1,3], shs_rest = features_rest
+                             * [P,M-1,3] (the two tensors get_features concatenates, scene/gaussian_model.py:121-124) */
+  int32_t activations;      /* OR of HGS_ACT_*; 0 = inputs are already activated (the reference's call) */
+  int32_t reserved;
 } hgs_raster_args;
+
+enum {
+  HGS_ACT_SCALE_EXP = 1,       /* scales = exp(raw)                     scene/gaussian_model.py:110 */
+  HGS_ACT_ROT_NORMALIZE = 2,   /* rotations = raw / max(|raw|, 1e-12)   scene/gaussian_model.py:114 */
+  HGS_ACT_OPACITY_SIGMOID = 4, /* opacities = sigmoid(raw)              scene/gaussian_model.py:126-127 */
+  HGS_ACT_OPACITY_ABS = 8      /* opacities = |raw| (hierarchy mode)    scene/gaussian_model.py:393 */
+};
+/* Activated values are DEFINED as the double-precision result rounded once to float32 (deterministic on every
+ * platform); the discrete outputs (radii, tile rectangles, sort keys) follow from those float32 values. */
 
 /* Workspace sizes in bytes.  geom: per-Gaussian state (P); bin: per-instance
  * keys/lists + tile ranges (L = number of (tile,Gaussian) instances, known after
@@ -126,6 +142,7 @@ typedef struct hgs_raster_grads {
   float* dL_dscales;    /* [P,3] or NULL */
   float* dL_drotations; /* [P,4] or NULL */
   float* dL_dcov3D;     /* [P,6] or NULL */
+  float* dL_dshs_rest;  /* [P,M-1,3] with args.shs_rest (dL_dshs is then [P,1,3]), else NULL */
 } hgs_raster_grads;
 
 /* Backward.  Needs the forward outputs (out_color, out_invdepth) and the

@@ -504,3 +504,24 @@ def naive_per_pixel_blend(gxp, gyp, conic, opac, rgb, invz, point_list, ranges, 
             out[:, y, x] = C + T * bg
             dep[y, x] = D
     return out, dep
+
+
+def activate_raw(scaling_raw, rotation_raw, opacity_raw, opacity_activation="sigmoid"):
+    """Specification of the raw-parameter path (include/hgs.h HGS_ACT_*): the activations of
+    scene/gaussian_model.py:108-128 evaluated in float64 and rounded ONCE to float32.  Returns float64 tensors whose
+    VALUES are those float32 numbers (so the discrete float32 spec sees exactly them) and whose autograd graph is
+    the exact activation (straight-through over the rounding)."""
+    def rounded(t):
+        return t + (t.detach().float().double() - t.detach())
+    s = rounded(torch.exp(scaling_raw.double()))
+    q = rotation_raw.double()
+    n = torch.sqrt(((q[:, 0] ** 2 + q[:, 1] ** 2) + q[:, 2] ** 2) + q[:, 3] ** 2).clamp_min(1e-12)
+    r = rounded(q / n[:, None])
+    x = opacity_raw.double()
+    if opacity_activation == "sigmoid":
+        o = rounded(1.0 / (1.0 + torch.exp(-x)))
+    elif opacity_activation == "abs":
+        o = x.abs()
+    else:
+        o = x
+    return s, r, o
