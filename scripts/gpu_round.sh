@@ -24,3 +24,5 @@ done
 cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof gpurun_out/pmc_* | head -30; nproc; free -g | head -2
 echo "== bench k=1"
 timeout 300 python bench.py --steps 30 --warmup 5 --views-per-step 1 --no-cpu-baseline > gpurun_out/bench_k1.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_k1.json | head -c 400; echo
+echo "== bench_next (SURVEY 8f rows)"
+timeout 600 python scripts/bench_next.py > gpurun_out/bench_next.jsonl 2> gpurun_out/bench_next.err; echo "bench_next exit $?"; cat gpurun_out/bench_next.jsonl; tail -3 gpurun_out/bench_next.err
