@@ -58,21 +58,23 @@ __global__ __launch_bounds__(256) void lod_gather_kernel(const int32_t* __restri
     reinterpret_cast<float4*>(out.rots)[i] = make_float4(w * a.x + u * sgn * b.x, w * a.y + u * sgn * b.y,
                                                          w * a.z + u * sgn * b.z, w * a.w + u * sgn * b.w);
   }
-  if (in.shs) {
-    const int nf = M * 3;
-    const float* sr = in.shs + r * nf;
-    const float* sp = in.shs + p * nf;
-    float* so = out.shs + (size_t)i * nf;
-    if ((nf & 3) == 0) {
-      for (int k = 0; k < nf / 4; ++k) {
-        const float4 a = reinterpret_cast<const float4*>(sr)[k];
-        const float4 b = reinterpret_cast<const float4*>(sp)[k];
-        reinterpret_cast<float4*>(so)[k] = make_float4(w * a.x + u * b.x, w * a.y + u * b.y, w * a.z + u * b.z, w * a.w + u * b.w);
-      }
-    } else {
-      for (int k = 0; k < nf; ++k) so[k] = w * sr[k] + u * sp[k];
-    }
-  }
+}
+
+// SH rows (3M floats, 192 B at M = 16) are moved by their own kernels with one lane per 16-byte (or 4-byte) chunk:
+// consecutive lanes walk one row, so every row is read / written as contiguous segments instead of 64 lanes striding
+// through 64 different rows.
+template <typename V>   // float4 when 3M % 4 == 0, else float
+__global__ __launch_bounds__(256) void lod_gather_sh_kernel(const int32_t* __restrict__ render_indices,
+                                                            const int32_t* __restrict__ parent_indices,
+                                                            const float* __restrict__ weights, int n, int cpr,
+                                                            const V* __restrict__ in, V* __restrict__ out) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)n * cpr) return;
+  const int i = (int)(e / cpr), c = (int)(e - (size_t)i * cpr);
+  const float w = weights[i], u = 1.0f - w;
+  const V a = in[(size_t)render_indices[i] * cpr + c];
+  const V b = in[(size_t)parent_indices[i] * cpr + c];
+  out[e] = w * a + u * b;
 }
 
 __global__ __launch_bounds__(256) void lod_monotone_kernel(const int32_t* __restrict__ parent_indices, int n,
@@ -101,7 +103,6 @@ __global__ __launch_bounds__(256) void lod_scatter_kernel(const int32_t* __restr
   const size_t r = (size_t)render_indices[i];
   const int p = parent_indices[i];
   const float w = weights[i];
-  const int nf = M * 3;
   const bool self_parent = (size_t)p == r;      // root: the "parent" is the node itself, the lerp is the identity
   // ---- node row: unique per cut entry -> plain stores -----------------------------------------
   const float wn = self_parent ? 1.0f : w;
@@ -109,7 +110,6 @@ __global__ __launch_bounds__(256) void lod_scatter_kernel(const int32_t* __restr
   if (g.scales) for (int k = 0; k < 3; ++k) d.scales[r * 3 + k] += wn * g.scales[(size_t)i * 3 + k];
   if (g.opac) d.opac[r] += wn * g.opac[i];
   if (g.rots) for (int k = 0; k < 4; ++k) d.rots[r * 4 + k] += wn * g.rots[(size_t)i * 4 + k];
-  if (g.shs) for (int k = 0; k < nf; ++k) d.shs[r * nf + k] += wn * g.shs[(size_t)i * nf + k];
   // ---- parent row: the first lane of each run of equal parents sums the run -------------------
   if (i > 0 && parent_indices[i - 1] == p) return;
   int j = i;
@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256) void lod_scatter_kernel(const int32_t* __restr
       for (int k = 0; k < 4; ++k) aq[k] += u * sgn * g.rots[(size_t)j * 4 + k];
     }
   }
-  const int run_end = j;
   const size_t pp = (size_t)p;
   if (atomic_mode) {
     if (g.means) for (int k = 0; k < 3; ++k) add_to<true>(d.means + pp * 3 + k, am[k]);
@@ -140,15 +139,36 @@ __global__ __launch_bounds__(256) void lod_scatter_kernel(const int32_t* __restr
     if (g.opac) add_to<false>(d.opac + pp, ao);
     if (g.rots) for (int k = 0; k < 4; ++k) add_to<false>(d.rots + pp * 4 + k, aq[k]);
   }
-  if (g.shs) {      // 3M values per row: stream them instead of holding the run sum in registers
-    for (int k = 0; k < nf; ++k) {
-      float acc = 0.f;
-      for (int jj = i; jj < run_end; ++jj) {
-        if (pp == (size_t)render_indices[jj]) continue;
-        acc += (1.0f - weights[jj]) * g.shs[(size_t)jj * nf + k];
-      }
-      if (atomic_mode) add_to<true>(d.shs + pp * nf + k, acc); else add_to<false>(d.shs + pp * nf + k, acc);
-    }
+}
+
+template <typename V, bool ATOMIC>
+__global__ __launch_bounds__(256) void lod_scatter_sh_kernel(const int32_t* __restrict__ render_indices,
+                                                             const int32_t* __restrict__ parent_indices,
+                                                             const float* __restrict__ weights, int n, int cpr,
+                                                             const V* __restrict__ g, V* __restrict__ d,
+                                                             const uint32_t* __restrict__ nonmono) {
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)n * cpr) return;
+  if (ATOMIC != (*nonmono != 0)) return;          // both instantiations are launched; the flag picks one
+  const int i = (int)(e / cpr), c = (int)(e - (size_t)i * cpr);
+  const int r = render_indices[i], p = parent_indices[i];
+  const bool self_parent = p == r;
+  const V gi = g[e];
+  d[(size_t)r * cpr + c] = (self_parent ? 1.0f : weights[i]) * gi;      // node rows are unique: plain store
+  if (i > 0 && parent_indices[i - 1] == p) return;                       // not the leader of its run of siblings
+  V acc = gi * 0.0f;
+  for (int j = i; j < n && parent_indices[j] == p; ++j) {
+    if (render_indices[j] == p) continue;
+    acc += (1.0f - weights[j]) * g[(size_t)j * cpr + c];
+  }
+  V* dst = d + (size_t)p * cpr + c;
+  if (ATOMIC) {
+    float* df = reinterpret_cast<float*>(dst);
+    const float* af = reinterpret_cast<const float*>(&acc);
+#pragma unroll
+    for (int k = 0; k < (int)(sizeof(V) / sizeof(float)); ++k) atomicAdd(df + k, af[k]);
+  } else {
+    *dst += acc;
   }
 }
 
@@ -174,6 +194,19 @@ int hgs_lod_gather(const int32_t* render_indices, const int32_t* parent_indices,
   hipLaunchKernelGGL(lod_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, weights,
                      n, M, in, out);
   HGS_LAUNCH_CHECK("lod_gather", s, false);
+  if (shs) {
+    const int nf = M * 3;
+    if ((nf & 3) == 0) {
+      const int cpr = nf / 4;
+      hipLaunchKernelGGL(lod_gather_sh_kernel<float4>, dim3((uint32_t)(((size_t)n * cpr + 255) / 256)), dim3(256), 0, s,
+                         render_indices, parent_indices, weights, n, cpr, reinterpret_cast<const float4*>(shs),
+                         reinterpret_cast<float4*>(o_shs));
+    } else {
+      hipLaunchKernelGGL(lod_gather_sh_kernel<float>, dim3((uint32_t)(((size_t)n * nf + 255) / 256)), dim3(256), 0, s,
+                         render_indices, parent_indices, weights, n, nf, shs, o_shs);
+    }
+    HGS_LAUNCH_CHECK("lod_gather_sh", s, false);
+  }
   return HGS_OK;
 }
 
@@ -199,6 +232,26 @@ int hgs_lod_gather_bwd(const int32_t* render_indices, const int32_t* parent_indi
   hipLaunchKernelGGL(lod_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, weights,
                      n, M, g, rotations, d, flag_tmp);
   HGS_LAUNCH_CHECK("lod_scatter", s, false);
+  if (g_shs) {
+    const int nf = M * 3;
+    if ((nf & 3) == 0) {
+      const int cpr = nf / 4;
+      const dim3 grid((uint32_t)(((size_t)n * cpr + 255) / 256));
+      const float4* gv = reinterpret_cast<const float4*>(g_shs);
+      float4* dv = reinterpret_cast<float4*>(d_shs);
+      hipLaunchKernelGGL((lod_scatter_sh_kernel<float4, false>), grid, dim3(256), 0, s, render_indices, parent_indices,
+                         weights, n, cpr, gv, dv, flag_tmp);
+      hipLaunchKernelGGL((lod_scatter_sh_kernel<float4, true>), grid, dim3(256), 0, s, render_indices, parent_indices,
+                         weights, n, cpr, gv, dv, flag_tmp);
+    } else {
+      const dim3 grid((uint32_t)(((size_t)n * nf + 255) / 256));
+      hipLaunchKernelGGL((lod_scatter_sh_kernel<float, false>), grid, dim3(256), 0, s, render_indices, parent_indices,
+                         weights, n, nf, g_shs, d_shs, flag_tmp);
+      hipLaunchKernelGGL((lod_scatter_sh_kernel<float, true>), grid, dim3(256), 0, s, render_indices, parent_indices,
+                         weights, n, nf, g_shs, d_shs, flag_tmp);
+    }
+    HGS_LAUNCH_CHECK("lod_scatter_sh", s, false);
+  }
   return HGS_OK;
 }
 
