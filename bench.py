@@ -54,7 +54,7 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     return b
 
 
-def cpu_baseline(scene, cam, bg, gc, gd, L_total, seed=3, n_tiles=512):
+def cpu_baseline(scene, cam, bg, gc, gd, L_total, seed=3, n_tiles=1024):
     """Naive PyTorch-CPU per-pixel alpha blend (= the oracle, float32) timed on the host cores on a
     bounded sample: the per-Gaussian stage for the whole scene + dense blending fwd+bwd of `n_tiles`
     randomly chosen tiles; the blend time is scaled by tile-instance count to a full frame."""
