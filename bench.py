@@ -32,6 +32,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+DOMINANT = "render_bwd"  # the kernel the roofline object describes (largest share of the frame, profiles/)
 
 
 def algorithmic_bytes(P, V, L, N, T, M, depth=True):
@@ -190,8 +191,11 @@ def main():
     timing = (not args.no_stage_timing)
     barrier()
     if timing:
+        # inside the timed region only the dominant kernel is bracketed by hipEvents (the roofline figure must
+        # come from the timed steps themselves); the other stages are timed in a short extra pass afterwards so
+        # that their 20 event records per view do not sit in the measured stream
         _lib.timing_read(reset=True)
-        _lib.timing_enable(True)
+        _lib.timing_enable(True, stages=[DOMINANT])
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -201,7 +205,14 @@ def main():
     stages = {}
     if timing:
         _lib.timing_enable(False)
+        dom_ms = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.timing_read(reset=True).items() if c}
+        _lib.timing_enable(True)
+        for _ in range(max(2, min(args.steps, 5))):
+            step()
+        barrier()
+        _lib.timing_enable(False)
         stages = {k: (ms / max(c, 1)) for k, (ms, c) in _lib.timing_read(reset=True).items() if c}
+        stages.update(dom_ms)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -232,7 +243,7 @@ def main():
             "frame_hbm_frac": total_bytes * (k * args.steps / elapsed) / 1e9 / HBM_PEAK_GBS,
         }
         if stages:
-            dom = max(stages, key=stages.get)
+            dom = DOMINANT if DOMINANT in stages else max(stages, key=stages.get)
             achieved = ab[dom] / (stages[dom] * 1e-3) / 1e9
             traffic = None
             pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")

@@ -16,7 +16,7 @@ static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate
                                             "tile_depth_sort", "render_fwd", "memset_bwd", "render_bwd",
                                             "preprocess_bwd"};
 struct Pending { int stage; hipEvent_t a, b; };
-static bool g_timing = false;
+static uint32_t g_timing = 0;      // bit 0: every stage; bit (1 + stage): that stage only
 static std::mutex g_tmu;
 static std::vector<Pending> g_pending;
 static std::vector<hipEvent_t> g_pool;
@@ -25,7 +25,7 @@ static uint32_t g_calls[ST_COUNT];
 
 struct StageTimer {
   int stage; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; bool on;
-  StageTimer(int st, hipStream_t stream) : stage(st), s(stream), on(g_timing) {
+  StageTimer(int st, hipStream_t stream) : stage(st), s(stream), on((g_timing & (1u | (2u << st))) != 0) {
     if (!on) return;
     std::lock_guard<std::mutex> lk(g_tmu);
     for (hipEvent_t* e : {&a, &b}) {
@@ -308,7 +308,7 @@ int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, c
 
 int hgs_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_tmu);
-  g_timing = on != 0;
+  g_timing = (uint32_t)on;
   return HGS_OK;
 }
 int hgs_timing_stage_count(void) { return ST_COUNT; }

@@ -65,6 +65,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(color, invdepth)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)      # no zero-filled "gradient" for radii / an unused invdepth
         return color, radii, invdepth
 
     @staticmethod
@@ -100,6 +101,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         ctx.split = features_rest is not None and features_rest.numel() > 0
         ctx.save_for_backward(color, invdepth)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
         return color, radii, invdepth
 
     @staticmethod

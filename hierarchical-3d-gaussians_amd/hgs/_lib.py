@@ -134,8 +134,16 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def timing_enable(on: bool):
-    check(lib().hgs_timing_enable(1 if on else 0), "hgs_timing_enable")
+def timing_enable(on, stages=None):
+    """on: bool; stages: optional iterable of stage names -- time only those (fewer events on the stream)."""
+    l = lib()
+    mask = 1 if on else 0
+    if on and stages:
+        names = [l.hgs_timing_stage_name(i).decode() for i in range(l.hgs_timing_stage_count())]
+        mask = 0
+        for s in stages:
+            mask |= 2 << names.index(s)
+    check(l.hgs_timing_enable(mask), "hgs_timing_enable")
 
 
 def timing_read(reset=True):

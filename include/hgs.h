@@ -182,6 +182,8 @@ int hgs_sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* k
 /* Optional per-stage timing with hipEvents recorded on the caller's stream (bench.py's
  * per-kernel roofline figures).  Off by default; no reference counterpart (the reference
  * records CUDA events it never reads: train_single.py:41-42,86,124). */
+/* on: 0 = off, 1 = every stage, otherwise a mask with bit (1 + i) selecting stage i only (two events per timed
+ * stage are recorded on the stream, so timing one kernel perturbs a measured region less than timing all). */
 int hgs_timing_enable(int on);
 int hgs_timing_stage_count(void);
 const char* hgs_timing_stage_name(int i);
