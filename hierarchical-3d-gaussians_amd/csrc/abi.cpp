@@ -182,8 +182,8 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
                           const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
   int rc;
+  if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;   // also zeroes b.ranges
   if (L > 0) {
-    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;
     if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
   }
   if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;

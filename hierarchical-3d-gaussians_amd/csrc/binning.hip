@@ -29,7 +29,10 @@ __device__ __forceinline__ uint32_t rect_count(uint2 r) {     // rects are zero 
 // row-major tiles inside a rectangle (SURVEY.md App. A.7 emission order).
 __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int gx, GeomWs g, uint32_t cap,
                                                                     uint32_t* __restrict__ tile_keys,
-                                                                    uint32_t* __restrict__ vals) {
+                                                                    uint32_t* __restrict__ vals,
+                                                                    uint32_t* __restrict__ ranges, int n_ranges) {
+  // the tile ranges must be zero before tile_ranges_kernel fills them: cleared here instead of by a memset launch
+  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
   __shared__ uint32_t excl[kPreBlock + 1];
   __shared__ uint2 lrect[kPreBlock];
   __shared__ uint32_t wave_tot[kPreBlock / 64];
@@ -142,11 +145,9 @@ __global__ __launch_bounds__(256) void tile_depth_sort_small_kernel(const uint32
   sort_tile_in_lds<256>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, n);
 }
 
-__global__ __launch_bounds__(1024) void tile_depth_sort_large_kernel(const uint32_t* __restrict__ ranges,
-                                                                     const float* __restrict__ depths,
-                                                                     uint32_t* __restrict__ vals,
-                                                                     const uint32_t* __restrict__ big, int T) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
+                                                 const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                                 const uint32_t* __restrict__ big, int T) {
   const uint32_t count = big[0];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
     const uint32_t tile = big[2 + e];
@@ -160,13 +161,11 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_large_kernel(const uint3
 // sort (4 x 8 bits of the depth key, id as payload) through the tile's own slice of two global
 // scratch arrays.  Slow (one CU per such tile) but size-unbounded; ids start ascending, so a stable
 // sort by depth alone yields the (depth, id) order.
-__global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32_t* __restrict__ ranges,
-                                                                    const float* __restrict__ depths,
-                                                                    uint32_t* __restrict__ vals,
-                                                                    uint32_t* __restrict__ scratch_k,
-                                                                    uint32_t* __restrict__ scratch_v,
-                                                                    uint32_t* __restrict__ scratch_k2,
-                                                                    const uint32_t* __restrict__ big, int T) {
+__device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ranges,
+                                                const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                                uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
+                                                uint32_t* __restrict__ scratch_k2,
+                                                const uint32_t* __restrict__ big, int T) {
   __shared__ uint32_t hist[256];
   __shared__ uint32_t base[256];
   __shared__ uint32_t wave_cnt[16][256];
@@ -232,6 +231,21 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_huge_kernel(const uint32
   }   // tile loop
 }
 
+// One launch for both oversized classes (their lists are almost always empty: a second launch would cost more
+// than the work).  128 KiB of dynamic LDS for the large class + 18 KiB static for the huge class.
+__global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_t* __restrict__ ranges,
+                                                                   const float* __restrict__ depths,
+                                                                   uint32_t* __restrict__ vals,
+                                                                   uint32_t* __restrict__ scratch_k,
+                                                                   uint32_t* __restrict__ scratch_v,
+                                                                   uint32_t* __restrict__ scratch_k2,
+                                                                   const uint32_t* __restrict__ big, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  sort_large_tiles(smem, ranges, depths, vals, big, T);
+  __syncthreads();
+  sort_huge_tiles(ranges, depths, vals, scratch_k, scratch_v, scratch_k2, big, T);
+}
+
 __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __restrict__ keys, uint32_t L_cap,
                                                           const uint32_t* __restrict__ L_dev,
                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
@@ -257,15 +271,18 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0 && L_cap > 0) {
+    const int T = grid_x(a.width) * grid_y(a.height);
     hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
-                       b.keys_in, b.vals_in);
+                       b.keys_in, b.vals_in, b.ranges, T * 2);
     HGS_LAUNCH_CHECK("duplicate_tiles", s, a.debug);
+  } else {
+    HGS_HIP(hipMemsetAsync(b.ranges, 0, (size_t)grid_x(a.width) * grid_y(a.height) * 2 * sizeof(uint32_t), s));
   }
   return HGS_OK;
 }
 
 int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug) {
-  HGS_HIP(hipMemsetAsync(b.ranges, 0, (size_t)T * 2 * sizeof(uint32_t), s));
+  // b.ranges was zeroed by launch_duplicate_tiles
   if (L_cap > 0) {
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((L_cap + 255) / 256), dim3(256), 0, s, b.keys_out, L_cap, L_dev, b.ranges,
                        b.big_tiles);
@@ -279,7 +296,7 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   if (L == 0) return HGS_OK;
   static bool attr_set = false;
   if (!attr_set) {   // 128 KiB of dynamic LDS needs an explicit opt-in
-    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_large_kernel),
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_big_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
     attr_set = true;
   }
@@ -287,13 +304,10 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                      b.vals_out, b.big_tiles, T);
   HGS_LAUNCH_CHECK("tile_depth_sort_small", s, a.debug);
   const int big_grid = T < 256 ? T : 256;
-  hipLaunchKernelGGL(tile_depth_sort_large_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,
-                     b.vals_out, b.big_tiles, T);
-  HGS_LAUNCH_CHECK("tile_depth_sort_large", s, a.debug);
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
-  hipLaunchKernelGGL(tile_depth_sort_huge_kernel, dim3(big_grid), dim3(1024), 0, s, b.ranges, g.depths, b.vals_out,
-                     b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T);
-  HGS_LAUNCH_CHECK("tile_depth_sort_huge", s, a.debug);
+  hipLaunchKernelGGL(tile_depth_sort_big_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,
+                     b.vals_out, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T);
+  HGS_LAUNCH_CHECK("tile_depth_sort_big", s, a.debug);
   return HGS_OK;
 }
 
