@@ -126,6 +126,8 @@ static int validate(const hgs_raster_args* a) {
       if (a->sh_degree < 0 || a->sh_degree > 3) { set_error("sh_degree %d not in 0..3", a->sh_degree); return HGS_ERR_INVALID; }
       if (a->M < (a->sh_degree + 1) * (a->sh_degree + 1) || a->M > 16) { set_error("M=%d incompatible with sh_degree=%d (max 16 coefficients)", a->M, a->sh_degree); return HGS_ERR_INVALID; }
     }
+    // the SH blocks and the quaternions are moved with 16-byte accesses
+    if (((uintptr_t)a->shs | (uintptr_t)a->shs_rest | (uintptr_t)a->rotations) & 15u) { set_error("shs / shs_rest / rotations must be 16-byte aligned"); return HGS_ERR_INVALID; }
     if (a->shs_rest && (!a->shs || a->M < 2)) { set_error("shs_rest needs shs (features_dc) and M >= 2"); return HGS_ERR_INVALID; }
     if ((a->activations & HGS_ACT_OPACITY_SIGMOID) && (a->activations & HGS_ACT_OPACITY_ABS)) { set_error("choose one opacity activation"); return HGS_ERR_INVALID; }
     if ((a->activations & (HGS_ACT_SCALE_EXP | HGS_ACT_ROT_NORMALIZE)) && a->cov3D_precomp) { set_error("scale / rotation activations need scales and rotations"); return HGS_ERR_INVALID; }

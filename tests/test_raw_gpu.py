@@ -123,3 +123,8 @@ def test_raw_path_argument_checks(gpu):
         dgr.GaussianRasterizer(rs).forward_raw(scene.means3D, m2, scene.shs[:, :1].contiguous(),
                                                scene.shs[:, 1:].contiguous(), scene.opacities, scene.scales,
                                                scene.rotations, opacity_activation="tanh")
+    # a contiguous slice whose first byte is not 16-byte aligned (12-byte rows) is refused, not mis-read
+    dc11 = torch.zeros(11, 1, 3, device=gpu)
+    with pytest.raises(RuntimeError, match="16-byte"):
+        dgr.GaussianRasterizer(rs).forward_raw(scene.means3D, m2, dc11[1:], scene.shs[:, 1:].contiguous(),
+                                               scene.opacities, scene.scales, scene.rotations)
