@@ -361,7 +361,7 @@ struct FwdPair {
 };
 
 template <bool DEPTH>
-__device__ __forceinline__ bool fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, bool c0, bool c1, const float4& q1,
+__device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, bool c0, bool c1, const float4& q1,
                                               const float4& q2, uint32_t idx1) {
   const f2 G = {fast_exp2(pw.x), fast_exp2(pw.y)};
   const f2 araw = q1.y * G;
@@ -380,12 +380,8 @@ __device__ __forceinline__ bool fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, bool c0,
   p.T = p.T * (1.0f - ae);
   p.last0 = blend0 ? idx1 : p.last0;
   p.last1 = blend1 ? idx1 : p.last1;
-  const bool anystop = __ballot(stop0 || stop1) != 0;
-  if (anystop) {
-    p.fly.x = stop0 ? kBig : p.fly.x;
-    p.fly.y = stop1 ? kBig : p.fly.y;
-  }
-  return anystop;
+  p.fly.x = stop0 ? kBig : p.fly.x;      // a saturated pixel leaves the tile (see above); whether the WHOLE tile
+  p.fly.y = stop1 ? kBig : p.fly.y;      // is finished is checked once per batch, not per stop event
 }
 
 template <bool DEPTH>
@@ -448,19 +444,19 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      // candidate tests as "max of the pair >= thr": one plain compare per ballot (a ballot of an OR of compares
+      // costs two more vector instructions), and one for the whole tile on the most common path -- no candidate
+      const float m0 = fmaxf(pw0.x, pw0.y), m1 = fmaxf(pw1.x, pw1.y);
+      if (__ballot(fmaxf(m0, m1) >= thr) == 0) continue;
+      const bool b0 = __ballot(m0 >= thr) != 0, b1 = __ballot(m1 >= thr) != 0;   // wave-uniform
       const bool c0 = pw0.x >= thr, c1 = pw0.y >= thr, c2 = pw1.x >= thr, c3 = pw1.y >= thr;
       const uint32_t idx1 = base - r0 + j + 1;
-      bool stopped = false;
-      if (__ballot(c0 || c1) != 0) stopped = fwd_pair_live<DEPTH>(P0, pw0, c0, c1, q1, q2, idx1);
-      if (__ballot(c2 || c3) != 0) stopped = fwd_pair_live<DEPTH>(P1, pw1, c2, c3, q1, q2, idx1) || stopped;
-      if (stopped) {   // wave-uniform, rare: some pixel saturated -> is the whole tile finished?
-        const bool any = (P0.fly.x < kBig) || (P0.fly.y < kBig) || (P1.fly.x < kBig) || (P1.fly.y < kBig);
-        if (__ballot(any) == 0) {
-          wave_done = true;
-          break;
-        }
-      }
+      if (b0) fwd_pair_live<DEPTH>(P0, pw0, c0, c1, q1, q2, idx1);
+      if (b1) fwd_pair_live<DEPTH>(P1, pw1, c2, c3, q1, q2, idx1);
     }
+    // every pixel saturated?  (finished pixels sit at y = kBig: the rest of a batch costs them only the
+    // no-candidate path above)
+    wave_done = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig) == 0;
   }
 
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
@@ -494,12 +490,19 @@ struct BwdSums {
   f2 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
 };
 
+// min(x, 0) as exactly one v_min_f32 (fminf adds a canonicalising v_max x, x in front of it)
+__device__ __forceinline__ float min_zero(float x) {
+  float r;
+  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
                                                   const float4& q1, const float4& q2) {
   // min(pw, 0): identical for live lanes (they require pw <= 0) and keeps G finite on the others,
   // whose contributions are multiplied by an exact 0 below
-  const f2 G = {fast_exp2(fminf(pw.x, 0.0f)), fast_exp2(fminf(pw.y, 0.0f))};
+  const f2 G = {fast_exp2(min_zero(pw.x)), fast_exp2(min_zero(pw.y))};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);   // = blended by the forward
@@ -635,13 +638,17 @@ __global__ __launch_bounds__(64) void render_bwd_packed_kernel(
       const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      // cheapest exit first: no pixel of the tile passes the alpha threshold (one max tree + one compare)
+      if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) continue;
       const bool c0 = (pw0.x >= thr) && (rel < P0.nc0), c1 = (pw0.y >= thr) && (rel < P0.nc1);
       const bool c2 = (pw1.x >= thr) && (rel < P1.nc0), c3 = (pw1.y >= thr) && (rel < P1.nc1);
+      const bool b0 = __ballot(c0 || c1) != 0, b1 = __ballot(c2 || c3) != 0;   // wave-uniform
+      if (!(b0 || b1)) continue;   // candidates only on pixels that had stopped before this Gaussian
       BwdSums S;
       S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
       uint64_t any_blend = 0;
-      if (__ballot(c0 || c1) != 0) any_blend |= bwd_pair_live<DEPTH>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
-      if (__ballot(c2 || c3) != 0) any_blend |= bwd_pair_live<DEPTH>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
+      if (b0) any_blend |= bwd_pair_live<DEPTH>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
+      if (b1) any_blend |= bwd_pair_live<DEPTH>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
       if (any_blend != 0) {   // wave-uniform
         // 10 sums x 64 lanes -> 12 slots in 28 VALU: fold the two strips of each pair, then halve the
         // lane count twice with permlane32/16 swaps (two values share a register afterwards), then
