@@ -26,3 +26,6 @@ echo "== bench k=1"
 timeout 300 python bench.py --steps 30 --warmup 5 --views-per-step 1 --no-cpu-baseline > gpurun_out/bench_k1.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_k1.json | head -c 400; echo
 echo "== bench_next (SURVEY 8f rows)"
 timeout 600 python scripts/bench_next.py > gpurun_out/bench_next.jsonl 2> gpurun_out/bench_next.err; echo "bench_next exit $?"; cat gpurun_out/bench_next.jsonl; tail -3 gpurun_out/bench_next.err
+echo "== PMC summary"
+python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db SQ2=gpurun_out/pmc_SQ2/pmc_results.db F=gpurun_out/pmc_FETCH_SIZE/pmc_results.db W=gpurun_out/pmc_WRITE_SIZE/pmc_results.db > gpurun_out/pmc_summary.json 2>/dev/null; echo "pmc summary exit $?"
+python scripts/rocprof_summary.py $(ls gpurun_out/prof/*.db | head -1) > gpurun_out/kernel_stats.txt 2>/dev/null; head -25 gpurun_out/kernel_stats.txt

@@ -1,0 +1,49 @@
+#!/usr/bin/env python
+"""Derive profiles/pmc_traffic.json (HBM bytes per launch) and profiles/pmc_valu.json (vector-ALU view) from the
+per-kernel PMC summary written by scripts/pmc_summary.py.
+
+    python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db ... > profiles/r01_runNN_pmc.json
+    python scripts/make_pmc_json.py profiles/r01_runNN_pmc.json
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and gfx950's
+FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STAGES = {           # bench.py stage -> substrings of the kernels it launches
+    "render_bwd": ["render_bwd_packed"], "render_fwd": ["render_fwd_packed"], "preprocess_fwd": ["preprocess_fwd"],
+    "preprocess_bwd": ["preprocess_bwd", "sh_bwd"], "duplicate_keys": ["duplicate_tiles"],
+    "tile_ranges": ["tile_ranges"], "tile_depth_sort": ["tile_depth_sort"],
+    "radix_sort": ["rs_histogram", "rs_scan", "rs_scatter"],
+}
+PER_FRAME = {"rs_histogram": 2, "rs_scan": 2, "rs_scatter": 2}   # launches per frame of one kernel symbol
+
+
+def main():
+    d = json.load(open(sys.argv[1]))
+    traffic, valu = {}, {}
+    for stage, pats in STAGES.items():
+        tot = 0.0
+        for p in pats:      # template variants of one kernel (accumulate on / off ...) are averaged, not added
+            vals = [(2 * cs["FETCH_SIZE"] + cs.get("WRITE_SIZE", 0.0)) * 1024 for k, cs in d.items()
+                    if p in k and "FETCH_SIZE" in cs]
+            if vals:
+                tot += sum(vals) / len(vals) * PER_FRAME.get(p, 1)
+        if tot:
+            traffic[stage] = tot
+    for stage in ("render_bwd", "render_fwd"):
+        for k, cs in d.items():
+            if STAGES[stage][0] in k and "SQ_INSTS_VALU" in cs:
+                w = cs.get("SQ_WAVES", 0.0) or 1.0
+                valu[stage] = {"valu_insts_per_launch": cs["SQ_INSTS_VALU"], "waves": cs.get("SQ_WAVES"),
+                               "valu_active_quadcycles_per_wave": cs.get("SQ_ACTIVE_INST_VALU", 0.0) / w,
+                               "wave_quadcycles_per_wave": cs.get("SQ_WAVE_CYCLES", 0.0) / w}
+    json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+    json.dump(valu, open(os.path.join(ROOT, "profiles", "pmc_valu.json"), "w"), indent=1)
+    print(json.dumps({"traffic": traffic, "valu": valu}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
