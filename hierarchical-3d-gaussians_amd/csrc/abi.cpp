@@ -190,7 +190,9 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
   }
   if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
   if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, s)))) return rc;
-  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
+  float* zero_ws = static_cast<float*>(a->bwd_ws_prezero);
+  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, zero_ws,
+                                                       zero_ws ? (size_t)L * kInstStride : 0, s));
 }
 
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
@@ -273,7 +275,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   float* inst = static_cast<float*>(bwd_ws);
   float* drgb = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + align_up((size_t)(L ? L : 1) * kInstStride * 4));
   if (L > 0) {
-    {
+    if (a->bwd_ws_prezero != bwd_ws) {   // else: zero-filled by the forward's compositing kernel
       StageTimer _t(ST_MEMSET_BWD, s);
       HGS_HIP(hipMemsetAsync(inst, 0, (size_t)L * kInstStride * sizeof(float), s));
     }

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib) {
+    uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_ws, uint32_t zero_vecs) {
   constexpr int BATCH = 64;
   constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
   __shared__ float4 lrec[BATCH * kLds];
@@ -478,6 +478,15 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       final_T[pix] = Tf[s];
       n_contrib[pix] = la[s];
     }
+  }
+  // Side job (hgs_raster_args.bwd_ws_prezero): every tile clears its share of the backward's instance scratch.
+  // This kernel is ALU-bound with HBM mostly idle, so the stores ride along for free; they are issued last so that
+  // nothing in this wave waits for them.
+  if (zero_ws) {
+    const uint32_t per = (zero_vecs + (uint32_t)T - 1) / (uint32_t)T;
+    const uint32_t z0 = (uint32_t)tg.tile * per;
+    const uint32_t z1 = min(z0 + per, zero_vecs);
+    for (uint32_t i = z0 + (uint32_t)lane; i < z1; i += 64u) zero_ws[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
@@ -696,7 +705,11 @@ static int launch_fwd_s(const hgs_raster_args& a, const GeomWs& g, const BinWs& 
 // variant: 0 (default) = one wave per tile, packed strip pairs; 1 / 2 / 3 = the generic kernels with
 // four / two / one wave(s) per tile (S = 1 / 2 / 4), kept for A/B profiling.
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
-                      float* out_color, float* out_invdepth, hipStream_t s) {
+                      float* out_color, float* out_invdepth, float* zero_ws, size_t zero_floats, hipStream_t s) {
+  if (zero_ws && ((a.variant >= 1 && a.variant <= 3) || (zero_floats >> 2) > 0xffffffffull)) {
+    HGS_HIP(hipMemsetAsync(zero_ws, 0, zero_floats * sizeof(float), s));   // A/B kernels do not carry the side job
+    zero_ws = nullptr;
+  }
   switch (a.variant) {
     case 1: return launch_fwd_s<1>(a, g, b, im, out_color, out_invdepth, s);
     case 2: return launch_fwd_s<2>(a, g, b, im, out_color, out_invdepth, s);
@@ -709,7 +722,8 @@ int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   auto kern = depth ? render_fwd_packed_kernel<true> : render_fwd_packed_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
-                     out_invdepth, im.final_T, im.n_contrib);
+                     out_invdepth, im.final_T, im.n_contrib, reinterpret_cast<float4*>(zero_ws),
+                     (uint32_t)(zero_floats >> 2));
   HGS_LAUNCH_CHECK("render_fwd_packed", s, a.debug);
   return HGS_OK;
 }

@@ -58,7 +58,7 @@ def _lod(weights, kids, P):
 class _Call:
     """Everything one forward needs to hand back to the backward.  ``L`` = instances rendered; ``L_ws`` = the
     instance capacity the binning workspace was carved with (== L on the two-stage path)."""
-    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device")
+    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device", "scratch")
 
 
 # Instance count of the previous forward per device: lets the next forward size its binning workspace
@@ -129,9 +129,11 @@ def _stream(device):
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                        num_node_kids, do_depth, variant=0, sh_rest=None, activations=0):
+                        num_node_kids, do_depth, variant=0, sh_rest=None, activations=0, prepare_backward=False):
     """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
-    invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward."""
+    invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward.  ``prepare_backward``: allocate
+    the backward's scratch now and let the forward's compositing kernel zero-fill it on the side
+    (hgs_raster_args.bwd_ws_prezero) instead of a memset in the backward."""
     if (render_indices is not None and render_indices.numel() > 0) or \
             (parent_indices is not None and parent_indices.numel() > 0):
         raise RuntimeError("rasterize_gaussians expects already gathered rows; non-empty render_indices / "
@@ -156,18 +158,23 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     L = C.c_uint32(0)
     devi = dev.index or 0
     binb = None
+    scratch = None
     L_ws = 0
     prev = _last_L.get(devi) if SPECULATIVE else None
     if prev is not None and P > 0:
         # no-bubble path: everything is enqueued before the host learns L
         L_ws = int(prev * 1.25) + 65536
-        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
+        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
         binb = torch.empty(sz[1].value, **u8)
+        if prepare_backward:
+            scratch = torch.empty(sz[3].value, **u8)
+            a.bwd_ws_prezero = scratch.data_ptr()
         rc = lib.hgs_raster_fwd(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws, _lib.ptr(radii),
                                 _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None, C.byref(L),
                                 _stream(dev), devi)
         if rc == _lib.ERR_CAPACITY:
-            binb = None             # the scene grew by more than 25 %: finish on the exact two-stage path
+            binb = scratch = None   # the scene grew by more than 25 %: finish on the exact two-stage path
+            a.bwd_ws_prezero = None
         else:
             _lib.check(rc, "hgs_raster_fwd")
     else:
@@ -175,8 +182,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                              _stream(dev), devi), "hgs_raster_fwd_stage1")
     if binb is None:
         L_ws = L.value
-        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, None), "hgs_raster_ws_sizes")
+        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
         binb = torch.empty(sz[1].value, **u8)
+        if prepare_backward and P > 0:
+            scratch = torch.empty(sz[3].value, **u8)
+            a.bwd_ws_prezero = scratch.data_ptr()
         _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
@@ -184,6 +194,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
+    call.scratch = scratch
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
@@ -226,10 +237,14 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
     g.dL_dshs_rest = p(d_shr)
     a.accumulate_grads = int(bool(accumulate and out is not None))
-    bwd_bytes = C.c_size_t()
-    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
-               "hgs_raster_ws_sizes")
-    scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
+    scratch = call.scratch           # allocated and zero-filled by the forward (prepare_backward), single use
+    call.scratch = None
+    if scratch is None:
+        a.bwd_ws_prezero = None
+        bwd_bytes = C.c_size_t()
+        _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
+                   "hgs_raster_ws_sizes")
+        scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
     _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L_ws,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),

@@ -60,7 +60,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             rs.bg, means3D, colors_precomp, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp,
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
             rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.render_indices, rs.parent_indices,
-            rs.interpolation_weights, rs.num_node_kids, rs.do_depth, getattr(_RasterizeGaussians, "variant", 0))
+            rs.interpolation_weights, rs.num_node_kids, rs.do_depth, getattr(_RasterizeGaussians, "variant", 0),
+            prepare_backward=any(ctx.needs_input_grad))
         ctx.call = call
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(color, invdepth)
@@ -96,7 +97,7 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
             rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, features_dc,
             rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, rs.render_indices, rs.parent_indices,
             rs.interpolation_weights, rs.num_node_kids, rs.do_depth, 0, sh_rest=features_rest,
-            activations=activations)
+            activations=activations, prepare_backward=any(ctx.needs_input_grad))
         ctx.call = call
         ctx.split = features_rest is not None and features_rest.numel() > 0
         ctx.save_for_backward(color, invdepth)

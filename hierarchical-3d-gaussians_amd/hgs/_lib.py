@@ -27,7 +27,7 @@ class RasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
-        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("reserved", C.c_int32),
+        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("reserved", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
     ]
 
 

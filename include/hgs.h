@@ -93,6 +93,11 @@ typedef struct hgs_raster_args {
                              * [P,M-1,3] (the two tensors get_features concatenates, scene/gaussian_model.py:121-124) */
   int32_t activations;      /* OR of HGS_ACT_*; 0 = inputs are already activated (the reference's call) */
   int32_t reserved;
+  /* Optional: the bwd_ws buffer the matching hgs_raster_bwd call will receive (bwd_bytes of hgs_raster_ws_sizes
+   * for the same L).  The forward then zero-fills its instance-gradient part from inside the compositing kernel --
+   * that kernel is ALU-bound and leaves HBM idle, so the 48 B per instance of zeroes cost nothing there -- and the
+   * backward, seeing the same pointer, skips its own memset.  NULL: the backward clears the scratch itself. */
+  void* bwd_ws_prezero;
 } hgs_raster_args;
 
 enum {
