@@ -397,3 +397,34 @@ def test_awkward_inputs(gpu):
     assert oo.geom.tiles_touched.max() == ((W + 15) // 16) * ((H + 15) // 16)
     _assert_case("awkward", hip, oo, og)
     assert float(hip["grads"]["opacities"][12:18].abs().max()) == 0.0
+
+
+def test_backward_scratch_prezero_and_memset_paths_agree(gpu):
+    """The instance-gradient scratch is cleared either by the forward's compositing kernel
+    (hgs_raster_args.bwd_ws_prezero, what the autograd op uses) or by a memset in the backward (a caller that did
+    not announce a backward).  Stale scratch contents must not leak into either; both give identical gradients."""
+    import diff_gaussian_rasterization as dgr
+    C_ = dgr._C
+    W, H, P = 200, 120, 3000
+    cam = synth.make_camera(W, H)
+    sc = synth.make_scene(P, cam, seed=5).to(gpu)
+    gc, gd = (t.to(gpu) for t in synth.upstream_grads(H, W))
+    e_i = torch.empty(0, dtype=torch.int32, device=gpu)
+    e_f = torch.empty(0, device=gpu)
+    poison = torch.full((64 << 20,), float("nan"), device=gpu)     # make the caching allocator hand out NaN-filled blocks
+    del poison
+    res = []
+    for prepare in (True, False, True):
+        out = C_.rasterize_gaussians(torch.zeros(3, device=gpu), sc.means3D, None, sc.opacities, sc.scales, sc.rotations,
+                                     1.0, None, cam.world_view_transform.to(gpu), cam.full_proj_transform.to(gpu),
+                                     cam.tanfovx, cam.tanfovy, H, W, sc.shs, 3, cam.camera_center.to(gpu), False, False,
+                                     e_i, e_i, e_f, e_i, True, prepare_backward=prepare)
+        color, invd, call = out[1], out[6], out[7]
+        assert (call.scratch is not None) == prepare
+        g = C_.rasterize_gaussians_backward(call, color, invd, gc, gd)
+        res.append([t.clone() for t in g if t is not None])
+        assert all(torch.isfinite(t).all() for t in res[-1])
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    for a, b in zip(res[0], res[2]):
+        assert torch.equal(a, b)
