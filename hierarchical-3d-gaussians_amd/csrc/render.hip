@@ -706,7 +706,7 @@ static int launch_fwd_s(const hgs_raster_args& a, const GeomWs& g, const BinWs& 
 // four / two / one wave(s) per tile (S = 1 / 2 / 4), kept for A/B profiling.
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, float* zero_ws, size_t zero_floats, hipStream_t s) {
-  if (zero_ws && ((a.variant >= 1 && a.variant <= 3) || (zero_floats >> 2) > 0xffffffffull)) {
+  if (zero_ws && ((a.variant >= 1 && a.variant <= 3) || (zero_floats >> 2) > 0xfff00000ull)) {
     HGS_HIP(hipMemsetAsync(zero_ws, 0, zero_floats * sizeof(float), s));   // A/B kernels do not carry the side job
     zero_ws = nullptr;
   }
