@@ -166,3 +166,113 @@ def build_hierarchy(scene) -> Hierarchy:
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
     return Hierarchy(xyz=t(mu), shs=t(sh), alpha=t(op[:, None]), log_scales=t(np.log(scales)), rots=t(quat),
                      nodes=torch.from_numpy(nodes), boxes=torch.from_numpy(boxes))
+
+
+def build_hierarchy_on_device(P, cam, device, seed=0, sh_degree=3, s_px=(0.5, 4.0), z_range=(2.0, 20.0)) -> Hierarchy:
+    """Scale-test generator (BASELINE config 5: tens of millions of nodes): same topology and layout as
+    ``build_hierarchy`` over the same leaf distribution as ``hgs.synth.make_scene``, but built with torch ops on
+    ``device`` in float32, and interior nodes are AXIS-ALIGNED moment matches (scales = sqrt of the merged covariance's
+    diagonal, identity rotation) instead of eigen-decomposed ones.  2 P - 1 nodes; everything stays on ``device``."""
+    import math
+    g = torch.Generator(device=device).manual_seed(seed)
+    U = lambda *s: torch.rand(*s, generator=g, device=device)
+    N_ = lambda *s: torch.randn(*s, generator=g, device=device)
+    z = z_range[0] + (z_range[1] - z_range[0]) * U(P)
+    xyz = torch.stack([z * cam.tanfovx * (2 * U(P) - 1), z * cam.tanfovy * (2 * U(P) - 1), z], 1)
+    fx = cam.image_width / (2.0 * cam.tanfovx)
+    spx = torch.exp(math.log(s_px[0]) + (math.log(s_px[1]) - math.log(s_px[0])) * U(P))
+    s_leaf = (z * spx / fx)[:, None] * (0.3 + 0.7 * U(P, 3))
+    q_leaf = torch.nn.functional.normalize(N_(P, 4), dim=1)
+    o_leaf = 0.05 + 0.9 * U(P)
+    M = (sh_degree + 1) ** 2
+    # Morton order of the leaves
+    lo_, hi_ = xyz.min(0).values, xyz.max(0).values
+    qi = ((xyz - lo_) / (hi_ - lo_).clamp_min(1e-12) * 1023.0).clamp(0, 1023).long()
+
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    order = torch.argsort(spread(qi[:, 0]) | (spread(qi[:, 1]) << 1) | (spread(qi[:, 2]) << 2), stable=True)
+    del qi
+    # ---- topology (BFS over index ranges; children contiguous) ------------------------------------------
+    lo, hi = [torch.zeros(1, dtype=torch.int64, device=device)], [torch.full((1,), P, dtype=torch.int64, device=device)]
+    parent = [torch.full((1,), -1, dtype=torch.int64, device=device)]
+    start_children, first_id, next_id = [], [0], 1
+    while True:
+        l, h = lo[-1], hi[-1]
+        interior = (h - l) > 1
+        n_int = int(interior.sum())
+        sc = torch.zeros_like(l)
+        sc[interior] = next_id + 2 * torch.arange(n_int, device=device)
+        start_children.append(sc)
+        if n_int == 0:
+            break
+        mid = (l[interior] + h[interior]) // 2
+        ids = first_id[-1] + interior.nonzero().flatten()
+        lo.append(torch.stack([l[interior], mid], 1).reshape(-1))
+        hi.append(torch.stack([mid, h[interior]], 1).reshape(-1))
+        parent.append(ids.repeat_interleave(2))
+        first_id.append(next_id)
+        next_id += 2 * n_int
+    N = next_id
+    lo_a = torch.cat(lo)
+    sc_a = torch.cat(start_children)
+    depth_a = torch.cat([torch.full((t.shape[0],), d, dtype=torch.int64, device=device) for d, t in enumerate(lo)])
+    parent_a = torch.cat(parent)
+    is_leaf = sc_a == 0
+    is_leaf[0] = P == 1
+    # ---- attributes -----------------------------------------------------------------------------------------
+    f32 = dict(dtype=torch.float32, device=device)
+    mu = torch.zeros(N, 3, **f32); var = torch.zeros(N, 3, **f32); w = torch.zeros(N, **f32)
+    op = torch.zeros(N, **f32); sh = torch.zeros(N, 16, 3, **f32)
+    bmin = torch.zeros(N, 3, **f32); bmax = torch.zeros(N, 3, **f32)
+    rots = torch.zeros(N, 4, **f32); rots[:, 0] = 1.0
+    leaf_ids = is_leaf.nonzero().flatten()
+    src = order[lo_a[leaf_ids]]
+    mu[leaf_ids] = xyz[src]
+    # axis-aligned second moments of an oriented leaf: diag(R diag(s^2) R^T)
+    r, x, y, zq = q_leaf[src].unbind(1)
+    R = torch.stack([1 - 2 * (y * y + zq * zq), 2 * (x * y - r * zq), 2 * (x * zq + r * y),
+                     2 * (x * y + r * zq), 1 - 2 * (x * x + zq * zq), 2 * (y * zq - r * x),
+                     2 * (x * zq - r * y), 2 * (y * zq + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    var[leaf_ids] = ((R * R) * (s_leaf[src] ** 2)[:, None, :]).sum(2)
+    del R
+    op[leaf_ids] = o_leaf[src]
+    w[leaf_ids] = o_leaf[src] * s_leaf[src].prod(1)
+    sh[leaf_ids, 0] = 0.5 * N_(P, 3)
+    if M > 1:
+        sh[leaf_ids, 1:M] = 0.05 * N_(P, M - 1, 3)
+    ext = 3.0 * s_leaf[src].max(1, keepdim=True).values
+    bmin[leaf_ids] = xyz[src] - ext
+    bmax[leaf_ids] = xyz[src] + ext
+    for lvl in range(len(lo) - 1, -1, -1):
+        a, b = first_id[lvl], first_id[lvl] + lo[lvl].shape[0]
+        ids = a + (~is_leaf[a:b]).nonzero().flatten()
+        if ids.numel() == 0:
+            continue
+        c0 = sc_a[ids]; c1 = c0 + 1
+        ws = (w[c0] + w[c1]).clamp_min(1e-30)
+        f0, f1 = (w[c0] / ws)[:, None], (w[c1] / ws)[:, None]
+        m = f0 * mu[c0] + f1 * mu[c1]
+        var[ids] = f0 * (var[c0] + (mu[c0] - m) ** 2) + f1 * (var[c1] + (mu[c1] - m) ** 2)
+        mu[ids] = m
+        sh[ids] = f0[:, :, None] * sh[c0] + f1[:, :, None] * sh[c1]
+        op[ids] = (f0[:, 0] * op[c0] + f1[:, 0] * op[c1]).clamp(0.0, 1.0)
+        w[ids] = ws
+        bmin[ids] = torch.minimum(bmin[c0], bmin[c1])
+        bmax[ids] = torch.maximum(bmax[c0], bmax[c1])
+    scales = var.clamp_min(1e-12).sqrt()
+    scales[leaf_ids] = s_leaf[src]
+    rots[leaf_ids] = q_leaf[src]
+    cc = torch.where(is_leaf, 0, 2)
+    nodes = torch.stack([depth_a, parent_a, torch.arange(N, device=device), is_leaf.long(), (~is_leaf).long(),
+                         torch.where(is_leaf, 0, sc_a), cc], 1).to(torch.int32).contiguous()
+    boxes = torch.zeros(N, 2, 4, **f32)
+    boxes[:, 0, :3] = bmin
+    boxes[:, 1, :3] = bmax
+    boxes[:, 0, 3] = (bmax - bmin).max(1).values
+    return Hierarchy(xyz=mu, shs=sh, alpha=op[:, None].contiguous(), log_scales=scales.log(), rots=rots, nodes=nodes,
+                     boxes=boxes)
