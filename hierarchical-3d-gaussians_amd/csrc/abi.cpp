@@ -84,7 +84,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
 
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
-  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 2 + 2) * 4) + sort_tmp_bytes(L ? L : 1) + kAlign;
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) + sort_tmp_bytes(L ? L : 1) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
@@ -95,7 +95,7 @@ BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   b.keys_out = carve<uint32_t>(c, l);
   b.vals_out = carve<uint32_t>(c, l);
   b.ranges = carve<uint32_t>(c, (size_t)T * 2);
-  b.big_tiles = carve<uint32_t>(c, (size_t)T * 2 + 2);
+  b.big_tiles = carve<uint32_t>(c, (size_t)T * 3 + 3);
   b.sort_tmp = c;
   return b;
 }

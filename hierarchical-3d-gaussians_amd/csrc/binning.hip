@@ -106,9 +106,6 @@ __device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t m) {
   }
 }
 
-// big[0] / big[1]: number of tiles in the large / huge class; big + 2: large list [T], then huge list [T].
-// The small-class launch (one workgroup per tile) files oversized tiles into these lists, so the large
-// and huge launches need only a small grid that walks them (usually empty).
 template <int THREADS>
 __device__ __forceinline__ void sort_tile_in_lds(uint64_t* keys, const float* __restrict__ depths,
                                                  uint32_t* __restrict__ vals, uint32_t r0, uint32_t n) {
@@ -127,22 +124,111 @@ __device__ __forceinline__ void sort_tile_in_lds(uint64_t* keys, const float* __
   for (uint32_t i = threadIdx.x; i < n; i += THREADS) vals[r0 + i] = (uint32_t)keys[i];
 }
 
-__global__ __launch_bounds__(256) void tile_depth_sort_small_kernel(const uint32_t* __restrict__ ranges,
-                                                                    const float* __restrict__ depths,
-                                                                    uint32_t* __restrict__ vals, uint32_t* big, int T) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const uint32_t r0 = ranges[blockIdx.x * 2 + 0], r1 = ranges[blockIdx.x * 2 + 1];
+// ---- register-resident bitonic sort: one WAVE per tile, E keys per lane, no LDS, no barriers ----------------
+// Logical element index i = lane * E + e.  Compare-exchange partners at distance j < E sit in the same lane
+// (pure VALU); at distance j >= E they sit in lane ^ (j / E) and are fetched with a 64-bit lane shuffle.  The
+// LDS version above pays a workgroup barrier per stage (45 stages for 512 keys) and is latency-bound; here the
+// stages of a wave simply follow each other.  Keys are unique ((depth bits << 32) | id), so the unstable network
+// yields the stable (depth, id) order.
+__device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
+  const bool sw = (a > b) == up;
+  const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+  a = lo;
+  b = hi;
+}
+
+template <int E>
+__device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                               uint32_t r0, uint32_t n, int lane) {
+  constexpr int M = 64 * E;
+  uint64_t key[E];
+  // coalesced load (register slot e of lane l <- list entry e * 64 + l): the network sorts whatever permutation
+  // it is given, only the OUTPUT position is tied to the logical index
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t i = (uint32_t)(e * 64 + lane);
+    uint64_t k = ~0ull;
+    if (i < n) {
+      const uint32_t gid = vals[r0 + i];
+      k = ((uint64_t)__float_as_uint(depths[gid]) << 32) | gid;
+    }
+    key[e] = k;
+  }
+  const uint32_t base = (uint32_t)lane * E;
+#pragma unroll
+  for (int k = 2; k <= M; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= E) {                                   // partner in another lane
+        const int lx = j / E;
+        const bool lower = (lane & lx) == 0;
+        const bool up = (base & (uint32_t)k) == 0;    // k >= 2E: the direction bit is a lane bit
+        const bool keep_min = lower == up;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint64_t other = __shfl_xor(key[e], lx, 64);
+          const bool other_less = other < key[e];
+          key[e] = (other_less == keep_min) ? other : key[e];
+        }
+      } else {                                        // partner in the same lane
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          if ((e & j) == 0) {
+            // direction bit of i = base + e: a bit of e while k < E (base is a multiple of E), a lane bit after
+            const bool up = k < E ? ((e & k) == 0) : ((base & (uint32_t)k) == 0);
+            cmp_swap(key[e], key[e | j], up);
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t i = base + (uint32_t)e;
+    if (i < n) vals[r0 + i] = (uint32_t)key[e];
+  }
+}
+
+constexpr uint32_t kWaveCap = 512;      // one wave, 8 keys per lane
+
+// One wave per tile (4 tiles per workgroup, no inter-wave communication).  Tiles above kWaveCap instances are filed
+// into the class lists: big[0] / big[1] / big[2] = number of large / huge / medium tiles; big + 3: large list [T],
+// huge list [T], medium list [T].
+__global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
+                                                                   const float* __restrict__ depths,
+                                                                   uint32_t* __restrict__ vals, uint32_t* big, int T) {
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= T) return;
+  const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
   const uint32_t n = r1 - r0;
   if (n <= 1) return;
-  if (n > kSmallCap) {
-    if (threadIdx.x == 0) {
-      const int cls = n > kLargeCap ? 1 : 0;
+  if (n > kWaveCap) {
+    if (lane == 0) {
+      const int cls = n > kLargeCap ? 1 : (n > kSmallCap ? 0 : 2);
       const uint32_t slot = atomicAdd(&big[cls], 1u);
-      big[2 + cls * T + slot] = blockIdx.x;
+      big[3 + cls * T + slot] = (uint32_t)tile;
     }
     return;
   }
-  sort_tile_in_lds<256>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, n);
+  if (n <= 128) wave_sort_tile<2>(depths, vals, r0, n, lane);
+  else if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
+  else wave_sort_tile<8>(depths, vals, r0, n, lane);
+}
+
+// Medium class (kWaveCap < n <= kSmallCap): 256-lane bitonic sort in 16 KiB of LDS, one workgroup per listed tile.
+__global__ __launch_bounds__(256) void tile_depth_sort_medium_kernel(const uint32_t* __restrict__ ranges,
+                                                                     const float* __restrict__ depths,
+                                                                     uint32_t* __restrict__ vals,
+                                                                     const uint32_t* __restrict__ big, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t count = big[2];
+  for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
+    const uint32_t tile = big[3 + 2 * T + e];
+    const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+    __syncthreads();
+    sort_tile_in_lds<256>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
+  }
 }
 
 __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
@@ -150,7 +236,7 @@ __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint
                                                  const uint32_t* __restrict__ big, int T) {
   const uint32_t count = big[0];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-    const uint32_t tile = big[2 + e];
+    const uint32_t tile = big[3 + e];
     const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
     __syncthreads();
     sort_tile_in_lds<1024>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
@@ -172,7 +258,7 @@ __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ran
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint32_t count = big[1];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-  const uint32_t tile = big[2 + T + e];
+  const uint32_t tile = big[3 + T + e];
   const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
   const uint32_t n = r1 - r0;
   __syncthreads();
@@ -251,7 +337,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
                                                           uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   const uint32_t L = L_dev ? min(*L_dev, L_cap) : L_cap;
-  if (i == 0) { big[0] = 0; big[1] = 0; }   // big-tile lists of the depth sort that follows
+  if (i == 0) { big[0] = 0; big[1] = 0; big[2] = 0; }   // class lists of the depth sort that follows
   if (i >= L) return;
   const uint32_t t = keys[i];
   if (i == 0) {
@@ -300,9 +386,13 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(tile_depth_sort_small_kernel, dim3(T), dim3(256), kSmallCap * 8, s, b.ranges, g.depths,
+  hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out,
+                     b.big_tiles, T);
+  HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
+  const int med_grid = T < 2048 ? T : 2048;
+  hipLaunchKernelGGL(tile_depth_sort_medium_kernel, dim3(med_grid), dim3(256), kSmallCap * 8, s, b.ranges, g.depths,
                      b.vals_out, b.big_tiles, T);
-  HGS_LAUNCH_CHECK("tile_depth_sort_small", s, a.debug);
+  HGS_LAUNCH_CHECK("tile_depth_sort_medium", s, a.debug);
   const int big_grid = T < 256 ? T : 256;
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   hipLaunchKernelGGL(tile_depth_sort_big_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,

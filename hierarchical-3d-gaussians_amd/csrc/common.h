@@ -68,7 +68,7 @@ struct BinWs {
   uint32_t* keys_out;  // [L] tile ids, stable-sorted
   uint32_t* vals_out;  // [L] per tile ascending id after the tile sort; point_list after the per-tile depth sort
   uint32_t* ranges;    // [T,2]
-  uint32_t* big_tiles; // [2 + 2T] counters + lists of tiles too crowded for the 256-lane LDS sort
+  uint32_t* big_tiles; // [3 + 3T] counters + lists of the tiles too crowded for the one-wave register sort
   void* sort_tmp;
   static size_t bytes(uint32_t L, int32_t T);
   static BinWs carve_from(void* base, uint32_t L, int32_t T);
