@@ -137,10 +137,71 @@ __device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
   b = hi;
 }
 
+// Value of lane ^ LX.  ds_bpermute (what __shfl_xor compiles to) goes through the LDS crossbar and its issue rate
+// bounds this kernel, so every distance that has a register-file path uses it: DPP quad permutes (1, 2), DPP row
+// rotate by half a row (8), v_permlane16_swap / v_permlane32_swap (16, 32); only 4 is left to the crossbar.
+template <int LX>
+__device__ __forceinline__ uint32_t lane_xor32(uint32_t v, int lane) {
+  if constexpr (LX == 1) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+  } else if constexpr (LX == 2) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+  } else if constexpr (LX == 8) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);    // row_ror:8
+  } else if constexpr (LX == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);          // r[0] = rows (0,0,2,2), r[1] = (1,1,3,3)
+    return (lane & 16) ? r[0] : r[1];
+  } else if constexpr (LX == 32) {
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);          // r[0] = (lo, lo), r[1] = (hi, hi)
+    return (lane & 32) ? r[0] : r[1];
+  } else {
+    return (uint32_t)__shfl_xor((int)v, LX, 64);
+  }
+}
+template <int LX>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
+  return ((uint64_t)lane_xor32<LX>((uint32_t)(v >> 32), lane) << 32) | lane_xor32<LX>((uint32_t)v, lane);
+}
+
+// One compare-exchange stage (K = bitonic block size, J = partner distance) of the network over i = lane * E + e.
+template <int E, int K, int J>
+__device__ __forceinline__ void wave_sort_stage(uint64_t (&key)[E], int lane, uint32_t base) {
+  if constexpr (J >= E) {                             // partner in lane ^ (J / E)
+    constexpr int LX = J / E;
+    const bool lower = (lane & LX) == 0;
+    const bool up = (base & (uint32_t)K) == 0;        // K >= 2E: the direction bit is a lane bit
+    const bool keep_min = lower == up;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint64_t other = lane_xor64<LX>(key[e], lane);
+      const bool other_less = other < key[e];
+      key[e] = (other_less == keep_min) ? other : key[e];
+    }
+  } else {                                            // partner in the same lane
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      if ((e & J) == 0) {
+        // direction bit of i = base + e: a bit of e while K < E (base is a multiple of E), a lane bit after
+        const bool up = K < E ? ((e & K) == 0) : ((base & (uint32_t)K) == 0);
+        cmp_swap(key[e], key[e | J], up);
+      }
+    }
+  }
+}
+template <int E, int K, int J>
+__device__ __forceinline__ void wave_sort_block(uint64_t (&key)[E], int lane, uint32_t base) {
+  wave_sort_stage<E, K, J>(key, lane, base);
+  if constexpr (J > 1) wave_sort_block<E, K, J / 2>(key, lane, base);
+}
+template <int E, int K>
+__device__ __forceinline__ void wave_sort_network(uint64_t (&key)[E], int lane, uint32_t base) {
+  wave_sort_block<E, K, K / 2>(key, lane, base);
+  if constexpr (K < 64 * E) wave_sort_network<E, K * 2>(key, lane, base);
+}
+
 template <int E>
 __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths, uint32_t* __restrict__ vals,
                                                uint32_t r0, uint32_t n, int lane) {
-  constexpr int M = 64 * E;
   uint64_t key[E];
   // coalesced load (register slot e of lane l <- list entry e * 64 + l): the network sorts whatever permutation
   // it is given, only the OUTPUT position is tied to the logical index
@@ -155,33 +216,7 @@ __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths,
     key[e] = k;
   }
   const uint32_t base = (uint32_t)lane * E;
-#pragma unroll
-  for (int k = 2; k <= M; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      if (j >= E) {                                   // partner in another lane
-        const int lx = j / E;
-        const bool lower = (lane & lx) == 0;
-        const bool up = (base & (uint32_t)k) == 0;    // k >= 2E: the direction bit is a lane bit
-        const bool keep_min = lower == up;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const uint64_t other = __shfl_xor(key[e], lx, 64);
-          const bool other_less = other < key[e];
-          key[e] = (other_less == keep_min) ? other : key[e];
-        }
-      } else {                                        // partner in the same lane
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          if ((e & j) == 0) {
-            // direction bit of i = base + e: a bit of e while k < E (base is a multiple of E), a lane bit after
-            const bool up = k < E ? ((e & k) == 0) : ((base & (uint32_t)k) == 0);
-            cmp_swap(key[e], key[e | j], up);
-          }
-        }
-      }
-    }
-  }
+  wave_sort_network<E, 2>(key, lane, base);
 #pragma unroll
   for (int e = 0; e < E; ++e) {
     const uint32_t i = base + (uint32_t)e;
