@@ -279,9 +279,8 @@ __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint
 }
 
 // Fallback for tiles above kLargeCap instances: one 1024-thread workgroup runs a stable LSD radix
-// sort (4 x 8 bits of the depth key, id as payload) through the tile's own slice of two global
-// scratch arrays.  Slow (one CU per such tile) but size-unbounded; ids start ascending, so a stable
-// sort by depth alone yields the (depth, id) order.
+// sort (4 x 8 bits of the id, then 4 x 8 bits of the depth key, id as payload) through the tile's own
+// slice of two global scratch arrays.  Slow (one CU per such tile) but size-unbounded.
 __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ranges,
                                                 const float* __restrict__ depths, uint32_t* __restrict__ vals,
                                                 uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
@@ -299,13 +298,19 @@ __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ran
   __syncthreads();
   uint32_t* kA = scratch_k + r0;    // keys ping
   uint32_t* kB = scratch_k2 + r0;   // keys pong
-  uint32_t* vA = vals + r0;         // values ping (final result lands here: 4 passes = even)
+  uint32_t* vA = vals + r0;         // values ping (final result lands here: 8 passes = even)
   uint32_t* vB = scratch_v + r0;    // values pong
-  for (uint32_t i = tid; i < n; i += 1024) kA[i] = __float_as_uint(depths[vA[i]]);
-  __syncthreads();
   const uint64_t lt_mask = (1ull << lane) - 1ull;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = pass * 8;
+  // 8 stable passes: first by id (the tile binning does not order a tile's entries), then by depth bits
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = (pass & 3) * 8;
+    if (pass == 0) {
+      for (uint32_t i = tid; i < n; i += 1024) kA[i] = vA[i];
+      __syncthreads();
+    } else if (pass == 4) {     // 4 passes done: the data is back in vA / kA
+      for (uint32_t i = tid; i < n; i += 1024) kA[i] = __float_as_uint(depths[vA[i]]);
+      __syncthreads();
+    }
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&hist[(kA[i] >> shift) & 255u], 1u);
