@@ -45,9 +45,9 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P
     b["scan"] = 8 * (P // 256 + 1)
     b["duplicate_keys"] = 12 * P + 8 * L
-    b["radix_sort"] = 16 * L                     # one pass over (tile id, Gaussian id) pairs
+    b["tile_sort"] = 8 * L + 4 * L + 8 * T        # (tile id, Gaussian id) pairs in, ids grouped by tile out, ranges
     b["tile_depth_sort"] = 8 * T + 4 * L + 4 * L + 4 * L   # ids in, depth gather, ids out
-    b["tile_ranges"] = 4 * L + 8 * T
+    b["tile_ranges"] = 0                         # ranges come out of the tile binning (radix fallback only)
     b["render_fwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N + 8 * N
     b["memset_bwd"] = inst * L
     b["render_bwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N * 2 + inst * L

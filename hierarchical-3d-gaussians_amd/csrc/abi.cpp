@@ -12,7 +12,7 @@ namespace hgs {
 // ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
 enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SORT_DEPTH, ST_RENDER_FWD,
              ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
-static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "radix_sort", "tile_ranges",
+static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "tile_sort", "tile_ranges",
                                             "tile_depth_sort", "render_fwd", "memset_bwd", "render_bwd",
                                             "preprocess_bwd"};
 struct Pending { int stage; hipEvent_t a, b; };
@@ -84,7 +84,9 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
 
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
-  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) + sort_tmp_bytes(L ? L : 1) + kAlign;
+  const size_t tmp_sort = sort_tmp_bytes(L ? L : 1), tmp_bin = tile_bin_tmp_bytes(L, T);
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) +
+         (tmp_sort > tmp_bin ? tmp_sort : tmp_bin) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
@@ -185,11 +187,16 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
                           const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
   int rc;
   if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;   // also zeroes b.ranges
-  if (L > 0) {
-    if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
+  const bool bin = L > 0 && tile_bin_supported(T);
+  if (bin) {            // counting pass + scatter pass; writes the tile ranges too
+    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, L_dev, T, b.ranges, b.big_tiles, s, a->debug)))) return rc;
+  } else {              // very large tile grids: stable radix sort by tile id, then ranges off the sorted ids
+    if (L > 0) {
+      if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
+    }
+    if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
   }
-  if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
-  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, s)))) return rc;
+  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
   float* zero_ws = static_cast<float*>(a->bwd_ws_prezero);
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, zero_ws,
                                                        zero_ws ? (size_t)L * kInstStride : 0, s));

@@ -231,12 +231,15 @@ constexpr uint32_t kWaveCap = 512;      // one wave, 8 keys per lane
 // huge list [T], medium list [T].
 __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
-                                                                   uint32_t* __restrict__ vals, uint32_t* big, int T) {
+                                                                   uint32_t* __restrict__ vals, uint32_t* big, int T,
+                                                                   uint32_t* __restrict__ tile_ids) {
   const int lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tile >= T) return;
   const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
   const uint32_t n = r1 - r0;
+  if (tile_ids)          // sorted tile-id column (introspection / parity tests) when no global sort produced it
+    for (uint32_t i = (uint32_t)lane; i < n; i += 64u) tile_ids[r0 + i] = (uint32_t)tile;
   if (n <= 1) return;
   if (n > kWaveCap) {
     if (lane == 0) {
@@ -418,7 +421,7 @@ int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, in
 }
 
 int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
-                           hipStream_t s) {
+                           bool fill_tile_ids, hipStream_t s) {
   if (L == 0) return HGS_OK;
   static bool attr_set = false;
   if (!attr_set) {   // 128 KiB of dynamic LDS needs an explicit opt-in
@@ -427,7 +430,7 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
     attr_set = true;
   }
   hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out,
-                     b.big_tiles, T);
+                     b.big_tiles, T, fill_tile_ids ? b.keys_out : nullptr);
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
   const int med_grid = T < 2048 ? T : 2048;
   hipLaunchKernelGGL(tile_depth_sort_medium_kernel, dim3(med_grid), dim3(256), kSmallCap * 8, s, b.ranges, g.depths,

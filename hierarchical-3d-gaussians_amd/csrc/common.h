@@ -94,8 +94,9 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
 int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug);
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s);
 int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug);
+// fill_tile_ids: also write every instance's tile id into b.keys_out (the tile-binning path does not produce it)
 int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
-                           hipStream_t s);
+                           bool fill_tile_ids, hipStream_t s);
 // zero_ws / zero_floats: optional buffer the kernel zero-fills on the side (hgs_raster_args.bwd_ws_prezero)
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, float* zero_ws, size_t zero_floats, hipStream_t s);
@@ -104,6 +105,11 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           const hgs_raster_grads& out, hipStream_t s);
+// tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
+bool tile_bin_supported(int32_t T);
+size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);
+int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
+                    const uint32_t* L_dev, int32_t T, uint32_t* ranges, uint32_t* big, hipStream_t s, bool debug);
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);

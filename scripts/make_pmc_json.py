@@ -15,10 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGES = {           # bench.py stage -> substrings of the kernels it launches
     "render_bwd": ["render_bwd_packed"], "render_fwd": ["render_fwd_packed"], "preprocess_fwd": ["preprocess_fwd"],
     "preprocess_bwd": ["preprocess_bwd", "sh_bwd"], "duplicate_keys": ["duplicate_tiles"],
-    "tile_ranges": ["tile_ranges"], "tile_depth_sort": ["tile_depth_sort"],
-    "radix_sort": ["rs_histogram", "rs_scan", "rs_scatter"],
+    "tile_ranges": ["tile_ranges"],
+    "tile_depth_sort": ["tile_depth_sort_wave", "tile_depth_sort_medium", "tile_depth_sort_big"],
+    "tile_sort": ["tb_count", "tb_colscan", "tb_base", "tb_scatter"],
 }
-PER_FRAME = {"rs_histogram": 2, "rs_scan": 2, "rs_scatter": 2}   # launches per frame of one kernel symbol
+PER_FRAME = {}   # launches per frame of one kernel symbol when it is not 1
 
 
 def main():

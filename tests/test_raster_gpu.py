@@ -428,3 +428,33 @@ def test_backward_scratch_prezero_and_memset_paths_agree(gpu):
         assert torch.equal(a, b)
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
+
+
+def test_huge_tile_grid_takes_the_radix_path(gpu):
+    """Tile grids above 32 768 tiles (here 320 x 180 = 57 600 at 5120 x 2880) do not fit the LDS histogram of the
+    counting tile-binning and fall back to the stable radix sort by tile id + ranges kernel.  Forward only;
+    oracle = geometry + binning spec (bit-exact ranges, point list, sorted tile ids)."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W, H, P = 5120, 2880, 60_000
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(P, cam, seed=21, s_px=(1.0, 12.0))
+    geom = ro.geometry_spec(scene.means3D.numpy(), scene.scales.numpy(), scene.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            cam.tanfovx, cam.tanfovy, 1.0)
+    binning = ro.binning_spec(geom)
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    sc = scene.to(gpu)
+    for _ in range(2):        # two-stage call first, speculative single call second
+        L, color, radii, geomb, binb, img, invd, call = dgr._C.rasterize_gaussians(
+            rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+            rs.interpolation_weights, rs.num_node_kids, True)
+        v = dgr._C.raster_views(call)
+        assert L == binning.num_rendered
+        assert np.array_equal(radii.cpu().numpy(), geom.radii)
+        assert np.array_equal(v["ranges"].cpu().numpy(), binning.ranges)
+        assert np.array_equal(v["point_list"].cpu().numpy(), binning.point_list)
+        assert np.array_equal(v["tile_ids_sorted"].cpu().numpy().astype(np.uint64),
+                              binning.keys_sorted >> np.uint64(32))
+        assert torch.isfinite(color).all() and float(color.max()) > 0.05
