@@ -50,60 +50,67 @@ __global__ __launch_bounds__(kTbThreads) void tb_colscan_kernel(uint32_t* __rest
   const int g = blockIdx.y;
   const int c0 = g * cpg, c1 = min(c0 + cpg, nchunks);
   uint32_t acc = 0;
-  for (int c = c0; c < c1; ++c) {
-    uint32_t* p = table + (size_t)c * T + t;
-    const uint32_t v = *p;
-    *p = acc;
-    acc += v;
+  for (int cb = c0; cb < c1; cb += 8) {           // 8 independent loads in flight, then the 8 prefix stores
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = (cb + k < c1) ? table[(size_t)(cb + k) * T + t] : 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (cb + k < c1) table[(size_t)(cb + k) * T + t] = acc;
+      acc += v[k];
+    }
   }
   gsum[(size_t)g * T + t] = acc;
 }
 
 // One workgroup: per tile, turn the group sums into absolute bases (gsum[g][t] := range start + groups before g),
-// write the tile ranges, reset the depth-sort class counters.
-__global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gsum, int T, uint32_t* __restrict__ ranges,
-                                                       uint32_t* __restrict__ big) {
+// write the tile ranges, reset the depth-sort class counters.  A lane owns `per` consecutive tiles so that all its
+// loads are in flight at once and the workgroup scans only once.
+__global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gsum, int T, int per,
+                                                       uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
   __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) { carry_s = 0; big[0] = 0; big[1] = 0; big[2] = 0; }
+  if (tid == 0) { big[0] = 0; big[1] = 0; big[2] = 0; }
+  const int t0 = tid * per;
+  uint32_t mine = 0;
+  for (int i = 0; i < per; ++i) {
+    const int t = t0 + i;
+    if (t < T) {
+#pragma unroll
+      for (int g = 0; g < kGroups; ++g) mine += gsum[(size_t)g * T + t];
+    }
+  }
+  uint32_t inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t v = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += v;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
   __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += 1024) {
-    const int t = t0 + tid;
-    uint32_t tot = 0;
-    if (t < T) {
+  uint32_t start = inc - mine;
+  for (int w = 0; w < wave; ++w) start += wave_tot[w];
+  for (int i = 0; i < per; ++i) {
+    const int t = t0 + i;
+    if (t >= T) break;
+    uint32_t acc = start;
 #pragma unroll
-      for (int g = 0; g < kGroups; ++g) tot += gsum[(size_t)g * T + t];
+    for (int g = 0; g < kGroups; ++g) {
+      const uint32_t v = gsum[(size_t)g * T + t];
+      gsum[(size_t)g * T + t] = acc;
+      acc += v;
     }
-    uint32_t inc = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t v = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += v;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    const uint32_t carry = carry_s;
-    const uint32_t start = carry + wbase + inc - tot;
-    if (t < T) {
-      ranges[t * 2 + 0] = start;
-      ranges[t * 2 + 1] = start + tot;
-      uint32_t acc = start;
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) {
-        const uint32_t v = gsum[(size_t)g * T + t];
-        gsum[(size_t)g * T + t] = acc;
-        acc += v;
-      }
-    }
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + inc;
-    __syncthreads();
+    const uint32_t tot = acc - start;
+    ranges[t * 2 + 0] = tot ? start : 0u;          // empty tiles read (0, 0), as after identifyTileRanges
+    ranges[t * 2 + 1] = tot ? acc : 0u;
+    start = acc;
   }
 }
 
+// CURSOR: LDS holds one absolute output cursor per tile (gbase + table row, loaded coalesced): one LDS fetch-and-add
+// per instance and no dependent global reads.  Otherwise (tile grid too large for 4 bytes of LDS per tile): packed
+// 16-bit chunk-local counters and two global reads per instance.
+template <bool CURSOR>
 __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ vals, uint32_t n_cap,
                                                                 const uint32_t* __restrict__ n_dev, int T, uint32_t chunk,
@@ -111,20 +118,28 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ gbase,
                                                                 uint32_t* __restrict__ vals_out) {
   extern __shared__ uint32_t h[];
-  const int words = (T + 1) >> 1;
-  for (int w = threadIdx.x; w < words; w += kTbThreads) h[w] = 0u;
+  const uint32_t* row = table + (size_t)blockIdx.x * T;
+  const uint32_t* grow = gbase + (size_t)(blockIdx.x / cpg) * T;
+  if (CURSOR) {
+    for (int t = threadIdx.x; t < T; t += kTbThreads) h[t] = grow[t] + row[t];
+  } else {
+    const int words = (T + 1) >> 1;
+    for (int w = threadIdx.x; w < words; w += kTbThreads) h[w] = 0u;
+  }
   __syncthreads();
   const uint32_t n = tb_n(n_cap, n_dev);
   const uint32_t base = blockIdx.x * chunk;
   const uint32_t end = min(base + chunk, n);
-  const uint32_t* row = table + (size_t)blockIdx.x * T;
-  const uint32_t* grow = gbase + (size_t)(blockIdx.x / cpg) * T;
   for (uint32_t i = base + threadIdx.x; i < end; i += kTbThreads) {
     const uint32_t t = keys[i];
     const uint32_t gid = vals[i];
-    const uint32_t sh = (t & 1u) * 16u;
-    const uint32_t r = (atomicAdd(&h[t >> 1], 1u << sh) >> sh) & 0xffffu;
-    vals_out[grow[t] + row[t] + r] = gid;
+    if (CURSOR) {
+      vals_out[atomicAdd(&h[t], 1u)] = gid;
+    } else {
+      const uint32_t sh = (t & 1u) * 16u;
+      const uint32_t r = (atomicAdd(&h[t >> 1], 1u << sh) >> sh) & 0xffffu;
+      vals_out[grow[t] + row[t] + r] = gid;
+    }
   }
 }
 
@@ -156,7 +171,9 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
   if (!attr_set) {   // up to 64 KiB of dynamic LDS at 4K
     HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_count_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_scatter_kernel),
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_scatter_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_scatter_kernel<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     attr_set = true;
   }
@@ -165,10 +182,14 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
   hipLaunchKernelGGL(tb_colscan_kernel, dim3((T + kTbThreads - 1) / kTbThreads, kGroups), dim3(kTbThreads), 0, s, table,
                      nchunks, cpg, T, gsum);
   HGS_LAUNCH_CHECK("tile_bin_colscan", s, debug);
-  hipLaunchKernelGGL(tb_base_kernel, dim3(1), dim3(1024), 0, s, gsum, T, ranges, big);
+  hipLaunchKernelGGL(tb_base_kernel, dim3(1), dim3(1024), 0, s, gsum, T, (T + 1023) / 1024, ranges, big);
   HGS_LAUNCH_CHECK("tile_bin_base", s, debug);
-  hipLaunchKernelGGL(tb_scatter_kernel, dim3(nchunks), dim3(kTbThreads), lds, s, keys, vals, L_cap, L_dev, T, chunk, cpg,
-                     table, gsum, vals_out);
+  if (T <= 16384)
+    hipLaunchKernelGGL(tb_scatter_kernel<true>, dim3(nchunks), dim3(kTbThreads), (size_t)T * 4, s, keys, vals, L_cap, L_dev,
+                       T, chunk, cpg, table, gsum, vals_out);
+  else
+    hipLaunchKernelGGL(tb_scatter_kernel<false>, dim3(nchunks), dim3(kTbThreads), lds, s, keys, vals, L_cap, L_dev, T, chunk,
+                       cpg, table, gsum, vals_out);
   HGS_LAUNCH_CHECK("tile_bin_scatter", s, debug);
   return HGS_OK;
 }
