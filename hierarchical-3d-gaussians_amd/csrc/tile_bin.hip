@@ -7,8 +7,8 @@
 //   count   : a workgroup histograms its chunk of instances over ALL tiles in LDS (two 16-bit counters per word)
 //             and writes the T counts of its chunk                                   table[chunk][tile]
 //   colscan : per tile, exclusive scan of the chunk counts inside each of kGroups chunk groups (in place)
-//   base    : per tile: group sums -> totals -> exclusive scan over the tiles = tile ranges; per-group bases
-//   scatter : pos = gbase[group][tile] + table[chunk][tile] + (LDS fetch-and-add inside the chunk); ids only
+//   base    : exclusive scan of the tile totals = tile ranges (one workgroup); group sums -> prefix over the groups
+//   scatter : pos = base[tile] + gprefix[group][tile] + table[chunk][tile] + (LDS fetch-and-add); ids only
 // Two passes over the instances instead of four, 4 launches instead of 7 (the tile ranges fall out of the scan).
 // Used while the 16-bit-per-tile LDS histogram fits (T <= kTileBinMaxTiles); larger grids take the radix path.
 #include "common.h"
@@ -25,10 +25,13 @@ __device__ __forceinline__ uint32_t tb_n(uint32_t n_cap, const uint32_t* __restr
 
 __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __restrict__ keys, uint32_t n_cap,
                                                               const uint32_t* __restrict__ n_dev, int T, uint32_t chunk,
-                                                              uint32_t* __restrict__ table) {
+                                                              uint32_t* __restrict__ table,
+                                                              uint32_t* __restrict__ totals) {
   extern __shared__ uint32_t h[];
   const int words = (T + 1) >> 1;
   for (int w = threadIdx.x; w < words; w += kTbThreads) h[w] = 0u;
+  if (blockIdx.x == 0)      // per-tile totals are accumulated with atomics by the column scan that follows
+    for (int t = threadIdx.x; t < T; t += kTbThreads) totals[t] = 0u;
   __syncthreads();
   const uint32_t n = tb_n(n_cap, n_dev);
   const uint32_t base = blockIdx.x * chunk;
@@ -44,7 +47,8 @@ __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __
 
 // grid (ceil(T / 256), kGroups): exclusive scan over the chunks of one group, per tile; group sums to gsum[g][t]
 __global__ __launch_bounds__(kTbThreads) void tb_colscan_kernel(uint32_t* __restrict__ table, int nchunks, int cpg, int T,
-                                                                uint32_t* __restrict__ gsum) {
+                                                                uint32_t* __restrict__ gsum,
+                                                                uint32_t* __restrict__ totals) {
   const int t = blockIdx.x * kTbThreads + threadIdx.x;
   if (t >= T) return;
   const int g = blockIdx.y;
@@ -61,25 +65,37 @@ __global__ __launch_bounds__(kTbThreads) void tb_colscan_kernel(uint32_t* __rest
     }
   }
   gsum[(size_t)g * T + t] = acc;
+  if (acc) atomicAdd(&totals[t], acc);
 }
 
-// One workgroup: per tile, turn the group sums into absolute bases (gsum[g][t] := range start + groups before g),
-// write the tile ranges, reset the depth-sort class counters.  A lane owns `per` consecutive tiles so that all its
-// loads are in flight at once and the workgroup scans only once.
-__global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gsum, int T, int per,
+// Workgroup 0: exclusive scan of the per-tile totals = tile ranges (a lane owns `per` consecutive tiles: one
+// workgroup-wide scan); resets the depth-sort class counters.  Workgroups 1..: per tile, exclusive prefix of the
+// group sums over the groups, in place (independent of workgroup 0).
+__global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gsum, const uint32_t* __restrict__ totals,
+                                                       int T, int per, uint32_t* __restrict__ base,
                                                        uint32_t* __restrict__ ranges, uint32_t* __restrict__ big) {
+  const int tid = threadIdx.x;
+  if (blockIdx.x > 0) {
+    const int t = (blockIdx.x - 1) * 1024 + tid;
+    if (t >= T) return;
+    uint32_t v[kGroups];
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) v[g] = gsum[(size_t)g * T + t];
+    uint32_t acc = 0;
+#pragma unroll
+    for (int g = 0; g < kGroups; ++g) {
+      gsum[(size_t)g * T + t] = acc;
+      acc += v[g];
+    }
+    return;
+  }
   __shared__ uint32_t wave_tot[16];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { big[0] = 0; big[1] = 0; big[2] = 0; }
   const int t0 = tid * per;
   uint32_t mine = 0;
-  for (int i = 0; i < per; ++i) {
-    const int t = t0 + i;
-    if (t < T) {
-#pragma unroll
-      for (int g = 0; g < kGroups; ++g) mine += gsum[(size_t)g * T + t];
-    }
-  }
+  for (int i = 0; i < per; ++i)
+    if (t0 + i < T) mine += totals[t0 + i];
   uint32_t inc = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -93,17 +109,11 @@ __global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gs
   for (int i = 0; i < per; ++i) {
     const int t = t0 + i;
     if (t >= T) break;
-    uint32_t acc = start;
-#pragma unroll
-    for (int g = 0; g < kGroups; ++g) {
-      const uint32_t v = gsum[(size_t)g * T + t];
-      gsum[(size_t)g * T + t] = acc;
-      acc += v;
-    }
-    const uint32_t tot = acc - start;
+    const uint32_t tot = totals[t];
+    base[t] = start;
     ranges[t * 2 + 0] = tot ? start : 0u;          // empty tiles read (0, 0), as after identifyTileRanges
-    ranges[t * 2 + 1] = tot ? acc : 0u;
-    start = acc;
+    ranges[t * 2 + 1] = tot ? start + tot : 0u;
+    start += tot;
   }
 }
 
@@ -116,12 +126,13 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
                                                                 const uint32_t* __restrict__ n_dev, int T, uint32_t chunk,
                                                                 int cpg, const uint32_t* __restrict__ table,
                                                                 const uint32_t* __restrict__ gbase,
+                                                                const uint32_t* __restrict__ tbase,
                                                                 uint32_t* __restrict__ vals_out) {
   extern __shared__ uint32_t h[];
   const uint32_t* row = table + (size_t)blockIdx.x * T;
   const uint32_t* grow = gbase + (size_t)(blockIdx.x / cpg) * T;
   if (CURSOR) {
-    for (int t = threadIdx.x; t < T; t += kTbThreads) h[t] = grow[t] + row[t];
+    for (int t = threadIdx.x; t < T; t += kTbThreads) h[t] = tbase[t] + grow[t] + row[t];
   } else {
     const int words = (T + 1) >> 1;
     for (int w = threadIdx.x; w < words; w += kTbThreads) h[w] = 0u;
@@ -138,7 +149,7 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
     } else {
       const uint32_t sh = (t & 1u) * 16u;
       const uint32_t r = (atomicAdd(&h[t >> 1], 1u << sh) >> sh) & 0xffffu;
-      vals_out[grow[t] + row[t] + r] = gid;
+      vals_out[tbase[t] + grow[t] + row[t] + r] = gid;
     }
   }
 }
@@ -153,7 +164,7 @@ size_t tile_bin_tmp_bytes(uint32_t L, int32_t T) {
   if (!tile_bin_supported(T)) return 0;
   const uint32_t chunk = tb_chunk(T);
   const size_t nchunks = ((size_t)(L ? L : 1) + chunk - 1) / chunk;
-  return align_up(nchunks * T * 4) + align_up((size_t)kGroups * T * 4) + kAlign;
+  return align_up(nchunks * T * 4) + align_up((size_t)kGroups * T * 4) + 2 * align_up((size_t)T * 4) + kAlign;
 }
 
 // keys / vals: the emitted (tile id, Gaussian id) instances; vals_out: ids grouped by tile (unordered inside a tile);
@@ -166,6 +177,8 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
   char* c = static_cast<char*>(tmp);
   uint32_t* table = carve<uint32_t>(c, (size_t)nchunks * T);
   uint32_t* gsum = carve<uint32_t>(c, (size_t)kGroups * T);
+  uint32_t* totals = carve<uint32_t>(c, (size_t)T);
+  uint32_t* tbase = carve<uint32_t>(c, (size_t)T);
   const size_t lds = (size_t)((T + 1) / 2) * 4;
   static bool attr_set = false;
   if (!attr_set) {   // up to 64 KiB of dynamic LDS at 4K
@@ -177,19 +190,20 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
     attr_set = true;
   }
-  hipLaunchKernelGGL(tb_count_kernel, dim3(nchunks), dim3(kTbThreads), lds, s, keys, L_cap, L_dev, T, chunk, table);
+  hipLaunchKernelGGL(tb_count_kernel, dim3(nchunks), dim3(kTbThreads), lds, s, keys, L_cap, L_dev, T, chunk, table, totals);
   HGS_LAUNCH_CHECK("tile_bin_count", s, debug);
   hipLaunchKernelGGL(tb_colscan_kernel, dim3((T + kTbThreads - 1) / kTbThreads, kGroups), dim3(kTbThreads), 0, s, table,
-                     nchunks, cpg, T, gsum);
+                     nchunks, cpg, T, gsum, totals);
   HGS_LAUNCH_CHECK("tile_bin_colscan", s, debug);
-  hipLaunchKernelGGL(tb_base_kernel, dim3(1), dim3(1024), 0, s, gsum, T, (T + 1023) / 1024, ranges, big);
+  hipLaunchKernelGGL(tb_base_kernel, dim3(1 + (T + 1023) / 1024), dim3(1024), 0, s, gsum, totals, T, (T + 1023) / 1024, tbase,
+                     ranges, big);
   HGS_LAUNCH_CHECK("tile_bin_base", s, debug);
   if (T <= 16384)
     hipLaunchKernelGGL(tb_scatter_kernel<true>, dim3(nchunks), dim3(kTbThreads), (size_t)T * 4, s, keys, vals, L_cap, L_dev,
-                       T, chunk, cpg, table, gsum, vals_out);
+                       T, chunk, cpg, table, gsum, tbase, vals_out);
   else
     hipLaunchKernelGGL(tb_scatter_kernel<false>, dim3(nchunks), dim3(kTbThreads), lds, s, keys, vals, L_cap, L_dev, T, chunk,
-                       cpg, table, gsum, vals_out);
+                       cpg, table, gsum, tbase, vals_out);
   HGS_LAUNCH_CHECK("tile_bin_scatter", s, debug);
   return HGS_OK;
 }
