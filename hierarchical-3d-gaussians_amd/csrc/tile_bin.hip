@@ -18,6 +18,7 @@ namespace {
 
 constexpr int kTbThreads = 256;
 constexpr int kGroups = 16;
+constexpr int kTbStage = 8192;   // tiles whose totals the base kernel stages in LDS (1080p: 8160)
 
 __device__ __forceinline__ uint32_t tb_n(uint32_t n_cap, const uint32_t* __restrict__ n_dev) {
   return n_dev ? min(*n_dev, n_cap) : n_cap;
@@ -90,12 +91,18 @@ __global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gs
     return;
   }
   __shared__ uint32_t wave_tot[16];
+  __shared__ uint32_t tot_s[kTbStage];     // totals, then range starts (coalesced global access on both sides)
   const int lane = tid & 63, wave = tid >> 6;
   if (tid == 0) { big[0] = 0; big[1] = 0; big[2] = 0; }
   const int t0 = tid * per;
+  const bool staged = T <= kTbStage;
+  if (staged) {
+    for (int t = tid; t < T; t += 1024) tot_s[t] = totals[t];
+    __syncthreads();
+  }
   uint32_t mine = 0;
   for (int i = 0; i < per; ++i)
-    if (t0 + i < T) mine += totals[t0 + i];
+    if (t0 + i < T) mine += staged ? tot_s[t0 + i] : totals[t0 + i];
   uint32_t inc = mine;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) {
@@ -106,12 +113,28 @@ __global__ __launch_bounds__(1024) void tb_base_kernel(uint32_t* __restrict__ gs
   __syncthreads();
   uint32_t start = inc - mine;
   for (int w = 0; w < wave; ++w) start += wave_tot[w];
+  if (staged) {
+    for (int i = 0; i < per; ++i) {
+      const int t = t0 + i;
+      if (t >= T) break;
+      const uint32_t tot = tot_s[t];
+      tot_s[t] = start;
+      start += tot;
+    }
+    __syncthreads();
+    for (int t = tid; t < T; t += 1024) {
+      const uint32_t st = tot_s[t], tot = totals[t];
+      base[t] = st;
+      reinterpret_cast<uint2*>(ranges)[t] = tot ? make_uint2(st, st + tot) : make_uint2(0u, 0u);   // empty tiles read
+    }                                                                                              // (0, 0), as after
+    return;                                                                                        // identifyTileRanges
+  }
   for (int i = 0; i < per; ++i) {
     const int t = t0 + i;
     if (t >= T) break;
     const uint32_t tot = totals[t];
     base[t] = start;
-    ranges[t * 2 + 0] = tot ? start : 0u;          // empty tiles read (0, 0), as after identifyTileRanges
+    ranges[t * 2 + 0] = tot ? start : 0u;
     ranges[t * 2 + 1] = tot ? start + tot : 0u;
     start += tot;
   }
