@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered (fwd+bwd) per rank between two gradient all-reduces")
+    ap.add_argument("--no-deferred-sh", action="store_true",
+                    help="per-view SH backward (accumulating) instead of one batched pass per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="L",
@@ -169,6 +171,10 @@ def main():
     dgr._RasterizeGaussians.grad_buffers = bucket.views
     info = {"L": 0, "V": 0}
 
+    # k > 1: the SH part of the k backwards (81 % of the gradient bytes) is left pending and done for all k views in one
+    # pass over the coefficients at the end of the step (hgs_raster_sh_bwd_batched)
+    dgr._RasterizeGaussians.defer_sh_backward = k > 1 and not args.no_deferred_sh
+
     def step():
         for j, rast in enumerate(rasts):
             dgr._RasterizeGaussians.grad_accumulate = j > 0
@@ -178,6 +184,8 @@ def main():
             info["L"] = color.grad_fn.num_rendered
             info["radii"] = radii
             torch.autograd.grad([color, invd], [params[kk] for kk in params] + [means2D], [gc, gd])
+        if dgr._RasterizeGaussians.defer_sh_backward:
+            dgr.finish_deferred_sh_backward()
         if world > 1:
             bucket.all_reduce()
 
@@ -236,6 +244,7 @@ def main():
                        "gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H,
                        "views_per_step_per_gpu": k,
                        "parallelism": f"per-view dp{world}, {k} views per rank per step accumulated in place" +
+                                      (", SH backward batched over the views" if dgr._RasterizeGaussians.defer_sh_backward else "") +
                                       (", one RCCL all-reduce of the 59P-float grad bucket per step" if world > 1 else ""),
                        "render_variant": args.variant},
             "algorithmic_bytes_per_frame": total_bytes,

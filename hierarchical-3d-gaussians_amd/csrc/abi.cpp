@@ -130,6 +130,7 @@ static int validate(const hgs_raster_args* a) {
     }
     // the SH blocks and the quaternions are moved with 16-byte accesses
     if (((uintptr_t)a->shs | (uintptr_t)a->shs_rest | (uintptr_t)a->rotations) & 15u) { set_error("shs / shs_rest / rotations must be 16-byte aligned"); return HGS_ERR_INVALID; }
+    if (a->defer_sh_bwd && a->shs_rest) { set_error("defer_sh_bwd is not available with split SH storage (shs_rest)"); return HGS_ERR_INVALID; }
     if (a->shs_rest && (!a->shs || a->M < 2)) { set_error("shs_rest needs shs (features_dc) and M >= 2"); return HGS_ERR_INVALID; }
     if ((a->activations & HGS_ACT_OPACITY_SIGMOID) && (a->activations & HGS_ACT_OPACITY_ABS)) { set_error("choose one opacity activation"); return HGS_ERR_INVALID; }
     if ((a->activations & (HGS_ACT_SCALE_EXP | HGS_ACT_ROT_NORMALIZE)) && a->cov3D_precomp) { set_error("scale / rotation activations need scales and rotations"); return HGS_ERR_INVALID; }
@@ -280,7 +281,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   const BinWs b = BinWs::carve_from(const_cast<void*>(bin_ws), L, T);
   const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), a->width, a->height);
   float* inst = static_cast<float*>(bwd_ws);
-  float* drgb = reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + align_up((size_t)(L ? L : 1) * kInstStride * 4));
+  float* drgb = bwd_ws_drgb(bwd_ws, L);
   if (L > 0) {
     if (a->bwd_ws_prezero != bwd_ws) {   // else: zero-filled by the forward's compositing kernel
       StageTimer _t(ST_MEMSET_BWD, s);
@@ -295,6 +296,29 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   if (!a->scales) { gr.dL_dscales = nullptr; gr.dL_drotations = nullptr; }
   if (!a->cov3D_precomp) gr.dL_dcov3D = nullptr;
   return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, gr, s));
+}
+
+int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
+                              const float* means3D, const float* shs, float* dL_dshs, float* dL_dmeans3D,
+                              int32_t accumulate, hgs_stream_t stream, int device) {
+  if (n_views <= 0 || P <= 0) return HGS_OK;
+  if (!views || n_views > HGS_MAX_DEFERRED_VIEWS) { set_error("1..%d deferred views per call", HGS_MAX_DEFERRED_VIEWS); return HGS_ERR_INVALID; }
+  if (!means3D || !shs || !dL_dshs || !dL_dmeans3D) { set_error("null argument"); return HGS_ERR_INVALID; }
+  if (sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) { set_error("M=%d incompatible with sh_degree=%d", M, sh_degree); return HGS_ERR_INVALID; }
+  if (((uintptr_t)shs | (uintptr_t)dL_dshs) & 15u) { set_error("shs / dL_dshs must be 16-byte aligned"); return HGS_ERR_INVALID; }
+  ShBwdViews v;
+  v.n = n_views;
+  for (int i = 0; i < HGS_MAX_DEFERRED_VIEWS; ++i) {
+    const hgs_sh_bwd_view& w = views[i < n_views ? i : 0];
+    if (!w.geom_ws || !w.bwd_ws || !w.campos) { set_error("deferred view %d has a null pointer", i); return HGS_ERR_INVALID; }
+    v.tiles_touched[i] = GeomWs::carve_from(const_cast<void*>(w.geom_ws), P).tiles_touched;
+    v.drgb[i] = bwd_ws_drgb(const_cast<void*>(w.bwd_ws), w.L);
+    v.campos[i] = w.campos;
+  }
+  HGS_HIP(hipSetDevice(device));
+  return HGS_TIMED(ST_PREPROCESS_BWD, static_cast<hipStream_t>(stream),
+                   launch_sh_bwd_batched(v, P, M, sh_degree, means3D, shs, dL_dshs, dL_dmeans3D, accumulate != 0,
+                                         static_cast<hipStream_t>(stream)));
 }
 
 int hgs_raster_views_get(int32_t P, int32_t width, int32_t height, uint32_t L, const void* geom_ws,

@@ -105,6 +105,18 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           const hgs_raster_grads& out, hipStream_t s);
+struct ShBwdViews {          // device pointers of the deferred views (hgs_raster_sh_bwd_batched)
+  const uint32_t* tiles_touched[HGS_MAX_DEFERRED_VIEWS];
+  const float* drgb[HGS_MAX_DEFERRED_VIEWS];
+  const float* campos[HGS_MAX_DEFERRED_VIEWS];
+  int n;
+};
+int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
+                          const float* shs, float* dL_dshs, float* dL_dmeans3D, bool accumulate, hipStream_t s);
+// the per-Gaussian colour gradients sit behind the instance gradients in the backward scratch
+inline float* bwd_ws_drgb(void* bwd_ws, uint32_t L) {
+  return reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + align_up((size_t)(L ? L : 1) * kInstStride * 4));
+}
 // tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
 bool tile_bin_supported(int32_t T);
 size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);

@@ -687,7 +687,122 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   }
 }
 
+// K8b for several views of the same Gaussians at once (hgs_raster_sh_bwd_batched): the SH block is read once and
+// the gradient block written once for all views -- per view this kernel's traffic is otherwise the largest of the
+// streaming kernels (384 B per Gaussian).
+template <bool ACC, bool COOP>   // COOP: 3M % 4 == 0, the SH block goes through LDS; else per-lane access
+__global__ __launch_bounds__(kPreBlock) void sh_bwd_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
+                                                                   const float* __restrict__ means3D,
+                                                                   const float* __restrict__ shs,
+                                                                   float* __restrict__ dL_dshs,
+                                                                   float* __restrict__ dL_dmeans3D) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int n = M * 3;
+  constexpr bool coop = COOP;
+  const int block_first = blockIdx.x * kPreBlock;
+  const int idx = block_first + threadIdx.x;
+  const bool valid = idx < P;
+  if (coop) {
+    coop_load_sh(shs, block_first, P, n, lds);
+    __syncthreads();
+  }
+  // the coefficients stay in this lane's LDS row and are re-read per view (keeping them in registers next to the
+  // 48 accumulators and the basis arrays costs a wave of occupancy)
+  float sh_reg[COOP ? 1 : 48];
+  if constexpr (!COOP) { if (valid) load_sh(shs, idx, M, sh_reg); }
+  float dsh[48];
+#pragma unroll
+  for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
+  float gm0 = 0.f, gm1 = 0.f, gm2 = 0.f;
+  if (valid) {
+    const float px = means3D[idx * 3 + 0], py = means3D[idx * 3 + 1], pz = means3D[idx * 3 + 2];
+    const int nb = (sh_degree + 1) * (sh_degree + 1);
+    for (int w = 0; w < v.n; ++w) {
+      if (v.tiles_touched[w][idx] == 0) continue;
+      const float gr0 = v.drgb[w][idx * 3 + 0], gr1 = v.drgb[w][idx * 3 + 1], gr2 = v.drgb[w][idx * 3 + 2];
+      // dotc[k] = gr . c_k straight from the LDS row (or the registers of the per-lane path): no 48-float copy
+      float dotc[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) dotc[k] = 0.f;
+      if constexpr (COOP) {
+        const float4* row4 = reinterpret_cast<const float4*>(lds + threadIdx.x * sh_row_stride(n));
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          if (i * 4 < n) {
+            const float4 t = row4[i];
+            const float tv[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const int ch = (i * 4 + c) % 3;
+              dotc[(i * 4 + c) / 3] += (ch == 0 ? gr0 : ch == 1 ? gr1 : gr2) * tv[c];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 48; ++i) dotc[i / 3] += (i % 3 == 0 ? gr0 : i % 3 == 1 ? gr1 : gr2) * sh_reg[i];
+      }
+      const float dx = px - v.campos[w][0], dy = py - v.campos[w][1], dz = pz - v.campos[w][2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+      {
+        float b[16];
+        sh_basis(sh_degree, ux, uy, uz, b);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nb) { dsh[k * 3 + 0] += b[k] * gr0; dsh[k * 3 + 1] += b[k] * gr1; dsh[k * 3 + 2] += b[k] * gr2; }
+        }
+      }
+      float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+      {
+        float dbx[16], dby[16], dbz[16];
+        sh_basis_grad(sh_degree, ux, uy, uz, dbx, dby, dbz);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nb) { gdx += dbx[k] * dotc[k]; gdy += dby[k] * dotc[k]; gdz += dbz[k] * dotc[k]; }
+        }
+      }
+      const float dot = ux * gdx + uy * gdy + uz * gdz;
+      gm0 += (gdx - ux * dot) * inv;
+      gm1 += (gdy - uy * dot) * inv;
+      gm2 += (gdz - uz * dot) * inv;
+    }
+    dL_dmeans3D[idx * 3 + 0] += gm0;
+    dL_dmeans3D[idx * 3 + 1] += gm1;
+    dL_dmeans3D[idx * 3 + 2] += gm2;
+  }
+  if (coop) {
+    __syncthreads();            // every lane is done reading its coefficients: the buffer becomes the output stage
+    if (valid) lds_row_write(lds, n, dsh);
+    __syncthreads();
+    coop_store_sh<ACC>(dL_dshs, block_first, P, n, lds);
+  } else if (valid) {
+    if (ACC) {
+      const float* old = dL_dshs + (size_t)idx * n;
+#pragma unroll
+      for (int i = 0; i < 48; ++i)
+        if (i < n) dsh[i] += old[i];
+    }
+    store_sh(dL_dshs, idx, M, dsh);
+  }
+}
+
 }  // namespace
+
+int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
+                          const float* shs, float* dL_dshs, float* dL_dmeans3D, bool accumulate, hipStream_t s) {
+  const int nblk = (P + kPreBlock - 1) / kPreBlock;
+  if (nblk <= 0) return HGS_OK;
+  const size_t lds_bytes = (size_t)kPreBlock * (M * 3 + 4) * sizeof(float);
+  const bool coop = ((M * 3) & 3) == 0;
+  auto kern = coop ? (accumulate ? sh_bwd_batched_kernel<true, true> : sh_bwd_batched_kernel<false, true>)
+                   : (accumulate ? sh_bwd_batched_kernel<true, false> : sh_bwd_batched_kernel<false, false>);
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(kPreBlock), lds_bytes, s, v, P, M, sh_degree, means3D, shs, dL_dshs,
+                     dL_dmeans3D);
+  HGS_LAUNCH_CHECK("sh_bwd_batched", s, false);
+  return HGS_OK;
+}
 
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
@@ -713,7 +828,7 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
     auto k8a = a.accumulate_grads ? preprocess_bwd_kernel<true> : preprocess_bwd_kernel<false>;
     hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
-    if (a.shs && out.dL_dshs) {
+    if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
       auto k8b = a.accumulate_grads ? sh_bwd_kernel<true> : sh_bwd_kernel<false>;
       hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);

@@ -58,7 +58,7 @@ def _lod(weights, kids, P):
 class _Call:
     """Everything one forward needs to hand back to the backward.  ``L`` = instances rendered; ``L_ws`` = the
     instance capacity the binning workspace was carved with (== L on the two-stage path)."""
-    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device", "scratch")
+    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device", "scratch", "deferred")
 
 
 # Instance count of the previous forward per device: lets the next forward size its binning workspace
@@ -195,16 +195,20 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
     call.scratch = scratch
+    call.deferred = None
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
-def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False):
+def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False,
+                                 defer_sh=False):
     """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
     dL_dscales, dL_drotations) -- plus dL_dsh_rest as a 9th entry for a forward with split SH storage; entries
     for absent inputs are None.  ``out``: optional dict of
     preallocated float32 GPU tensors (keys means3D, shs, colors_precomp, opacities, scales, rotations,
     cov3D_precomp) the gradients are written into -- e.g. the views of a data-parallel flat bucket;
-    ``accumulate``: add to their contents (gradient accumulation over the views of one optimizer step)."""
+    ``accumulate``: add to their contents (gradient accumulation over the views of one optimizer step).
+    ``defer_sh``: leave dL_dsh (and the view-direction part of dL_dmeans3D) to a later ``sh_backward_batched`` call
+    over several views; ``call.deferred`` then holds what that call needs."""
     lib = _lib.lib()
     a, P, dev = call.args, call.P, call.device
     f32 = dict(dtype=torch.float32, device=dev)
@@ -237,6 +241,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     g.dL_dopacity, g.dL_dscales, g.dL_drotations, g.dL_dcov3D = p(d_op), p(d_sc), p(d_rot), p(d_cov)
     g.dL_dshs_rest = p(d_shr)
     a.accumulate_grads = int(bool(accumulate and out is not None))
+    a.defer_sh_bwd = int(bool(defer_sh and sh is not None and sh_rest is None))
     scratch = call.scratch           # allocated and zero-filled by the forward (prepare_backward), single use
     call.scratch = None
     if scratch is None:
@@ -249,9 +254,40 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),
                                   dev.index or 0), "hgs_raster_bwd")
+    call.deferred = (scratch, d_sh, d_m3) if a.defer_sh_bwd else None
     if sh_rest is not None:
         return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot, d_shr
     return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot
+
+
+def sh_backward_batched(calls, accumulate=False):
+    """Finish the SH part of the backward of several views (``defer_sh=True``) in one pass over the coefficients.
+    All views must share means3D / shs and their gradient buffers (``out=`` of the backward).  dL_dsh = (accumulate ?
+    dL_dsh : 0) + sum over the views; dL_dmeans3D += the views' view-direction terms."""
+    if not calls:
+        return
+    lib = _lib.lib()
+    first = calls[0]
+    means3D, sh = first.keep[4], first.keep[5]
+    _, d_sh, d_m3 = first.deferred
+    for c in calls:
+        if c.deferred is None:
+            raise RuntimeError("sh_backward_batched needs calls whose backward ran with defer_sh=True")
+        if c.keep[4].data_ptr() != means3D.data_ptr() or c.keep[5].data_ptr() != sh.data_ptr() or \
+                c.deferred[1].data_ptr() != d_sh.data_ptr() or c.deferred[2].data_ptr() != d_m3.data_ptr():
+            raise RuntimeError("deferred views must share means3D / shs and their gradient buffers")
+    dev = first.device
+    for i in range(0, len(calls), _lib.MAX_DEFERRED_VIEWS):
+        chunk = calls[i:i + _lib.MAX_DEFERRED_VIEWS]
+        arr = (_lib.ShBwdView * len(chunk))()
+        for v, c in zip(arr, chunk):
+            v.geom_ws, v.bwd_ws, v.campos, v.L = c.geom.data_ptr(), c.deferred[0].data_ptr(), c.keep[3].data_ptr(), c.L_ws
+        _lib.check(lib.hgs_raster_sh_bwd_batched(arr, len(chunk), first.P, first.args.M, first.args.sh_degree,
+                                                 _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(d_sh), _lib.ptr(d_m3),
+                                                 int(bool(accumulate or i > 0)), _stream(dev), dev.index or 0),
+                   "hgs_raster_sh_bwd_batched")
+    for c in calls:
+        c.deferred = None
 
 
 def raster_views(call):

@@ -51,6 +51,11 @@ class _RasterizeGaussians(torch.autograd.Function):
     # the Gaussian parameters straight into these buffers (hgs.dp.GradBucket views) instead of fresh tensors.
     grad_buffers = None
     grad_accumulate = False   # with grad_buffers: add to the buffers (accumulation over several views)
+    # With grad_buffers: leave the SH part of every backward (dL_dshs, 81 % of the gradient bytes, and the view-direction
+    # term of dL_dmeans3D) pending; finish_deferred_sh_backward() then does it for all pending views in ONE pass over
+    # the coefficients.  Until then the shs / means3D gradient buffers are incomplete.
+    defer_sh_backward = False
+    pending_sh = []
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -75,9 +80,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         call = ctx.call
         if grad_color is None:
             grad_color = torch.zeros_like(color)
+        cls = _RasterizeGaussians
+        defer = bool(cls.defer_sh_backward and cls.grad_buffers is not None)
         d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(
-            call, color, invdepth, grad_color, grad_invdepth, out=_RasterizeGaussians.grad_buffers,
-            accumulate=_RasterizeGaussians.grad_accumulate)
+            call, color, invdepth, grad_color, grad_invdepth, out=cls.grad_buffers,
+            accumulate=cls.grad_accumulate, defer_sh=defer)
+        if getattr(call, "deferred", None) is not None:
+            cls.pending_sh.append(call)
         ctx.call = None
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
         return d_m3, d_m2, d_sh, d_col, d_op, d_sc, d_rot, d_cov, None
@@ -117,6 +126,14 @@ class _RasterizeGaussiansRaw(torch.autograd.Function):
         d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = res[:8]
         d_rest = res[8] if ctx.split else None
         return d_m3, d_m2, d_sh, d_rest, d_op, d_sc, d_rot, None, None
+
+
+def finish_deferred_sh_backward(accumulate=False):
+    """Complete the backward of every view rendered since the last call with ``_RasterizeGaussians.defer_sh_backward``
+    set: one pass over the SH coefficients for all of them (hgs_raster_sh_bwd_batched).  ``accumulate``: add to what
+    the shs gradient buffer already holds instead of overwriting it."""
+    pending, _RasterizeGaussians.pending_sh = _RasterizeGaussians.pending_sh, []
+    _C.sh_backward_batched(pending, accumulate=accumulate)
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
@@ -199,4 +216,4 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "_C"]
+           "finish_deferred_sh_backward", "_C"]

@@ -27,7 +27,7 @@ class RasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
-        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("reserved", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
     ]
 
 
@@ -51,6 +51,14 @@ class HierHost(C.Structure):
                 ("xyz", C.c_void_p), ("shs", C.c_void_p), ("alpha", C.c_void_p),
                 ("log_scales", C.c_void_p), ("rots", C.c_void_p), ("nodes", C.c_void_p),
                 ("boxes", C.c_void_p)]
+
+
+class ShBwdView(C.Structure):
+    _fields_ = [("geom_ws", C.c_void_p), ("bwd_ws", C.c_void_p), ("campos", C.c_void_p), ("L", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+MAX_DEFERRED_VIEWS = 8
 
 
 class AdamTensor(C.Structure):
@@ -93,6 +101,8 @@ SIGNATURES = {
     "hgs_lod_gather": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
     "hgs_lod_gather_bwd": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, C.c_int]),
+    "hgs_raster_sh_bwd_batched": (C.c_int, [C.POINTER(ShBwdView), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
+                                            _P, _P, C.c_int32, _P, C.c_int]),
     "hgs_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_int64, _P, C.c_int64, _P, _P, C.c_int]),
     "hgs_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "hgs_dist2_knn3": (C.c_int, [_P, C.c_int32, _P, _P, _P, C.c_int]),

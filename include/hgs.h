@@ -92,7 +92,8 @@ typedef struct hgs_raster_args {
   const float* shs_rest;    /* NULL: shs is [P,M,3].  Else shs = features_dc [P,1,3], shs_rest = features_rest
                              * [P,M-1,3] (the two tensors get_features concatenates, scene/gaussian_model.py:121-124) */
   int32_t activations;      /* OR of HGS_ACT_*; 0 = inputs are already activated (the reference's call) */
-  int32_t reserved;
+  int32_t defer_sh_bwd;     /* backward: skip the SH part (dL_dshs and the view-direction term of dL_dmeans3D); the
+                             * caller finishes it for several views at once with hgs_raster_sh_bwd_batched */
   /* Optional: the bwd_ws buffer the matching hgs_raster_bwd call will receive (bwd_bytes of hgs_raster_ws_sizes
    * for the same L).  The forward then zero-fills its instance-gradient part from inside the compositing kernel --
    * that kernel is ALU-bound and leaves HBM idle, so the 48 B per instance of zeroes cost nothing there -- and the
@@ -157,6 +158,23 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
                    const float* out_color, const float* out_invdepth,
                    const float* dL_dcolor, const float* dL_dinvdepth,
                    const hgs_raster_grads* grads, hgs_stream_t stream, int device);
+
+/* SH part of the backward for up to HGS_MAX_DEFERRED_VIEWS views of the SAME Gaussians in one pass (gradient
+ * accumulation over the views of one optimiser step / of one data-parallel rank): the [P,M,3] coefficients are read
+ * once and dL_dshs is written once, instead of once per view.  Each view ran hgs_raster_bwd with
+ * args.defer_sh_bwd = 1; its geom_ws and bwd_ws (the per-Gaussian colour gradients live there) must still be intact.
+ * dL_dshs = (accumulate ? dL_dshs : 0) + sum over the views; dL_dmeans3D += the views' view-direction terms. */
+#define HGS_MAX_DEFERRED_VIEWS 8
+typedef struct hgs_sh_bwd_view {
+  const void* geom_ws;
+  const void* bwd_ws;
+  const float* campos; /* device [3] */
+  uint32_t L;          /* the L the view's hgs_raster_bwd was called with */
+  uint32_t reserved;
+} hgs_sh_bwd_view;
+int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
+                              const float* means3D, const float* shs, float* dL_dshs, float* dL_dmeans3D,
+                              int32_t accumulate, hgs_stream_t stream, int device);
 
 /* Introspection for the parity tests ("bit-exact on tile/sort indices"):
  * device pointers into the workspaces after stage 2. */

@@ -458,3 +458,45 @@ def test_huge_tile_grid_takes_the_radix_path(gpu):
         assert np.array_equal(v["tile_ids_sorted"].cpu().numpy().astype(np.uint64),
                               binning.keys_sorted >> np.uint64(32))
         assert torch.isfinite(color).all() and float(color.max()) > 0.05
+
+
+def test_deferred_batched_sh_backward(gpu):
+    """Gradient accumulation over several views with the SH part of the backward deferred and done in ONE pass
+    (hgs_raster_sh_bwd_batched) must equal the sum of the views' separately computed gradients -- for every input,
+    since the view-direction term of dL_dmeans3D moves into the batched pass as well."""
+    import diff_gaussian_rasterization as dgr
+    from hgs import dp
+    W, H, P, K = 176, 112, 1500, 3
+    base = synth.make_camera(W, H)
+    scene = synth.make_scene(P, base, seed=7)
+    cams = [synth.orbit_camera(W, H, j, K, radius=0.4) for j in range(K)]
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.zeros(3)
+    sep = [pa.run_hip(scene, c, bg, gc, gd, gpu)["grads"] for c in cams]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    sc = scene.to(gpu)
+    params = {n: getattr(sc, n).clone().requires_grad_(True) for n in names}
+    bucket = dp.GradBucket({n: tuple(v.shape) for n, v in params.items()}, gpu)
+    bucket.flat.fill_(float("nan"))               # stale contents must not survive
+    cls = dgr._RasterizeGaussians
+    cls.grad_buffers, cls.defer_sh_backward = bucket.views, True
+    try:
+        for j, c in enumerate(cams):
+            cls.grad_accumulate = j > 0
+            rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(c, bg, 3, device=gpu))
+            m2 = torch.zeros(P, 3, device=gpu, requires_grad=True)
+            color, radii, invd = dgr.GaussianRasterizer(rs)(
+                means3D=params["means3D"], means2D=m2, shs=params["shs"], opacities=params["opacities"],
+                scales=params["scales"], rotations=params["rotations"])
+            torch.autograd.grad([color, invd], [params[n] for n in names] + [m2], [gc.to(gpu), gd.to(gpu)])
+        assert len(cls.pending_sh) == K
+        dgr.finish_deferred_sh_backward()
+        assert len(cls.pending_sh) == 0
+    finally:
+        cls.grad_buffers, cls.grad_accumulate, cls.defer_sh_backward, cls.pending_sh = None, False, False, []
+    for n in names:
+        want = sum(s[n] for s in sep)
+        got = bucket.views[n].cpu()
+        assert torch.isfinite(got).all(), n
+        assert torch.allclose(got, want, rtol=1e-5, atol=2e-6 * float(want.abs().max())), \
+            (n, float((got - want).abs().max()), float(want.abs().max()))

@@ -49,7 +49,8 @@ class _OracleC:
         return out.binning.num_rendered, out.color.detach().float(), out.radii.clone(), None, None, None, invd, call
 
     @staticmethod
-    def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False):
+    def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False,
+                                     defer_sh=False):
         with torch.enable_grad():
             loss = (call.out.color * dL_dcolor.double()).sum()
             if call.do_depth and dL_dinvdepth is not None:
