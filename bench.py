@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DOMINANT = "render_bwd"  # the kernel the roofline object describes (largest share of the frame, profiles/)
 
 
-def algorithmic_bytes(P, V, L, N, T, M, depth=True):
+def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False):
     """SURVEY.md §8(d) byte model, per stage, for the measured P (Gaussians), V (visible), L (tile
     instances), N (pixels), T (tiles), M (SH coefficients).  Each boundary tensor is counted once
     read / once written; irreducible intermediates once written + once read; the sort as one pass."""
@@ -52,6 +52,11 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True):
     b["memset_bwd"] = inst * L
     b["render_bwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N * 2 + inst * L
     b["preprocess_bwd"] = inst * L + P * 44 + V * 12 * M + 12 * P + P * (56 + 12 * M)
+    b["memset_bwd"] = 0                          # the forward's compositing kernel clears the scratch on the side
+    if deferred_sh:
+        # per view: geometry chain only (SH neither read nor written); per STEP: one pass over the coefficients
+        b["preprocess_bwd"] = inst * L + P * 44 + 12 * P + P * 56 + 12 * P
+        b["sh_bwd_batched"] = P * 12 * M * 2 + k * (16 * P) + 24 * P
     return b
 
 
@@ -232,8 +237,10 @@ def main():
         L = int(info["L"])
         V = int((info["radii"] > 0).sum().item())
         N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), scene.shs.shape[1]
-        ab = algorithmic_bytes(P, V, L, N, T, M)
-        total_bytes = sum(ab.values())
+        deferred = bool(dgr._RasterizeGaussians.defer_sh_backward)
+        ab = algorithmic_bytes(P, V, L, N, T, M, k=k, deferred_sh=deferred)
+        # per frame: the batched SH pass runs once per step of k views
+        total_bytes = sum(v for kk_, v in ab.items() if kk_ != "sh_bwd_batched") + ab.get("sh_bwd_batched", 0) / k
         result = {
             "metric": "fwd+bwd frames/s @1080p, 1M Gaussians", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -11,10 +11,10 @@ namespace hgs {
 
 // ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
 enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SORT_DEPTH, ST_RENDER_FWD,
-             ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_COUNT };
+             ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_BATCHED, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "tile_sort", "tile_ranges",
                                             "tile_depth_sort", "render_fwd", "memset_bwd", "render_bwd",
-                                            "preprocess_bwd"};
+                                            "preprocess_bwd", "sh_bwd_batched"};
 struct Pending { int stage; hipEvent_t a, b; };
 static uint32_t g_timing = 0;      // bit 0: every stage; bit (1 + stage): that stage only
 static std::mutex g_tmu;
@@ -316,7 +316,7 @@ int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int
     v.campos[i] = w.campos;
   }
   HGS_HIP(hipSetDevice(device));
-  return HGS_TIMED(ST_PREPROCESS_BWD, static_cast<hipStream_t>(stream),
+  return HGS_TIMED(ST_SH_BATCHED, static_cast<hipStream_t>(stream),
                    launch_sh_bwd_batched(v, P, M, sh_degree, means3D, shs, dL_dshs, dL_dmeans3D, accumulate != 0,
                                          static_cast<hipStream_t>(stream)));
 }
