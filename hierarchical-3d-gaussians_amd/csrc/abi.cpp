@@ -184,24 +184,9 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 
 // Stage-2 launches.  L is exact when L_dev == nullptr; otherwise it is a capacity and the kernels read the
 // actual instance count from device memory.
-// The fused tile binning works straight from K1's rectangles (no instance arrays); variant 5 = unfused, for A/B runs.
-static bool use_fused_binning(const hgs_raster_args* a, uint32_t L, int T) {
-  return L > 0 && a->variant != 5 && tile_bin_fused_supported(T);
-}
-
 static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
-                          const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s,
-                          bool sums_scanned = true, bool fused_count_done = false) {
+                          const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
   int rc;
-  if (use_fused_binning(a, L, T)) {
-    if (!fused_count_done &&
-        (rc = HGS_TIMED(ST_DUPLICATE, s, launch_tile_bin_fused(*a, g, b.vals_out, b.sort_tmp, L, sums_scanned, T, b.ranges, b.big_tiles, 0, s)))) return rc;
-    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin_fused(*a, g, b.vals_out, b.sort_tmp, L, sums_scanned, T, b.ranges, b.big_tiles, 1, s)))) return rc;
-    if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, true, s)))) return rc;
-    float* zws = static_cast<float*>(a->bwd_ws_prezero);
-    return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, zws,
-                                                         zws ? (size_t)L * kInstStride : 0, s));
-  }
   if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;   // also zeroes b.ranges
   const bool bin = L > 0 && tile_bin_supported(T);
   if (bin) {            // counting pass + scatter pass; writes the tile ranges too
@@ -250,13 +235,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   *L_out_host = 0;
   if (a->P == 0) return enqueue_stage2(a, g, b, im, 0, nullptr, T, out_color, out_invdepth, s);
   if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
-  // fused binning: its count kernel derives the emission offsets and L from K1's raw workgroup sums (no scan launch)
-  const bool fused = use_fused_binning(a, L_cap, T);
-  if (fused) {
-    if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_tile_bin_fused(*a, g, b.vals_out, b.sort_tmp, L_cap, false, T, b.ranges, b.big_tiles, 0, s)))) return rc;
-  } else {
-    if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
-  }
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   const uint32_t* L_dev = g.block_sums + nblk;
   uint32_t* stage = pinned_L();
@@ -266,7 +245,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   HGS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   hipError_t e = hipEventRecord(ev, s);
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
-  if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s, !fused, fused);
+  if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);
   if (e == hipSuccess) e = hipEventSynchronize(ev);
   (void)hipEventDestroy(ev);
   if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }

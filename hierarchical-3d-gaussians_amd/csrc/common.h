@@ -120,10 +120,6 @@ inline float* bwd_ws_drgb(void* bwd_ws, uint32_t L) {
 // tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
 bool tile_bin_supported(int32_t T);
 size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);
-bool tile_bin_fused_supported(int32_t T);
-int launch_tile_bin_fused(const hgs_raster_args& a, const GeomWs& g, uint32_t* vals_out, void* tmp, uint32_t L_cap,
-                          bool sums_scanned, int32_t T, uint32_t* ranges, uint32_t* big, int phase, hipStream_t s);
-// phase 0: the count kernel (writes the emission offsets, and L for raw sums); phase 1: scans + scatter
 int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
                     const uint32_t* L_dev, int32_t T, uint32_t* ranges, uint32_t* big, hipStream_t s, bool debug);
 size_t sort_tmp_bytes(uint32_t n);

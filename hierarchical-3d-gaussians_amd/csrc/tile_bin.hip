@@ -177,116 +177,16 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
   }
 }
 
-// ---- fused variant: the instances are never materialised -------------------------------------------------------
-// K3's expansion (tile rectangle -> instances, output slots mapped to lanes through an LDS prefix) runs twice, once
-// feeding the LDS histogram (MODE 0) and once the LDS cursors (MODE 1), over chunks of `sub` x 256 Gaussians.  No
-// (tile id, Gaussian id) arrays in HBM, no separate count kernel, and the emission offsets come from the chunk's own
-// prefix over K1's raw workgroup sums (no scan launch).  Needs 4 bytes of LDS per tile.
-constexpr int kFusedMaxTiles = 16384;
-constexpr int kFusedMaxChunks = 1024;
-
-template <int MODE>
-__global__ __launch_bounds__(kPreBlock) void tb_dup_kernel(int P, int gx, GeomWs g, int nblk, int sub, int sums_scanned,
-                                                          int T, uint32_t cap, uint32_t* __restrict__ table, int cpg,
-                                                          const uint32_t* __restrict__ gbase,
-                                                          const uint32_t* __restrict__ tbase,
-                                                          uint32_t* __restrict__ totals,
-                                                          uint32_t* __restrict__ vals_out) {
-  extern __shared__ uint32_t h[];                      // [T] counts (MODE 0) / absolute cursors (MODE 1)
-  __shared__ uint32_t excl[kPreBlock + 1];
-  __shared__ uint2 lrect[kPreBlock];
-  __shared__ uint32_t wave_tot[kPreBlock / 64];
-  __shared__ uint32_t chunk_base_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int b0 = blockIdx.x * sub, b1 = min(b0 + sub, nblk);      // K1 workgroups (256 Gaussians each) of this chunk
-  if (MODE == 0) {
-    for (int t = tid; t < T; t += kPreBlock) h[t] = 0u;
-    if (blockIdx.x == 0)
-      for (int t = tid; t < T; t += kPreBlock) totals[t] = 0u;
-  } else {
-    const uint32_t* row = table + (size_t)blockIdx.x * T;
-    const uint32_t* grow = gbase + (size_t)(blockIdx.x / cpg) * T;
-    for (int t = tid; t < T; t += kPreBlock) h[t] = tbase[t] + grow[t] + row[t];
-  }
-  // emission offset of the chunk's first instance
-  uint32_t base;
-  if (sums_scanned) {
-    base = g.block_sums[b0];
-  } else {
-    uint32_t part = 0;
-    for (int b = tid; b < b0; b += kPreBlock) part += g.block_sums[b];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off, 64);
-    if (lane == 0) wave_tot[wave] = part;
-    __syncthreads();
-    if (tid == 0) chunk_base_s = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-    base = chunk_base_s;
-  }
-  __syncthreads();
-  for (int b = b0; b < b1; ++b) {
-    const int i = b * kPreBlock + tid;
-    const uint32_t gid = (uint32_t)i;
-    const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
-    const uint32_t cnt = ((myrect.y & 0xffffu) - (myrect.x & 0xffffu)) * ((myrect.y >> 16) - (myrect.x >> 16));
-    lrect[tid] = myrect;
-    uint32_t inc = cnt;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    const uint32_t my_excl = wbase + inc - cnt;
-    excl[tid] = my_excl;
-    if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
-    if (MODE == 0 && i < P && cnt) g.offsets[gid] = base + my_excl;     // emission offset of this Gaussian's run
-    __syncthreads();
-    const uint32_t total = excl[kPreBlock];
-    for (uint32_t s = tid; s < total; s += kPreBlock) {
-      int lo = 0, hi = kPreBlock;                  // largest j with excl[j] <= s
-#pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int mid = (lo + hi) >> 1;
-        if (excl[mid] <= s) lo = mid; else hi = mid;
-      }
-      const uint32_t k = s - excl[lo];
-      const uint2 rc = lrect[lo];
-      const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
-      const uint32_t w = (rc.y & 0xffffu) - minx;
-      const uint32_t tile = (miny + k / w) * (uint32_t)gx + (minx + k % w);
-      if (MODE == 0) {
-        atomicAdd(&h[tile], 1u);
-      } else {
-        const uint32_t pos = atomicAdd(&h[tile], 1u);
-        if (pos < cap) vals_out[pos] = (uint32_t)(b * kPreBlock + lo);
-      }
-    }
-    base += total;
-    __syncthreads();
-  }
-  if (MODE == 0) {
-    uint32_t* row = table + (size_t)blockIdx.x * T;
-    for (int t = tid; t < T; t += kPreBlock) row[t] = h[t];
-    if (!sums_scanned && b1 == nblk && tid == 0) g.block_sums[nblk] = base;      // L, read by the host and by L_dev users
-  }
-}
-
 inline uint32_t tb_chunk(int T) { return T <= 12288 ? 4096u : 16384u; }
 
 }  // namespace
 
 bool tile_bin_supported(int32_t T) { return T <= 32768; }
-bool tile_bin_fused_supported(int32_t T) { return T <= kFusedMaxTiles; }
 
 size_t tile_bin_tmp_bytes(uint32_t L, int32_t T) {
   if (!tile_bin_supported(T)) return 0;
   const uint32_t chunk = tb_chunk(T);
-  size_t nchunks = ((size_t)(L ? L : 1) + chunk - 1) / chunk;
-  if (tile_bin_fused_supported(T) && nchunks < (size_t)kFusedMaxChunks) nchunks = kFusedMaxChunks;   // fused variant
+  const size_t nchunks = ((size_t)(L ? L : 1) + chunk - 1) / chunk;
   return align_up(nchunks * T * 4) + align_up((size_t)kGroups * T * 4) + 2 * align_up((size_t)T * 4) + kAlign;
 }
 
@@ -328,48 +228,6 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
     hipLaunchKernelGGL(tb_scatter_kernel<false>, dim3(nchunks), dim3(kTbThreads), lds, s, keys, vals, L_cap, L_dev, T, chunk,
                        cpg, table, gsum, tbase, vals_out);
   HGS_LAUNCH_CHECK("tile_bin_scatter", s, debug);
-  return HGS_OK;
-}
-
-// Fused variant: straight from K1's tile rectangles to ids grouped by tile.  sums_scanned: g.block_sums already hold
-// the exclusive scan (two-stage entry point); otherwise they are K1's raw workgroup sums and L is written here.
-int launch_tile_bin_fused(const hgs_raster_args& a, const GeomWs& g, uint32_t* vals_out, void* tmp, uint32_t L_cap,
-                          bool sums_scanned, int32_t T, uint32_t* ranges, uint32_t* big, int phase, hipStream_t s) {
-  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
-  int sub = 6;
-  if ((nblk + sub - 1) / sub > kFusedMaxChunks) sub = (nblk + kFusedMaxChunks - 1) / kFusedMaxChunks;
-  const int nchunks = (nblk + sub - 1) / sub;
-  const int cpg = (nchunks + kGroups - 1) / kGroups;
-  char* c = static_cast<char*>(tmp);
-  uint32_t* table = carve<uint32_t>(c, (size_t)(nchunks > kFusedMaxChunks ? nchunks : kFusedMaxChunks) * T);
-  uint32_t* gsum = carve<uint32_t>(c, (size_t)kGroups * T);
-  uint32_t* totals = carve<uint32_t>(c, (size_t)T);
-  uint32_t* tbase = carve<uint32_t>(c, (size_t)T);
-  const size_t lds = (size_t)T * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_dup_kernel<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxTiles * 4));
-    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tb_dup_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, kFusedMaxTiles * 4));
-    attr_set = true;
-  }
-  const int gxx = grid_x(a.width);
-  if (phase == 0) {       // count pass (also: emission offsets, and L when the sums are raw)
-    hipLaunchKernelGGL(tb_dup_kernel<0>, dim3(nchunks), dim3(kPreBlock), lds, s, a.P, gxx, g, nblk, sub, sums_scanned ? 1 : 0,
-                       T, L_cap, table, cpg, gsum, tbase, totals, vals_out);
-    HGS_LAUNCH_CHECK("tile_bin_dup_count", s, a.debug);
-    return HGS_OK;
-  }
-  hipLaunchKernelGGL(tb_colscan_kernel, dim3((T + kTbThreads - 1) / kTbThreads, kGroups), dim3(kTbThreads), 0, s, table,
-                     nchunks, cpg, T, gsum, totals);
-  HGS_LAUNCH_CHECK("tile_bin_colscan", s, a.debug);
-  hipLaunchKernelGGL(tb_base_kernel, dim3(1 + (T + 1023) / 1024), dim3(1024), 0, s, gsum, totals, T, (T + 1023) / 1024, tbase,
-                     ranges, big);
-  HGS_LAUNCH_CHECK("tile_bin_base", s, a.debug);
-  hipLaunchKernelGGL(tb_dup_kernel<1>, dim3(nchunks), dim3(kPreBlock), lds, s, a.P, gxx, g, nblk, sub, sums_scanned ? 1 : 0, T,
-                     L_cap, table, cpg, gsum, tbase, totals, vals_out);
-  HGS_LAUNCH_CHECK("tile_bin_dup_scatter", s, a.debug);
   return HGS_OK;
 }
 
