@@ -1,4 +1,4 @@
-"""CPU restatement of the reference optimiser step -- TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+"""CPU restatement of the reference optimiser step -- TEST INFRASTRUCTURE ONLY (see the header of oracle/raster_oracle.py).
 
 Follows scene/OurAdam.py:249-337 (_single_tensor_adam, the row-sparse update used by train_single.py:171-176 and
 train_coarse.py:133-134) and :339-420 (_single_tensor_adam2, dense, taken when relevant.size(0) == 0), non-capturable,
