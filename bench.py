@@ -35,7 +35,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DOMINANT = "render_bwd"  # the kernel the roofline object describes (largest share of the frame, profiles/)
 
 
-def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False):
+def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_forward=False):
     """SURVEY.md §8(d) byte model, per stage, for the measured P (Gaussians), V (visible), L (tile
     instances), N (pixels), T (tiles), M (SH coefficients).  Each boundary tensor is counted once
     read / once written; irreducible intermediates once written + once read; the sort as one pass."""
@@ -57,6 +57,10 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False):
         # per view: geometry chain only (SH neither read nor written); per STEP: one pass over the coefficients
         b["preprocess_bwd"] = inst * L + P * 44 + 12 * P + P * 56 + 12 * P
         b["sh_bwd_batched"] = P * 12 * M * 2 + k * (16 * P) + 24 * P
+    if sh_forward:
+        # the colours come from one batched pass per step; K1 reads 12 B of colour instead of 12 M B of coefficients
+        b["preprocess_fwd"] = P * 44 + V * 12 + 4 * P + V * (rec + 12) + 8 * P
+        b["sh_colors_batched"] = P * 12 * M + 12 * P + k * (13 * P)
     return b
 
 
@@ -114,6 +118,8 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered (fwd+bwd) per rank between two gradient all-reduces")
+    ap.add_argument("--batched-sh-forward", action="store_true",
+                    help="k > 1: evaluate the SH colours of all k views in one pass and rasterize with colors_precomp")
     ap.add_argument("--no-deferred-sh", action="store_true",
                     help="per-view SH backward (accumulating) instead of one batched pass per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -178,9 +184,36 @@ def main():
 
     # k > 1: the SH part of the k backwards (81 % of the gradient bytes) is left pending and done for all k views in one
     # pass over the coefficients at the end of the step (hgs_raster_sh_bwd_batched)
-    dgr._RasterizeGaussians.defer_sh_backward = k > 1 and not args.no_deferred_sh
+    dgr._RasterizeGaussians.defer_sh_backward = k > 1 and not args.no_deferred_sh and not args.batched_sh_forward
+
+    sh_fwd = bool(args.batched_sh_forward and k > 1)
+    campos = [r.raster_settings.campos for r in rasts]
+    raster_names = [kk for kk in params if kk != "shs"]
+
+    def step_sh_forward():
+        # colours of all k views in ONE pass over the coefficients (the reference's convert_SHs_python route, in HIP),
+        # k rasterizations with colors_precomp, then ONE pass for dL/dSH and the view-direction part of dL/dmeans3D
+        with torch.no_grad():
+            rgbs, clamps = dgr.sh_colors_batched(params["means3D"], params["shs"], scene.sh_degree, campos)
+        d_rgbs = []
+        for j, rast in enumerate(rasts):
+            dgr._RasterizeGaussians.grad_accumulate = j > 0
+            rgb = rgbs[j].requires_grad_(True)
+            color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, colors_precomp=rgb,
+                                      opacities=params["opacities"], scales=params["scales"],
+                                      rotations=params["rotations"])
+            info["L"] = color.grad_fn.num_rendered
+            info["radii"] = radii
+            g = torch.autograd.grad([color, invd], [params[kk] for kk in raster_names] + [means2D, rgb], [gc, gd])
+            d_rgbs.append(g[-1])
+        dgr.sh_colors_batched_backward(params["means3D"], params["shs"], scene.sh_degree, campos, clamps, d_rgbs,
+                                       bucket.views["shs"], bucket.views["means3D"])
+        if world > 1:
+            bucket.all_reduce()
 
     def step():
+        if sh_fwd:
+            return step_sh_forward()
         for j, rast in enumerate(rasts):
             dgr._RasterizeGaussians.grad_accumulate = j > 0
             color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, shs=params["shs"],
@@ -237,10 +270,11 @@ def main():
         L = int(info["L"])
         V = int((info["radii"] > 0).sum().item())
         N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), scene.shs.shape[1]
-        deferred = bool(dgr._RasterizeGaussians.defer_sh_backward)
-        ab = algorithmic_bytes(P, V, L, N, T, M, k=k, deferred_sh=deferred)
-        # per frame: the batched SH pass runs once per step of k views
-        total_bytes = sum(v for kk_, v in ab.items() if kk_ != "sh_bwd_batched") + ab.get("sh_bwd_batched", 0) / k
+        deferred = bool(dgr._RasterizeGaussians.defer_sh_backward) or sh_fwd
+        ab = algorithmic_bytes(P, V, L, N, T, M, k=k, deferred_sh=deferred, sh_forward=sh_fwd)
+        # per frame: the batched SH passes run once per step of k views
+        per_step = ("sh_bwd_batched", "sh_colors_batched")
+        total_bytes = sum(v for kk_, v in ab.items() if kk_ not in per_step) + sum(ab.get(kk_, 0) for kk_ in per_step) / k
         result = {
             "metric": "fwd+bwd frames/s @1080p, 1M Gaussians", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -252,6 +286,7 @@ def main():
                        "views_per_step_per_gpu": k,
                        "parallelism": f"per-view dp{world}, {k} views per rank per step accumulated in place" +
                                       (", SH backward batched over the views" if dgr._RasterizeGaussians.defer_sh_backward else "") +
+                                      (", SH colours and their backward batched over the views" if sh_fwd else "") +
                                       (", one RCCL all-reduce of the 59P-float grad bucket per step" if world > 1 else ""),
                        "render_variant": args.variant},
             "algorithmic_bytes_per_frame": total_bytes,

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
 // the gradient block written once for all views -- per view this kernel's traffic is otherwise the largest of the
 // streaming kernels (384 B per Gaussian).
 template <bool ACC, bool COOP>   // COOP: 3M % 4 == 0, the SH block goes through LDS; else per-lane access
-__global__ __launch_bounds__(kPreBlock) void sh_bwd_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
+__global__ __launch_bounds__(kPreBlock, 3) void sh_bwd_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
                                                                    const float* __restrict__ means3D,
                                                                    const float* __restrict__ shs,
                                                                    float* __restrict__ dL_dshs,
@@ -719,8 +719,15 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_batched_kernel(ShBwdViews v,
     const float px = means3D[idx * 3 + 0], py = means3D[idx * 3 + 1], pz = means3D[idx * 3 + 2];
     const int nb = (sh_degree + 1) * (sh_degree + 1);
     for (int w = 0; w < v.n; ++w) {
-      if (v.tiles_touched[w][idx] == 0) continue;
-      const float gr0 = v.drgb[w][idx * 3 + 0], gr1 = v.drgb[w][idx * 3 + 1], gr2 = v.drgb[w][idx * 3 + 2];
+      if (v.tiles_touched[w] && v.tiles_touched[w][idx] == 0) continue;
+      float gr0 = v.drgb[w][idx * 3 + 0], gr1 = v.drgb[w][idx * 3 + 1], gr2 = v.drgb[w][idx * 3 + 2];
+      if (v.clamp[w]) {       // colour path: the incoming gradient is w.r.t. the clamped colour
+        const uint32_t m = v.clamp[w][idx];
+        if (m & 1u) gr0 = 0.f;
+        if (m & 2u) gr1 = 0.f;
+        if (m & 4u) gr2 = 0.f;
+        if (gr0 == 0.f && gr1 == 0.f && gr2 == 0.f) continue;      // culled / not contributing in this view
+      }
       // dotc[k] = gr . c_k straight from the LDS row (or the registers of the per-lane path): no 48-float copy
       float dotc[16];
 #pragma unroll
@@ -789,6 +796,62 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_batched_kernel(ShBwdViews v,
 }
 
 }  // namespace
+
+// Colours of one block of Gaussians for every view: SH block through LDS once, basis per view.
+__global__ __launch_bounds__(kPreBlock) void sh_colors_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
+                                                                      const float* __restrict__ means3D,
+                                                                      const float* __restrict__ shs) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds = reinterpret_cast<float*>(smem_raw);
+  const int n = M * 3;
+  const bool coop = (n & 3) == 0;
+  const int block_first = blockIdx.x * kPreBlock;
+  const int idx = block_first + threadIdx.x;
+  if (coop) {
+    coop_load_sh(shs, block_first, P, n, lds);
+    __syncthreads();
+  }
+  if (idx >= P) return;
+  float sh[48];
+  if (coop) lds_row_read(lds, n, sh); else load_sh(shs, idx, M, sh);
+  const float px = means3D[idx * 3 + 0], py = means3D[idx * 3 + 1], pz = means3D[idx * 3 + 2];
+  const int nb = (sh_degree + 1) * (sh_degree + 1);
+  for (int w = 0; w < v.n; ++w) {
+    float dx = px - v.campos[w][0], dy = py - v.campos[w][1], dz = pz - v.campos[w][2];
+    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    float b[16];
+    sh_basis(sh_degree, dx, dy, dz, b);
+    float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < nb) {
+        r0 += b[k] * sh[k * 3 + 0];
+        r1 += b[k] * sh[k * 3 + 1];
+        r2 += b[k] * sh[k * 3 + 2];
+      }
+    }
+    r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+    uint32_t m = 0;
+    if (r0 < 0.f) { r0 = 0.f; m |= 1u; }
+    if (r1 < 0.f) { r1 = 0.f; m |= 2u; }
+    if (r2 < 0.f) { r2 = 0.f; m |= 4u; }
+    v.rgb_out[w][idx * 3 + 0] = r0;
+    v.rgb_out[w][idx * 3 + 1] = r1;
+    v.rgb_out[w][idx * 3 + 2] = r2;
+    v.clamp_out[w][idx] = (uint8_t)m;
+  }
+}
+
+int launch_sh_colors_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
+                             const float* shs, hipStream_t s) {
+  const int nblk = (P + kPreBlock - 1) / kPreBlock;
+  if (nblk <= 0) return HGS_OK;
+  const size_t lds_bytes = (size_t)kPreBlock * (M * 3 + 4) * sizeof(float);
+  hipLaunchKernelGGL(sh_colors_batched_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, v, P, M, sh_degree, means3D, shs);
+  HGS_LAUNCH_CHECK("sh_colors_batched", s, false);
+  return HGS_OK;
+}
 
 int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
                           const float* shs, float* dL_dshs, float* dL_dmeans3D, bool accumulate, hipStream_t s) {

@@ -290,6 +290,53 @@ def sh_backward_batched(calls, accumulate=False):
         c.deferred = None
 
 
+def _color_views(campos_list, rgbs, clamps, d_rgbs):
+    n = len(campos_list)
+    if not 1 <= n <= _lib.MAX_DEFERRED_VIEWS:
+        raise RuntimeError(f"1..{_lib.MAX_DEFERRED_VIEWS} views per call")
+    arr = (_lib.ShColorView * n)()
+    keep = []
+    for i, v in enumerate(arr):
+        cp = _small(campos_list[i], "campos", 3)
+        keep.append(cp)
+        v.campos = cp.data_ptr()
+        v.rgb = rgbs[i].data_ptr() if rgbs is not None else None
+        v.clamp = clamps[i].data_ptr()
+        v.d_rgb = d_rgbs[i].data_ptr() if d_rgbs is not None else None
+    return arr, keep
+
+
+def sh_colors_batched(means3D, shs, sh_degree, campos_list):
+    """Colours of the same Gaussians seen from several cameras, one pass over the SH coefficients: the batched HIP
+    form of the reference's convert_SHs_python branch (gaussian_renderer/__init__.py:84-89).  Returns (rgbs, clamps):
+    per view a [P,3] float32 tensor to pass as ``colors_precomp`` and the uint8 clamp mask the backward needs."""
+    _require_gpu(means3D, "means3D")
+    _require_gpu(shs, "shs")
+    P, M = means3D.shape[0], shs.shape[1]
+    dev = means3D.device
+    rgbs = [torch.empty(P, 3, dtype=torch.float32, device=dev) for _ in campos_list]
+    clamps = [torch.empty(P, dtype=torch.uint8, device=dev) for _ in campos_list]
+    arr, keep = _color_views(campos_list, rgbs, clamps, None)
+    _lib.check(_lib.lib().hgs_sh_colors_batched(arr, len(campos_list), P, M, int(sh_degree), _lib.ptr(means3D),
+                                                _lib.ptr(shs), _stream(dev), dev.index or 0), "hgs_sh_colors_batched")
+    return rgbs, clamps
+
+
+def sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D, accumulate=False):
+    """d_rgbs: per view dL/d(colors_precomp) [P,3].  d_shs = (accumulate ? d_shs : 0) + sum over the views;
+    d_means3D += the views' view-direction terms (both float32 GPU tensors shaped like shs / means3D)."""
+    P, M = means3D.shape[0], shs.shape[1]
+    dev = means3D.device
+    d_rgbs = [g.to(torch.float32).contiguous() for g in d_rgbs]
+    for t, name in ((d_shs, "d_shs"), (d_means3D, "d_means3D")):
+        _require_gpu(t, name)
+    arr, keep = _color_views(campos_list, None, clamps, d_rgbs)
+    _lib.check(_lib.lib().hgs_sh_colors_batched_bwd(arr, len(campos_list), P, M, int(sh_degree), _lib.ptr(means3D),
+                                                    _lib.ptr(shs), _lib.ptr(d_shs), _lib.ptr(d_means3D),
+                                                    int(bool(accumulate)), _stream(dev), dev.index or 0),
+               "hgs_sh_colors_batched_bwd")
+
+
 def raster_views(call):
     """Test/introspection helper: typed torch views of the sorted keys, point list, tile ranges, ..."""
     lib = _lib.lib()

@@ -136,6 +136,18 @@ def finish_deferred_sh_backward(accumulate=False):
     _C.sh_backward_batched(pending, accumulate=accumulate)
 
 
+def sh_colors_batched(means3D, shs, sh_degree, campos_list):
+    """See _C.sh_colors_batched: view-dependent colours for several cameras in one pass (no autograd: pass every
+    returned colour tensor with requires_grad_() as colors_precomp and hand its gradient to
+    sh_colors_batched_backward)."""
+    return _C.sh_colors_batched(means3D, shs, sh_degree, campos_list)
+
+
+def sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D, accumulate=False):
+    return _C.sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D,
+                                         accumulate)
+
+
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
                             raster_settings, opacity_activation="sigmoid"):
     """opacity_activation: 'sigmoid' (scene/gaussian_model.py:126-127), 'abs' (hierarchy mode, :393) or 'none'."""
@@ -216,4 +228,4 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "finish_deferred_sh_backward", "_C"]
+           "finish_deferred_sh_backward", "sh_colors_batched", "sh_colors_batched_backward", "_C"]

@@ -58,6 +58,10 @@ class ShBwdView(C.Structure):
                 ("reserved", C.c_uint32)]
 
 
+class ShColorView(C.Structure):
+    _fields_ = [("campos", C.c_void_p), ("rgb", C.c_void_p), ("clamp", C.c_void_p), ("d_rgb", C.c_void_p)]
+
+
 MAX_DEFERRED_VIEWS = 8
 
 
@@ -102,6 +106,10 @@ SIGNATURES = {
     "hgs_lod_gather_bwd": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P,
                                      _P, _P, C.c_int]),
     "hgs_raster_sh_bwd_batched": (C.c_int, [C.POINTER(ShBwdView), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
+                                            _P, _P, C.c_int32, _P, C.c_int]),
+    "hgs_sh_colors_batched": (C.c_int, [C.POINTER(ShColorView), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
+                                        C.c_int]),
+    "hgs_sh_colors_batched_bwd": (C.c_int, [C.POINTER(ShColorView), C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P,
                                             _P, _P, C.c_int32, _P, C.c_int]),
     "hgs_adam_step": (C.c_int, [C.POINTER(AdamTensor), C.c_int32, C.c_int64, _P, C.c_int64, _P, _P, C.c_int]),
     "hgs_knn_tmp_bytes": (C.c_size_t, [C.c_int32]),

@@ -176,6 +176,24 @@ int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int
                               const float* means3D, const float* shs, float* dL_dshs, float* dL_dmeans3D,
                               int32_t accumulate, hgs_stream_t stream, int device);
 
+/* View-dependent colours of the same Gaussians for up to HGS_MAX_DEFERRED_VIEWS cameras in one pass over the SH
+ * coefficients -- the batched HIP form of the reference's convert_SHs_python branch (gaussian_renderer/__init__.py:
+ * 84-89: eval_sh + 0.5, clamped at 0, result handed to the rasterizer as colors_precomp).  Forward writes rgb [P,3] and
+ * a clamp mask [P] (bit c set: channel c was clamped) per view; backward takes dL/d(rgb) per view (the dL_dcolors of
+ * the views' hgs_raster_bwd), masks it, and writes dL_dshs = (accumulate ? dL_dshs : 0) + sum over the views and
+ * dL_dmeans3D += the view-direction terms. */
+typedef struct hgs_sh_color_view {
+  const float* campos;  /* device [3] */
+  float* rgb;           /* forward out [P,3] */
+  uint8_t* clamp;       /* forward out / backward in [P] */
+  const float* d_rgb;   /* backward in [P,3] */
+} hgs_sh_color_view;
+int hgs_sh_colors_batched(const hgs_sh_color_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
+                          const float* means3D, const float* shs, hgs_stream_t stream, int device);
+int hgs_sh_colors_batched_bwd(const hgs_sh_color_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
+                              const float* means3D, const float* shs, float* dL_dshs, float* dL_dmeans3D,
+                              int32_t accumulate, hgs_stream_t stream, int device);
+
 /* Introspection for the parity tests ("bit-exact on tile/sort indices"):
  * device pointers into the workspaces after stage 2. */
 typedef struct hgs_raster_views {

@@ -39,6 +39,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.HierHost) == 16 + 7 * 8
     assert C.sizeof(_lib.AdamTensor) == 4 * 8 + 10 * 4
     assert C.sizeof(_lib.ShBwdView) == 3 * 8 + 2 * 4
+    assert C.sizeof(_lib.ShColorView) == 4 * 8
 
 
 def test_workspace_size_queries_need_no_gpu():

@@ -500,3 +500,52 @@ def test_deferred_batched_sh_backward(gpu):
         assert torch.isfinite(got).all(), n
         assert torch.allclose(got, want, rtol=1e-5, atol=2e-6 * float(want.abs().max())), \
             (n, float((got - want).abs().max()), float(want.abs().max()))
+
+
+def test_batched_sh_colors_route(gpu):
+    """Colours of several views in one pass (hgs_sh_colors_batched), rasterization with colors_precomp, one pass for
+    dL/dSH (hgs_sh_colors_batched_bwd) -- the batched form of the reference's convert_SHs_python route -- must give
+    the colours of the in-op SH evaluation and the summed gradients of the views' standard backward."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W, H, P, K = 176, 112, 1500, 3
+    base = synth.make_camera(W, H)
+    scene = synth.make_scene(P, base, seed=17)
+    cams = [synth.orbit_camera(W, H, j, K, radius=0.4) for j in range(K)]
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.zeros(3)
+    sep = [pa.run_hip(scene, c, bg, gc, gd, gpu) for c in cams]
+    sc = scene.to(gpu)
+    campos = [c.camera_center.to(gpu) for c in cams]
+    rgbs, clamps = dgr.sh_colors_batched(sc.means3D, sc.shs, 3, campos)
+    for j, c in enumerate(cams):        # forward: against the torch restatement of utils/sh_utils.eval_sh
+        d = scene.means3D - c.camera_center
+        d = d / d.norm(dim=1, keepdim=True)
+        ref = torch.clamp_min(ro.eval_sh_torch(3, scene.shs.double(), d.double()) + 0.5, 0.0)
+        assert float((rgbs[j].cpu().double() - ref).abs().max()) <= 2e-6
+        assert bool(((clamps[j].cpu() != 0) <= (rgbs[j].cpu() == 0).any(dim=1)).all())     # clamped => a zero channel
+    names = ("means3D", "opacities", "scales", "rotations")
+    params = {n: getattr(sc, n).clone().requires_grad_(True) for n in names}
+    tot = {n: torch.zeros_like(params[n]) for n in names}
+    d_rgbs = []
+    for j, c in enumerate(cams):
+        rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(c, bg, 3, device=gpu))
+        m2 = torch.zeros(P, 3, device=gpu, requires_grad=True)
+        rgb = rgbs[j].requires_grad_(True)
+        color, radii, invd = dgr.GaussianRasterizer(rs)(
+            means3D=params["means3D"], means2D=m2, colors_precomp=rgb, opacities=params["opacities"],
+            scales=params["scales"], rotations=params["rotations"])
+        assert float((color.detach().cpu() - sep[j]["color"]).abs().max()) <= 1e-5
+        g = torch.autograd.grad([color, invd], [params[n] for n in names] + [rgb], [gc.to(gpu), gd.to(gpu)])
+        for n, t in zip(names, g):
+            tot[n] += t
+        d_rgbs.append(g[-1])
+    d_shs = torch.full_like(sc.shs, float("nan"))
+    dgr.sh_colors_batched_backward(sc.means3D, sc.shs, 3, campos, clamps, d_rgbs, d_shs, tot["means3D"])
+    tot["shs"] = d_shs
+    for n in ("means3D", "shs", "opacities", "scales", "rotations"):
+        want = sum(s["grads"][n] for s in sep)
+        got = tot[n].cpu()
+        assert torch.isfinite(got).all(), n
+        assert torch.allclose(got, want, rtol=1e-5, atol=2e-6 * float(want.abs().max())), \
+            (n, float((got - want).abs().max()), float(want.abs().max()))
