@@ -308,15 +308,13 @@ int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int
   if (((uintptr_t)shs | (uintptr_t)dL_dshs) & 15u) { set_error("shs / dL_dshs must be 16-byte aligned"); return HGS_ERR_INVALID; }
   ShBwdViews v;
   v.n = n_views;
+  v.color = 0;
   for (int i = 0; i < HGS_MAX_DEFERRED_VIEWS; ++i) {
     const hgs_sh_bwd_view& w = views[i < n_views ? i : 0];
     if (!w.geom_ws || !w.bwd_ws || !w.campos) { set_error("deferred view %d has a null pointer", i); return HGS_ERR_INVALID; }
-    v.tiles_touched[i] = GeomWs::carve_from(const_cast<void*>(w.geom_ws), P).tiles_touched;
-    v.clamp[i] = nullptr;
+    v.mask[i] = GeomWs::carve_from(const_cast<void*>(w.geom_ws), P).tiles_touched;
     v.drgb[i] = bwd_ws_drgb(const_cast<void*>(w.bwd_ws), w.L);
     v.campos[i] = w.campos;
-    v.rgb_out[i] = nullptr;
-    v.clamp_out[i] = nullptr;
   }
   HGS_HIP(hipSetDevice(device));
   return HGS_TIMED(ST_SH_BATCHED, static_cast<hipStream_t>(stream),
@@ -324,32 +322,30 @@ int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int
                                          static_cast<hipStream_t>(stream)));
 }
 
-static int sh_color_views(const hgs_sh_color_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
-                          const float* means3D, const float* shs, bool backward, ShBwdViews& v) {
+static int sh_color_check(const hgs_sh_color_view* views, int32_t n_views, int32_t M, int32_t sh_degree,
+                          const float* means3D, const float* shs, bool backward) {
   if (!views || n_views > HGS_MAX_DEFERRED_VIEWS) { set_error("1..%d views per call", HGS_MAX_DEFERRED_VIEWS); return HGS_ERR_INVALID; }
   if (!means3D || !shs) { set_error("null argument"); return HGS_ERR_INVALID; }
   if (sh_degree < 0 || sh_degree > 3 || M < (sh_degree + 1) * (sh_degree + 1) || M > 16) { set_error("M=%d incompatible with sh_degree=%d", M, sh_degree); return HGS_ERR_INVALID; }
   if ((uintptr_t)shs & 15u) { set_error("shs must be 16-byte aligned"); return HGS_ERR_INVALID; }
-  v.n = n_views;
-  for (int i = 0; i < HGS_MAX_DEFERRED_VIEWS; ++i) {
-    const hgs_sh_color_view& w = views[i < n_views ? i : 0];
-    if (!w.campos || !w.clamp || (backward ? !w.d_rgb : !w.rgb)) { set_error("colour view %d has a null pointer", i); return HGS_ERR_INVALID; }
-    v.tiles_touched[i] = nullptr;
-    v.clamp[i] = w.clamp;
-    v.drgb[i] = w.d_rgb;
-    v.campos[i] = w.campos;
-    v.rgb_out[i] = w.rgb;
-    v.clamp_out[i] = w.clamp;
-  }
+  for (int i = 0; i < n_views; ++i)
+    if (!views[i].campos || !views[i].clamp || (backward ? !views[i].d_rgb : !views[i].rgb)) { set_error("colour view %d has a null pointer", i); return HGS_ERR_INVALID; }
   return HGS_OK;
 }
 
 int hgs_sh_colors_batched(const hgs_sh_color_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,
                           const float* means3D, const float* shs, hgs_stream_t stream, int device) {
   if (n_views <= 0 || P <= 0) return HGS_OK;
-  ShBwdViews v;
-  int rc = sh_color_views(views, n_views, P, M, sh_degree, means3D, shs, false, v);
+  int rc = sh_color_check(views, n_views, M, sh_degree, means3D, shs, false);
   if (rc) return rc;
+  ShFwdViews v;
+  v.n = n_views;
+  for (int i = 0; i < HGS_MAX_DEFERRED_VIEWS; ++i) {
+    const hgs_sh_color_view& w = views[i < n_views ? i : 0];
+    v.campos[i] = w.campos;
+    v.rgb_out[i] = w.rgb;
+    v.clamp_out[i] = w.clamp;
+  }
   HGS_HIP(hipSetDevice(device));
   return launch_sh_colors_batched(v, P, M, sh_degree, means3D, shs, static_cast<hipStream_t>(stream));
 }
@@ -359,9 +355,17 @@ int hgs_sh_colors_batched_bwd(const hgs_sh_color_view* views, int32_t n_views, i
                               int32_t accumulate, hgs_stream_t stream, int device) {
   if (n_views <= 0 || P <= 0) return HGS_OK;
   if (!dL_dshs || !dL_dmeans3D || ((uintptr_t)dL_dshs & 15u)) { set_error("dL_dshs (16-byte aligned) / dL_dmeans3D missing"); return HGS_ERR_INVALID; }
-  ShBwdViews v;
-  int rc = sh_color_views(views, n_views, P, M, sh_degree, means3D, shs, true, v);
+  int rc = sh_color_check(views, n_views, M, sh_degree, means3D, shs, true);
   if (rc) return rc;
+  ShBwdViews v;
+  v.n = n_views;
+  v.color = 1;
+  for (int i = 0; i < HGS_MAX_DEFERRED_VIEWS; ++i) {
+    const hgs_sh_color_view& w = views[i < n_views ? i : 0];
+    v.mask[i] = w.clamp;
+    v.drgb[i] = w.d_rgb;
+    v.campos[i] = w.campos;
+  }
   HGS_HIP(hipSetDevice(device));
   return HGS_TIMED(ST_SH_BATCHED, static_cast<hipStream_t>(stream),
                    launch_sh_bwd_batched(v, P, M, sh_degree, means3D, shs, dL_dshs, dL_dmeans3D, accumulate != 0,

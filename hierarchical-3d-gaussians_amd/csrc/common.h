@@ -105,16 +105,23 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           const hgs_raster_grads& out, hipStream_t s);
-struct ShBwdViews {          // per-view device pointers of the batched SH kernels
-  const uint32_t* tiles_touched[HGS_MAX_DEFERRED_VIEWS];   // deferred raster backward: visibility (NULL: see clamp)
-  const uint8_t* clamp[HGS_MAX_DEFERRED_VIEWS];            // colour path: clamp mask of the forward (NULL: drgb is masked)
+// Per-view device pointers of the batched SH kernels.  Kept small (24 pointers): they are kernel arguments and must
+// stay in scalar registers across the view loop.
+struct ShBwdViews {
+  const void* mask[HGS_MAX_DEFERRED_VIEWS];    // deferred raster backward: uint32 tiles_touched[P] (visibility);
+                                               // colour route: uint8 clamp mask[P] of the forward
   const float* drgb[HGS_MAX_DEFERRED_VIEWS];
   const float* campos[HGS_MAX_DEFERRED_VIEWS];
-  float* rgb_out[HGS_MAX_DEFERRED_VIEWS];                  // colour forward
+  int n;
+  int color;                                   // which of the two meanings `mask` has
+};
+struct ShFwdViews {
+  const float* campos[HGS_MAX_DEFERRED_VIEWS];
+  float* rgb_out[HGS_MAX_DEFERRED_VIEWS];
   uint8_t* clamp_out[HGS_MAX_DEFERRED_VIEWS];
   int n;
 };
-int launch_sh_colors_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
+int launch_sh_colors_batched(const ShFwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
                              const float* shs, hipStream_t s);
 int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
                           const float* shs, float* dL_dshs, float* dL_dmeans3D, bool accumulate, hipStream_t s);

@@ -690,12 +690,13 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
 // K8b for several views of the same Gaussians at once (hgs_raster_sh_bwd_batched): the SH block is read once and
 // the gradient block written once for all views -- per view this kernel's traffic is otherwise the largest of the
 // streaming kernels (384 B per Gaussian).
-template <bool ACC, bool COOP>   // COOP: 3M % 4 == 0, the SH block goes through LDS; else per-lane access
-__global__ __launch_bounds__(kPreBlock, 3) void sh_bwd_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
-                                                                   const float* __restrict__ means3D,
-                                                                   const float* __restrict__ shs,
-                                                                   float* __restrict__ dL_dshs,
-                                                                   float* __restrict__ dL_dmeans3D) {
+// COOP: 3M % 4 == 0, the SH block goes through LDS, else per-lane access.  COLOR: the views come from the batched
+// colour route (gradient w.r.t. the clamped colour + clamp mask) instead of deferred raster backwards (masked
+// gradient + visibility).
+template <bool ACC, bool COOP, bool COLOR>
+__device__ __forceinline__ void sh_bwd_batched_body(const ShBwdViews& v, int P, int M, int sh_degree,
+                                                    const float* __restrict__ means3D, const float* __restrict__ shs,
+                                                    float* __restrict__ dL_dshs, float* __restrict__ dL_dmeans3D) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int n = M * 3;
@@ -719,10 +720,10 @@ __global__ __launch_bounds__(kPreBlock, 3) void sh_bwd_batched_kernel(ShBwdViews
     const float px = means3D[idx * 3 + 0], py = means3D[idx * 3 + 1], pz = means3D[idx * 3 + 2];
     const int nb = (sh_degree + 1) * (sh_degree + 1);
     for (int w = 0; w < v.n; ++w) {
-      if (v.tiles_touched[w] && v.tiles_touched[w][idx] == 0) continue;
+      if (!COLOR && static_cast<const uint32_t*>(v.mask[w])[idx] == 0) continue;
       float gr0 = v.drgb[w][idx * 3 + 0], gr1 = v.drgb[w][idx * 3 + 1], gr2 = v.drgb[w][idx * 3 + 2];
-      if (v.clamp[w]) {       // colour path: the incoming gradient is w.r.t. the clamped colour
-        const uint32_t m = v.clamp[w][idx];
+      if (COLOR) {            // the incoming gradient is w.r.t. the clamped colour
+        const uint32_t m = static_cast<const uint8_t*>(v.mask[w])[idx];
         if (m & 1u) gr0 = 0.f;
         if (m & 2u) gr1 = 0.f;
         if (m & 4u) gr2 = 0.f;
@@ -797,8 +798,25 @@ __global__ __launch_bounds__(kPreBlock, 3) void sh_bwd_batched_kernel(ShBwdViews
 
 }  // namespace
 
+template <bool ACC, bool COOP>
+__global__ __launch_bounds__(kPreBlock) void sh_bwd_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
+                                                                   const float* __restrict__ means3D,
+                                                                   const float* __restrict__ shs,
+                                                                   float* __restrict__ dL_dshs,
+                                                                   float* __restrict__ dL_dmeans3D) {
+  sh_bwd_batched_body<ACC, COOP, false>(v, P, M, sh_degree, means3D, shs, dL_dshs, dL_dmeans3D);
+}
+template <bool ACC, bool COOP>     // 3 workgroups per CU = what the LDS stage allows: keeps the registers under 170
+__global__ __launch_bounds__(kPreBlock, 3) void sh_bwd_batched_color_kernel(ShBwdViews v, int P, int M, int sh_degree,
+                                                                            const float* __restrict__ means3D,
+                                                                            const float* __restrict__ shs,
+                                                                            float* __restrict__ dL_dshs,
+                                                                            float* __restrict__ dL_dmeans3D) {
+  sh_bwd_batched_body<ACC, COOP, true>(v, P, M, sh_degree, means3D, shs, dL_dshs, dL_dmeans3D);
+}
+
 // Colours of one block of Gaussians for every view: SH block through LDS once, basis per view.
-__global__ __launch_bounds__(kPreBlock) void sh_colors_batched_kernel(ShBwdViews v, int P, int M, int sh_degree,
+__global__ __launch_bounds__(kPreBlock) void sh_colors_batched_kernel(ShFwdViews v, int P, int M, int sh_degree,
                                                                       const float* __restrict__ means3D,
                                                                       const float* __restrict__ shs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -843,7 +861,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_colors_batched_kernel(ShBwdViews
   }
 }
 
-int launch_sh_colors_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
+int launch_sh_colors_batched(const ShFwdViews& v, int32_t P, int32_t M, int32_t sh_degree, const float* means3D,
                              const float* shs, hipStream_t s) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
   if (nblk <= 0) return HGS_OK;
@@ -859,8 +877,11 @@ int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_
   if (nblk <= 0) return HGS_OK;
   const size_t lds_bytes = (size_t)kPreBlock * (M * 3 + 4) * sizeof(float);
   const bool coop = ((M * 3) & 3) == 0;
-  auto kern = coop ? (accumulate ? sh_bwd_batched_kernel<true, true> : sh_bwd_batched_kernel<false, true>)
-                   : (accumulate ? sh_bwd_batched_kernel<true, false> : sh_bwd_batched_kernel<false, false>);
+  const bool color = v.color != 0;
+  auto kern = color ? (coop ? (accumulate ? sh_bwd_batched_color_kernel<true, true> : sh_bwd_batched_color_kernel<false, true>)
+                            : (accumulate ? sh_bwd_batched_color_kernel<true, false> : sh_bwd_batched_color_kernel<false, false>))
+                    : (coop ? (accumulate ? sh_bwd_batched_kernel<true, true> : sh_bwd_batched_kernel<false, true>)
+                            : (accumulate ? sh_bwd_batched_kernel<true, false> : sh_bwd_batched_kernel<false, false>));
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(kPreBlock), lds_bytes, s, v, P, M, sh_degree, means3D, shs, dL_dshs,
                      dL_dmeans3D);
   HGS_LAUNCH_CHECK("sh_bwd_batched", s, false);
