@@ -9,7 +9,11 @@
 A step = one optimizer step's worth of rasterizer work on every rank: `--views-per-step` (default 4)
 views, each a full GaussianRasterizer forward + backward through the C ABI (preprocess, binning, sorts,
 compositing, compositing backward, preprocess backward) with inputs resident in HBM, their gradients
-accumulated in place into one flat 59*P-float bucket; with N > 1 every rank renders different views of
+accumulated in place into one flat 59*P-float bucket.  The SH-dependent ends of the k views are batched: their
+colours come from ONE pass over the coefficients (hgs_sh_colors_batched -- the HIP form of the reference's
+convert_SHs_python route, gaussian_renderer/__init__.py:84-89; the rasterizer then takes colors_precomp) and dL/dSH
+from ONE pass (hgs_sh_colors_batched_bwd); `--no-batched-sh-forward` evaluates SH inside every rasterizer call (then
+only the backward is batched), `--no-deferred-sh` nothing.  With N > 1 every rank renders different views of
 the same replicated Gaussians and the step ends with ONE RCCL all-reduce of that bucket (per-view data
 parallelism with gradient accumulation).  The per-rank work is the same for every N
 (weak scaling); value = N * views_per_step * steps / max-over-ranks time.  The 236 MB all-reduce costs
@@ -118,8 +122,9 @@ def main():
     ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
     ap.add_argument("--views-per-step", type=int, default=4,
                     help="views rendered (fwd+bwd) per rank between two gradient all-reduces")
-    ap.add_argument("--batched-sh-forward", action="store_true",
-                    help="k > 1: evaluate the SH colours of all k views in one pass and rasterize with colors_precomp")
+    ap.add_argument("--no-batched-sh-forward", action="store_true",
+                    help="k > 1: evaluate the SH colours inside every view's rasterizer call instead of once per step "
+                         "for all k views (then only the SH backward is batched, see --no-deferred-sh)")
     ap.add_argument("--no-deferred-sh", action="store_true",
                     help="per-view SH backward (accumulating) instead of one batched pass per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -184,9 +189,9 @@ def main():
 
     # k > 1: the SH part of the k backwards (81 % of the gradient bytes) is left pending and done for all k views in one
     # pass over the coefficients at the end of the step (hgs_raster_sh_bwd_batched)
-    dgr._RasterizeGaussians.defer_sh_backward = k > 1 and not args.no_deferred_sh and not args.batched_sh_forward
+    dgr._RasterizeGaussians.defer_sh_backward = k > 1 and not args.no_deferred_sh and args.no_batched_sh_forward
 
-    sh_fwd = bool(args.batched_sh_forward and k > 1)
+    sh_fwd = bool(k > 1 and not args.no_batched_sh_forward)
     campos = [r.raster_settings.campos for r in rasts]
     raster_names = [kk for kk in params if kk != "shs"]
 
