@@ -558,7 +558,7 @@ __device__ __forceinline__ float swap16_add(float a, float b) {   // rows: [a.r0
 }
 
 template <bool DEPTH>
-__global__ __launch_bounds__(64) void render_bwd_packed_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_bwd_packed_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
