@@ -4,6 +4,7 @@
   f-1  in-op LOD gather-lerp        vs the Python glue of gaussian_renderer/__init__.py:199-235 (torch ops)
   f-3  raw-parameter path            vs torch activations + cat (scene/gaussian_model.py:108-128) around the op
   f-4  fused row-sparse Adam         vs the torch-op chain of scene/OurAdam.py:249-337 (restated with torch ops)
+  train  a complete optimiser step: 4 views (batched SH ends) with an L1 + inverse-depth loss, fused Adam
 
 Every leg is a full training-style iteration (forward + backward, or one optimiser step) at 1080p on synthetic
 data, timed with the stream drained on both sides.  One JSON object per leg on stdout.
@@ -203,19 +204,74 @@ def leg_adam(args, dev):
                      "dense_achieved_GBps": P * 59 * 28 / t_dense / 1e6})
 
 
+def leg_trainstep(args, dev):
+    """A complete optimiser step at 1 M Gaussians / 1080p: SH colours of k views in one pass, k x (rasterize, L1 +
+    inverse-depth loss, backward accumulating into the flat bucket), SH backward in one pass, fused Adam."""
+    import diff_gaussian_rasterization as dgr
+    from hgs import dp
+    from hgs.optim import Adam
+    W, H, k = 1920, 1080, 4
+    base = synth.make_camera(W, H)
+    scene = synth.make_scene(args.gaussians, base, seed=0).to(dev)
+    cams = [synth.orbit_camera(W, H, j, k).to(dev) for j in range(k)]
+    names = ("means3D", "shs", "opacities", "scales", "rotations")
+    params = {n: torch.nn.Parameter(getattr(scene, n).clone()) for n in names}
+    lrs = dict(means3D=1.6e-5, shs=2.5e-3, opacities=1e-3, scales=1e-6, rotations=1e-5)
+    bucket = dp.GradBucket({n: tuple(v.shape) for n, v in params.items()}, dev)
+    for n in names:
+        params[n].grad = bucket.views[n]
+    opt = Adam([dict(params=[params[n]], lr=lrs[n], name=n) for n in names], lr=0.0, eps=1e-15)
+    rasts, campos = [], []
+    for c in cams:
+        rasts.append(dgr.GaussianRasterizer(settings(dgr, c, dev)))
+        campos.append(c.camera_center)
+    g = torch.Generator(device=dev).manual_seed(1)
+    targets = [(torch.rand(3, H, W, device=dev, generator=g), torch.rand(1, H, W, device=dev, generator=g) * 0.3)
+               for _ in range(k)]
+    means2D = torch.zeros(scene.P, 3, device=dev, requires_grad=True)
+    raster_names = [n for n in names if n != "shs"]
+    cls = dgr._RasterizeGaussians
+    cls.grad_buffers = bucket.views
+
+    def step():
+        with torch.no_grad():
+            rgbs, clamps = dgr.sh_colors_batched(params["means3D"], params["shs"], 3, campos)
+        d_rgbs = []
+        for j, rast in enumerate(rasts):
+            cls.grad_accumulate = j > 0
+            rgb = rgbs[j].requires_grad_(True)
+            color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, colors_precomp=rgb,
+                                      opacities=params["opacities"], scales=params["scales"],
+                                      rotations=params["rotations"])
+            loss = (color - targets[j][0]).abs().mean() + 0.1 * (invd - targets[j][1]).abs().mean()
+            gr = torch.autograd.grad(loss, [params[n] for n in raster_names] + [means2D, rgb])
+            d_rgbs.append(gr[-1])
+        dgr.sh_colors_batched_backward(params["means3D"], params["shs"], 3, campos, clamps, d_rgbs,
+                                       bucket.views["shs"], bucket.views["means3D"])
+        opt.step(None)
+
+    try:
+        t = timed(step, args.warmup, args.steps)
+    finally:
+        cls.grad_buffers, cls.grad_accumulate = None, False
+    return dict(leg="training step (4 views fwd+bwd with L1 + inverse-depth loss, batched SH ends, fused Adam)",
+                gaussians=scene.P, image=[W, H], views_per_step=k, ms_per_step=t, steps_per_s=1e3 / t,
+                views_per_s=k * 1e3 / t)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--leaves", type=int, default=500_000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--legs", default="raw,lod,adam")
+    ap.add_argument("--legs", default="raw,lod,adam,train")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_next.py needs a GPU (no CPU fallback)")
     dev = torch.device("cuda:0")
     for name in args.legs.split(","):
-        res = {"raw": leg_raw, "lod": leg_lod, "adam": leg_adam}[name](args, dev)
+        res = {"raw": leg_raw, "lod": leg_lod, "adam": leg_adam, "train": leg_trainstep}[name](args, dev)
         print(json.dumps(res), flush=True)
 
 
