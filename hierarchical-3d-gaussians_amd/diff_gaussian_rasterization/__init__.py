@@ -42,10 +42,6 @@ class GaussianRasterizationSettings(NamedTuple):
     do_depth: bool = False
 
 
-def _empty_like_none(t):
-    return t if t is not None else torch.Tensor([])
-
-
 class _RasterizeGaussians(torch.autograd.Function):
     # Optional {input name: preallocated float32 GPU tensor}: when set, the backward writes the gradients of
     # the Gaussian parameters straight into these buffers (hgs.dp.GradBucket views) instead of fresh tensors.

@@ -9,7 +9,7 @@ znear 0.01 / zfar 100.  Everything is generated on the CPU from a
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 
 import numpy as np
 import torch

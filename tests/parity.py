@@ -9,8 +9,6 @@ pixels and gradients'):
     decision within 1e-5 (relative) of its threshold ("fragile": alpha vs 1/255, T vs 1e-4)
     are excluded from the pixel comparison; their count is bounded by FRAGILE_FRAC.
 """
-import math
-
 import numpy as np
 import torch
 

@@ -3,7 +3,6 @@
 import inspect
 import os
 
-import numpy as np
 import pytest
 import torch
 

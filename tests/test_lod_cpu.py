@@ -1,6 +1,5 @@
 """LOD-cut oracle + synthetic hierarchy generator: structural invariants (CPU)."""
 import numpy as np
-import torch
 
 from hgs import hierarchy, synth
 from oracle import lod_oracle as lo

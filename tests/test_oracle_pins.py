@@ -3,7 +3,6 @@ Python utilities (tests/golden/make_golden.py imports them from /root/reference)
 utils/sh_utils.py eval_sh, utils/general_utils.py build_rotation / build_scaling_rotation /
 strip_symmetric, utils/graphics_utils.py getWorld2View2 / getProjectionMatrix / geom_transform_points.
 These are the only numerical pins the reference offers for this path (it has no tests)."""
-import math
 import os
 
 import numpy as np

@@ -2,7 +2,6 @@
 and reads features_dc / features_rest separately.  Checked against the oracle driven through the activation spec
 (oracle.raster_oracle.activate_raw): indices bit-exact, pixels and gradients w.r.t. the RAW tensors <= 1e-5, and
 against the op's own standard path fed with torch-activated inputs."""
-import numpy as np
 import pytest
 import torch
 

@@ -9,7 +9,6 @@ the only place the reference's glue can be exercised.  For that purpose -- and o
 -- the extension-module layer (`diff_gaussian_rasterization._C`) is swapped for an oracle-backed
 stand-in and ``device="cuda"`` is mapped to the CPU.  The product package itself has no such path.
 """
-import math
 import os
 import sys
 import types

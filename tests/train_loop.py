@@ -4,8 +4,6 @@ normalised quaternions, sigmoid opacity, cat(dc, rest) SH), one camera per step 
 loss plus an inverse-depth L1 term (train_single.py:110-117, without the DSSIM term), Adam with per-group learning
 rates in the proportions of arguments/__init__.py:86-95, PSNR as utils/image_utils.py:17-19.
 """
-import math
-
 import torch
 
 from hgs import synth
