@@ -82,6 +82,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             call, color, invdepth, grad_color, grad_invdepth, out=cls.grad_buffers,
             accumulate=cls.grad_accumulate, defer_sh=defer)
         if getattr(call, "deferred", None) is not None:
+            if len(cls.pending_sh) >= 64:      # every pending view pins its workspaces
+                raise RuntimeError("64 views are waiting for finish_deferred_sh_backward(); call it once per step")
             cls.pending_sh.append(call)
         ctx.call = None
         # order: means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings
