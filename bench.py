@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--no-batched-sh-forward", action="store_true",
                     help="k > 1: evaluate the SH colours inside every view's rasterizer call instead of once per step "
                          "for all k views (then only the SH backward is batched, see --no-deferred-sh)")
+    ap.add_argument("--no-stream-overlap", action="store_true",
+                    help="enqueue the backwards on the forwards' stream (default: a second HIP stream, so that the "
+                         "HBM-bound stages of one view overlap with the ALU-bound compositing of the next)")
     ap.add_argument("--no-deferred-sh", action="store_true",
                     help="per-view SH backward (accumulating) instead of one batched pass per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -185,6 +188,10 @@ def main():
     # the backward writes (first view) / accumulates (later views) straight into the flat bucket
     bucket = dp.GradBucket({kk: tuple(v.shape) for kk, v in params.items()}, dev)
     dgr._RasterizeGaussians.grad_buffers = bucket.views
+    # forwards on the current stream, backwards on a second one: view j's backward (and its HBM-bound preprocess /
+    # gradient kernels) runs next to view j+1's forward
+    overlap = not args.no_stream_overlap
+    dgr._RasterizeGaussians.backward_stream = torch.cuda.Stream(device=dev) if overlap else None
     info = {"L": 0, "V": 0}
 
     # k > 1: the SH part of the k backwards (81 % of the gradient bytes) is left pending and done for all k views in one
@@ -213,6 +220,7 @@ def main():
             d_rgbs.append(g[-1])
         dgr.sh_colors_batched_backward(params["means3D"], params["shs"], scene.sh_degree, campos, clamps, d_rgbs,
                                        bucket.views["shs"], bucket.views["means3D"])
+        dgr.wait_backward_stream()
         if world > 1:
             bucket.all_reduce()
 
@@ -229,6 +237,7 @@ def main():
             torch.autograd.grad([color, invd], [params[kk] for kk in params] + [means2D], [gc, gd])
         if dgr._RasterizeGaussians.defer_sh_backward:
             dgr.finish_deferred_sh_backward()
+        dgr.wait_backward_stream()
         if world > 1:
             bucket.all_reduce()
 
@@ -292,6 +301,7 @@ def main():
                        "parallelism": f"per-view dp{world}, {k} views per rank per step accumulated in place" +
                                       (", SH backward batched over the views" if dgr._RasterizeGaussians.defer_sh_backward else "") +
                                       (", SH colours and their backward batched over the views" if sh_fwd else "") +
+                                      (", backwards on a second HIP stream" if overlap else "") +
                                       (", one RCCL all-reduce of the 59P-float grad bucket per step" if world > 1 else ""),
                        "render_variant": args.variant},
             "algorithmic_bytes_per_frame": total_bytes,

@@ -42,6 +42,41 @@ class GaussianRasterizationSettings(NamedTuple):
     do_depth: bool = False
 
 
+class _on_backward_stream:
+    """Context: run the enclosed backward on ``stream`` (None: no-op) -- it first waits for everything the current
+    stream holds, and every tensor of the forward that the backward kernels read is registered with the caching
+    allocator as in use on that stream."""
+
+    def __init__(self, stream, call, tensors):
+        self.stream, self.call, self.tensors = stream, call, tensors
+        self.ctx = None
+
+    def __enter__(self):
+        sb = self.stream
+        if sb is None:
+            return self
+        sb.wait_stream(torch.cuda.current_stream(sb.device))
+        c = self.call
+        for t in tuple(self.tensors) + (c.geom, c.binb, c.img, getattr(c, "scratch", None)) + tuple(c.keep):
+            if torch.is_tensor(t) and t.is_cuda:
+                t.record_stream(sb)
+        self.ctx = torch.cuda.stream(sb)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
+def wait_backward_stream():
+    """Make the current stream wait for the backwards enqueued on ``_RasterizeGaussians.backward_stream``."""
+    sb = _RasterizeGaussians.backward_stream
+    if sb is not None:
+        torch.cuda.current_stream(sb.device).wait_stream(sb)
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     # Optional {input name: preallocated float32 GPU tensor}: when set, the backward writes the gradients of
     # the Gaussian parameters straight into these buffers (hgs.dp.GradBucket views) instead of fresh tensors.
@@ -52,6 +87,11 @@ class _RasterizeGaussians(torch.autograd.Function):
     # the coefficients.  Until then the shs / means3D gradient buffers are incomplete.
     defer_sh_backward = False
     pending_sh = []
+    # Optional torch.cuda.Stream: every backward is enqueued there instead of on the forward's stream, after waiting for
+    # what the forward's stream holds at that moment.  In the usual loop (forward j, backward j, forward j+1, ...) the
+    # HBM-bound stages of one view then overlap with the ALU-bound compositing kernels of the next.  The returned
+    # gradients (and grad_buffers) are valid ON THAT STREAM: call wait_backward_stream() before using them elsewhere.
+    backward_stream = None
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -78,9 +118,10 @@ class _RasterizeGaussians(torch.autograd.Function):
             grad_color = torch.zeros_like(color)
         cls = _RasterizeGaussians
         defer = bool(cls.defer_sh_backward and cls.grad_buffers is not None)
-        d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(
-            call, color, invdepth, grad_color, grad_invdepth, out=cls.grad_buffers,
-            accumulate=cls.grad_accumulate, defer_sh=defer)
+        with _on_backward_stream(cls.backward_stream, call, (color, invdepth, grad_color, grad_invdepth)):
+            d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(
+                call, color, invdepth, grad_color, grad_invdepth, out=cls.grad_buffers,
+                accumulate=cls.grad_accumulate, defer_sh=defer)
         if getattr(call, "deferred", None) is not None:
             if len(cls.pending_sh) >= 64:      # every pending view pins its workspaces
                 raise RuntimeError("64 views are waiting for finish_deferred_sh_backward(); call it once per step")
@@ -131,7 +172,12 @@ def finish_deferred_sh_backward(accumulate=False):
     set: one pass over the SH coefficients for all of them (hgs_raster_sh_bwd_batched).  ``accumulate``: add to what
     the shs gradient buffer already holds instead of overwriting it."""
     pending, _RasterizeGaussians.pending_sh = _RasterizeGaussians.pending_sh, []
-    _C.sh_backward_batched(pending, accumulate=accumulate)
+    sb = _RasterizeGaussians.backward_stream
+    if sb is None:
+        _C.sh_backward_batched(pending, accumulate=accumulate)
+    else:                      # the pending views' backwards were enqueued there
+        with torch.cuda.stream(sb):
+            _C.sh_backward_batched(pending, accumulate=accumulate)
 
 
 def sh_colors_batched(means3D, shs, sh_degree, campos_list):
@@ -142,8 +188,17 @@ def sh_colors_batched(means3D, shs, sh_degree, campos_list):
 
 
 def sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D, accumulate=False):
-    return _C.sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D,
-                                         accumulate)
+    """Runs on ``_RasterizeGaussians.backward_stream`` when that is set (the d_rgbs were produced there)."""
+    sb = _RasterizeGaussians.backward_stream
+    if sb is None:
+        return _C.sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D,
+                                             accumulate)
+    sb.wait_stream(torch.cuda.current_stream(sb.device))
+    for t in tuple(clamps) + tuple(campos_list):
+        t.record_stream(sb)
+    with torch.cuda.stream(sb):
+        return _C.sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_rgbs, d_shs, d_means3D,
+                                             accumulate)
 
 
 def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_raw, scaling_raw, rotation_raw,
@@ -226,4 +281,5 @@ class GaussianRasterizer(nn.Module):
 
 
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_gaussians_raw",
-           "finish_deferred_sh_backward", "sh_colors_batched", "sh_colors_batched_backward", "_C"]
+           "finish_deferred_sh_backward", "sh_colors_batched", "sh_colors_batched_backward", "wait_backward_stream",
+           "_C"]
