@@ -33,7 +33,8 @@ def main():
     e_f = torch.empty(0, dtype=torch.float32, device=dev)
     bg = torch.zeros(3, device=dev)
     campos = [c.camera_center for c in cams]
-    sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    prio = {"nn": (0, 0), "hn": (-1, 0), "nh": (0, -1)}[os.environ.get("PROBE_PRIO", "nn")]
+    sA, sB = torch.cuda.Stream(device=dev, priority=prio[0]), torch.cuda.Stream(device=dev, priority=prio[1])
 
     def forward(j, rgb):
         c = cams[j]
@@ -71,6 +72,9 @@ def main():
         if two_streams:
             torch.cuda.current_stream(dev).wait_stream(fa)
             torch.cuda.current_stream(dev).wait_stream(fb)
+            if os.environ.get("PROBE_STEP_BARRIER", "1") == "1":
+                fa.wait_stream(fb)      # an optimiser update would sit here: the next step's forwards wait for this
+                                        # step's backwards (without it the probe overlaps across the step boundary)
 
     res = {}
     for mode in (False, True, False, True):
@@ -84,6 +88,7 @@ def main():
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / n
         res.setdefault("two_streams" if mode else "one_stream", []).append(k / dt)
+    res["prio_fwd_bwd"] = prio
     print(json.dumps(res))
 
 
