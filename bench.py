@@ -191,7 +191,7 @@ def main():
     # forwards on the current stream, backwards on a second one: view j's backward (and its HBM-bound preprocess /
     # gradient kernels) runs next to view j+1's forward
     overlap = not args.no_stream_overlap
-    dgr._RasterizeGaussians.backward_stream = torch.cuda.Stream(device=dev, priority=-1) if overlap else None
+    dgr._RasterizeGaussians.backward_stream = torch.cuda.Stream(device=dev) if overlap else None
     info = {"L": 0, "V": 0}
 
     # k > 1: the SH part of the k backwards (81 % of the gradient bytes) is left pending and done for all k views in one
