@@ -26,6 +26,10 @@ echo "== bench k=1"
 timeout 300 python bench.py --steps 30 --warmup 5 --views-per-step 1 --no-cpu-baseline > gpurun_out/bench_k1.json 2>> gpurun_out/bench.err; cat gpurun_out/bench_k1.json | head -c 400; echo
 echo "== bench_next (SURVEY 8f rows)"
 timeout 600 python scripts/bench_next.py > gpurun_out/bench_next.jsonl 2> gpurun_out/bench_next.err; echo "bench_next exit $?"; cat gpurun_out/bench_next.jsonl; tail -3 gpurun_out/bench_next.err
+echo "== rocprof, single-stream schedule (per-kernel times without co-running kernels)"
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_serial -o r01 -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-stage-timing --no-stream-overlap > /dev/null 2>&1; echo "rocprof serial exit $?"
+cd $GRAFT_REPO_ROOT
+python scripts/rocprof_summary.py $(ls gpurun_out/prof_serial/*.db | head -1) > gpurun_out/kernel_stats_serial.txt 2>/dev/null
 echo "== PMC summary"
 python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db SQ2=gpurun_out/pmc_SQ2/pmc_results.db F=gpurun_out/pmc_FETCH_SIZE/pmc_results.db W=gpurun_out/pmc_WRITE_SIZE/pmc_results.db > gpurun_out/pmc_summary.json 2>/dev/null; echo "pmc summary exit $?"
 python scripts/rocprof_summary.py $(ls gpurun_out/prof/*.db | head -1) > gpurun_out/kernel_stats.txt 2>/dev/null; head -25 gpurun_out/kernel_stats.txt
