@@ -190,7 +190,7 @@ def main():
     dgr._RasterizeGaussians.grad_buffers = bucket.views
     # forwards on the current stream, backwards on a second one: view j's backward (and its HBM-bound preprocess /
     # gradient kernels) runs next to view j+1's forward
-    overlap = not args.no_stream_overlap
+    overlap = not args.no_stream_overlap and k > 1      # one view per step: nothing to run next to
     dgr._RasterizeGaussians.backward_stream = torch.cuda.Stream(device=dev) if overlap else None
     info = {"L": 0, "V": 0}
 
