@@ -13,7 +13,9 @@ accumulated in place into one flat 59*P-float bucket.  The SH-dependent ends of 
 colours come from ONE pass over the coefficients (hgs_sh_colors_batched -- the HIP form of the reference's
 convert_SHs_python route, gaussian_renderer/__init__.py:84-89; the rasterizer then takes colors_precomp) and dL/dSH
 from ONE pass (hgs_sh_colors_batched_bwd); `--no-batched-sh-forward` evaluates SH inside every rasterizer call (then
-only the backward is batched), `--no-deferred-sh` nothing.  With N > 1 every rank renders different views of
+only the backward is batched), `--no-deferred-sh` nothing.  The backwards are enqueued on a second HIP stream
+(`--no-stream-overlap`: on the forwards' stream), so that the HBM-bound kernels of one view run next to the ALU-bound
+compositing kernels of the next; the step ends when both streams have drained.  With N > 1 every rank renders different views of
 the same replicated Gaussians and the step ends with ONE RCCL all-reduce of that bucket (per-view data
 parallelism with gradient accumulation).  The per-rank work is the same for every N
 (weak scaling); value = N * views_per_step * steps / max-over-ranks time.  The 236 MB all-reduce costs
