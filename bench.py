@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A step = one optimizer step's worth of rasterizer work on every rank: `--views-per-step` (default 4)
+A step = one optimizer step's worth of rasterizer work on every rank: `--views-per-step` (default 8)
 views, each a full GaussianRasterizer forward + backward through the C ABI (preprocess, binning, sorts,
 compositing, compositing backward, preprocess backward) with inputs resident in HBM, their gradients
 accumulated in place into one flat 59*P-float bucket.  The SH-dependent ends of the k views are batched: their
@@ -19,7 +19,8 @@ compositing kernels of the next; the step ends when both streams have drained.  
 the same replicated Gaussians and the step ends with ONE RCCL all-reduce of that bucket (per-view data
 parallelism with gradient accumulation).  The per-rank work is the same for every N
 (weak scaling); value = N * views_per_step * steps / max-over-ranks time.  The 236 MB all-reduce costs
-about as much as one view's compute on xGMI, hence the accumulation window (k = 1 is available).
+about as much as one view's compute on xGMI, hence the accumulation window (k = 1 is available; k = 8 keeps the
+exposed all-reduce near 13 % of a step at 8 GPUs and gives the two-stream schedule 7 overlapped view pairs per step).
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -122,7 +123,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--variant", type=int, default=0, help="render-kernel strip layout (0 = library default)")
-    ap.add_argument("--views-per-step", type=int, default=4,
+    ap.add_argument("--views-per-step", type=int, default=8,
                     help="views rendered (fwd+bwd) per rank between two gradient all-reduces")
     ap.add_argument("--no-batched-sh-forward", action="store_true",
                     help="k > 1: evaluate the SH colours inside every view's rasterizer call instead of once per step "
