@@ -580,7 +580,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
 
   float fly[4], Tr[4], bgd[4], g0[4], g1[4], g2[4], gd[4];
   uint32_t nc[4];
-  uint32_t maxnc = 0, minnc = 0xffffffffu;
+  uint32_t maxnc = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int py = py0 + 4 * s;
@@ -597,13 +597,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       nc[s] = n_contrib[pix];
     }
     maxnc = max(maxnc, nc[s]);
-    if (px < W && py < H) minnc = min(minnc, nc[s]);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
-    minnc = min(minnc, (uint32_t)__shfl_xor((int)minnc, off, 64));     // below it no pixel needs the n_contrib gate
-  }
+  for (int off = 32; off > 0; off >>= 1) maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
   if (maxnc == 0) return;
   BwdPair P0, P1;
   P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
@@ -653,20 +649,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
       // cheapest exit first: no pixel of the tile passes the alpha threshold (one max tree + one compare)
       if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) continue;
-      bool c0 = pw0.x >= thr, c1 = pw0.y >= thr, c2 = pw1.x >= thr, c3 = pw1.y >= thr;
-      bool b0, b1;                                                              // wave-uniform
-      if (rel < minnc) {
-        // every pixel of the tile was still open when the forward reached this Gaussian: no per-pixel gate, and the
-        // pair ballots come from a max + one compare each
-        b0 = __ballot(fmaxf(pw0.x, pw0.y) >= thr) != 0;
-        b1 = __ballot(fmaxf(pw1.x, pw1.y) >= thr) != 0;
-      } else {
-        c0 = c0 && (rel < P0.nc0); c1 = c1 && (rel < P0.nc1);
-        c2 = c2 && (rel < P1.nc0); c3 = c3 && (rel < P1.nc1);
-        b0 = __ballot(c0 || c1) != 0;
-        b1 = __ballot(c2 || c3) != 0;
-        if (!(b0 || b1)) continue;   // candidates only on pixels that had stopped before this Gaussian
-      }
+      const bool c0 = (pw0.x >= thr) && (rel < P0.nc0), c1 = (pw0.y >= thr) && (rel < P0.nc1);
+      const bool c2 = (pw1.x >= thr) && (rel < P1.nc0), c3 = (pw1.y >= thr) && (rel < P1.nc1);
+      const bool b0 = __ballot(c0 || c1) != 0, b1 = __ballot(c2 || c3) != 0;   // wave-uniform
+      if (!(b0 || b1)) continue;   // candidates only on pixels that had stopped before this Gaussian
       BwdSums S;
       S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
       uint64_t any_blend = 0;
