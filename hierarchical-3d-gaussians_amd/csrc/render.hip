@@ -516,8 +516,7 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);   // = blended by the forward
   const bool live1 = c1 && (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
-  const uint64_t lm = __ballot(live0 || live1);
-  if (lm == 0) return 0;
+  // (no wave-level "nobody live" exit: the candidate test already is the alpha test up to its 1e-3 guard band)
   // non-live lanes take part with alpha = 0: identity for T, for the A recurrence and for every sum
   const f2 ae = {live0 ? alpha.x : 0.0f, live1 ? alpha.y : 0.0f};
   const f2 oma = 1.0f - ae;
@@ -545,7 +544,7 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   p.A = An;
   p.la = ae;
   p.lq = q;
-  return lm;
+  return 1;
 }
 
 __device__ __forceinline__ float swap32_add(float a, float b) {   // [a.lo+a.hi | b.lo+b.hi]
