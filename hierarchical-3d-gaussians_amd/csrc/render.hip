@@ -650,7 +650,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) continue;
       const bool c0 = (pw0.x >= thr) && (rel < P0.nc0), c1 = (pw0.y >= thr) && (rel < P0.nc1);
       const bool c2 = (pw1.x >= thr) && (rel < P1.nc0), c3 = (pw1.y >= thr) && (rel < P1.nc1);
-      const bool b0 = __ballot(c0 || c1) != 0, b1 = __ballot(c2 || c3) != 0;   // wave-uniform
+      // wave-uniform "pair has a candidate": ballots of the PLAIN compares (one v_cmp each, the mask lands in scalar
+      // registers) combined with scalar and / or -- a ballot of the combined predicate costs two more vector
+      // instructions per pair
+      const bool b0 = ((__ballot(pw0.x >= thr) & __ballot(rel < P0.nc0)) | (__ballot(pw0.y >= thr) & __ballot(rel < P0.nc1))) != 0;
+      const bool b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
       if (!(b0 || b1)) continue;   // candidates only on pixels that had stopped before this Gaussian
       BwdSums S;
       S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
