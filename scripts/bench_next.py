@@ -232,6 +232,7 @@ def leg_trainstep(args, dev):
     raster_names = [n for n in names if n != "shs"]
     cls = dgr._RasterizeGaussians
     cls.grad_buffers = bucket.views
+    cls.backward_stream = torch.cuda.Stream(device=dev)     # backwards next to the following view's forward + loss
 
     def step():
         with torch.no_grad():
@@ -248,13 +249,14 @@ def leg_trainstep(args, dev):
             d_rgbs.append(gr[-1])
         dgr.sh_colors_batched_backward(params["means3D"], params["shs"], 3, campos, clamps, d_rgbs,
                                        bucket.views["shs"], bucket.views["means3D"])
+        dgr.wait_backward_stream()
         opt.step(None)
 
     try:
         t = timed(step, args.warmup, args.steps)
     finally:
-        cls.grad_buffers, cls.grad_accumulate = None, False
-    return dict(leg="training step (4 views fwd+bwd with L1 + inverse-depth loss, batched SH ends, fused Adam)",
+        cls.grad_buffers, cls.grad_accumulate, cls.backward_stream = None, False, None
+    return dict(leg="training step (4 views fwd+bwd with L1 + inverse-depth loss, batched SH ends, two streams, fused Adam)",
                 gaussians=scene.P, image=[W, H], views_per_step=k, ms_per_step=t, steps_per_s=1e3 / t,
                 views_per_s=k * 1e3 / t)
 
