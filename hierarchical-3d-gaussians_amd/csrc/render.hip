@@ -361,13 +361,14 @@ struct FwdPair {
 };
 
 template <bool DEPTH>
-__device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, bool c0, bool c1, const float4& q1,
+__device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const float4& q1,
                                               const float4& q2, uint32_t idx1) {
   const f2 G = {fast_exp2(pw.x), fast_exp2(pw.y)};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-  const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);
-  const bool live1 = c1 && (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
+  // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band)
+  const bool live0 = (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);
+  const bool live1 = (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
   const f2 Tn = p.T * (1.0f - alpha);
   const bool stop0 = live0 && (Tn.x < kTEps), stop1 = live1 && (Tn.y < kTEps);
   const bool blend0 = live0 && !stop0, blend1 = live1 && !stop1;
@@ -449,10 +450,9 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       const float m0 = fmaxf(pw0.x, pw0.y), m1 = fmaxf(pw1.x, pw1.y);
       if (__ballot(fmaxf(m0, m1) >= thr) == 0) continue;
       const bool b0 = __ballot(m0 >= thr) != 0, b1 = __ballot(m1 >= thr) != 0;   // wave-uniform
-      const bool c0 = pw0.x >= thr, c1 = pw0.y >= thr, c2 = pw1.x >= thr, c3 = pw1.y >= thr;
       const uint32_t idx1 = base - r0 + j + 1;
-      if (b0) fwd_pair_live<DEPTH>(P0, pw0, c0, c1, q1, q2, idx1);
-      if (b1) fwd_pair_live<DEPTH>(P1, pw1, c2, c3, q1, q2, idx1);
+      if (b0) fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
+      if (b1) fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
     }
     // every pixel saturated?  (finished pixels sit at y = kBig: the rest of a batch costs them only the
     // no-candidate path above)
