@@ -75,3 +75,41 @@ def test_hier_roundtrip(tmp_path):
     trunc.write_bytes(open(path, "rb").read()[:200])
     with pytest.raises(RuntimeError, match="truncated"):
         load_hierarchy(str(trunc))
+
+
+def test_opt_in_fast_paths_fail_loudly_on_cpu_tensors():
+    """The opt-in entry points (raw-parameter path, batched SH colours, fused Adam) have no CPU path either."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    cam = synth.make_camera(32, 32)
+    sc = synth.make_scene(8, cam)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dgr.sh_colors_batched(sc.means3D, sc.shs, 3, [cam.camera_center])
+    from hgs.optim import Adam
+    p = torch.nn.Parameter(torch.zeros(4, 3))
+    p.grad = torch.ones(4, 3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        Adam([p], lr=1e-3).step(None)
+    with pytest.raises(NotImplementedError):
+        Adam([p], lr=1e-3, amsgrad=True)
+    e_i, e_f = torch.empty(0, dtype=torch.int32), torch.empty(0)
+    rs = dgr.GaussianRasterizationSettings(
+        image_height=32, image_width=32, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=torch.zeros(3),
+        scale_modifier=1.0, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+        campos=cam.camera_center, prefiltered=False, debug=False, do_depth=True, render_indices=e_i,
+        parent_indices=e_i, interpolation_weights=e_f, num_node_kids=e_i)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        dgr.GaussianRasterizer(rs).forward_raw(sc.means3D, torch.zeros(8, 3), sc.shs[:, :1].contiguous(),
+                                               sc.shs[:, 1:].contiguous(), sc.opacities, sc.scales, sc.rotations)
+    with pytest.raises(RuntimeError, match="unknown opacity_activation"):
+        dgr.GaussianRasterizer(rs).forward_raw(sc.means3D, torch.zeros(8, 3), sc.shs[:, :1].contiguous(),
+                                               sc.shs[:, 1:].contiguous(), sc.opacities, sc.scales, sc.rotations,
+                                               opacity_activation="tanh")
+
+
+def test_stream_and_deferral_switches_default_off():
+    cls = dgr._RasterizeGaussians
+    assert cls.backward_stream is None and cls.defer_sh_backward is False and cls.grad_buffers is None
+    assert cls.grad_accumulate is False and cls.pending_sh == []
+    dgr.wait_backward_stream()              # no-op without a backward stream
+    dgr.finish_deferred_sh_backward()       # no-op without pending views
