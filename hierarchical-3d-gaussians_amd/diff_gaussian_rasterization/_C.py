@@ -316,9 +316,12 @@ def sh_colors_batched(means3D, shs, sh_degree, campos_list):
     dev = means3D.device
     rgbs = [torch.empty(P, 3, dtype=torch.float32, device=dev) for _ in campos_list]
     clamps = [torch.empty(P, dtype=torch.uint8, device=dev) for _ in campos_list]
-    arr, keep = _color_views(campos_list, rgbs, clamps, None)
-    _lib.check(_lib.lib().hgs_sh_colors_batched(arr, len(campos_list), P, M, int(sh_degree), _lib.ptr(means3D),
-                                                _lib.ptr(shs), _stream(dev), dev.index or 0), "hgs_sh_colors_batched")
+    B = _lib.MAX_DEFERRED_VIEWS
+    for i in range(0, len(campos_list), B):          # more views than one launch takes: one pass per group of 8
+        arr, keep = _color_views(campos_list[i:i + B], rgbs[i:i + B], clamps[i:i + B], None)
+        _lib.check(_lib.lib().hgs_sh_colors_batched(arr, len(arr), P, M, int(sh_degree), _lib.ptr(means3D),
+                                                    _lib.ptr(shs), _stream(dev), dev.index or 0),
+                   "hgs_sh_colors_batched")
     return rgbs, clamps
 
 
@@ -330,11 +333,13 @@ def sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_r
     d_rgbs = [g.to(torch.float32).contiguous() for g in d_rgbs]
     for t, name in ((d_shs, "d_shs"), (d_means3D, "d_means3D")):
         _require_gpu(t, name)
-    arr, keep = _color_views(campos_list, None, clamps, d_rgbs)
-    _lib.check(_lib.lib().hgs_sh_colors_batched_bwd(arr, len(campos_list), P, M, int(sh_degree), _lib.ptr(means3D),
-                                                    _lib.ptr(shs), _lib.ptr(d_shs), _lib.ptr(d_means3D),
-                                                    int(bool(accumulate)), _stream(dev), dev.index or 0),
-               "hgs_sh_colors_batched_bwd")
+    B = _lib.MAX_DEFERRED_VIEWS
+    for i in range(0, len(campos_list), B):
+        arr, keep = _color_views(campos_list[i:i + B], None, clamps[i:i + B], d_rgbs[i:i + B])
+        _lib.check(_lib.lib().hgs_sh_colors_batched_bwd(arr, len(arr), P, M, int(sh_degree), _lib.ptr(means3D),
+                                                        _lib.ptr(shs), _lib.ptr(d_shs), _lib.ptr(d_means3D),
+                                                        int(bool(accumulate or i > 0)), _stream(dev), dev.index or 0),
+                   "hgs_sh_colors_batched_bwd")
 
 
 def raster_views(call):
