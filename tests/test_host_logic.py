@@ -113,3 +113,23 @@ def test_stream_and_deferral_switches_default_off():
     assert cls.grad_accumulate is False and cls.pending_sh == []
     dgr.wait_backward_stream()              # no-op without a backward stream
     dgr.finish_deferred_sh_backward()       # no-op without pending views
+
+
+def test_bench_byte_model_is_consistent():
+    """bench.py's algorithmic byte model: every stage positive, the batched-SH variants move strictly fewer bytes
+    per view than the per-view model, and the headline figure is reproduced (1.25 GB-scale per frame at 1 M / 1080p)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    P, L, N, T, M = 1_000_000, 2_665_270, 1920 * 1080, 8160, 16
+    base = bench.algorithmic_bytes(P, P, L, N, T, M)
+    assert all(v >= 0 for v in base.values()) and 1.5e9 < sum(base.values()) < 2.0e9
+    k = 8
+    per_step = ("sh_bwd_batched", "sh_colors_batched")
+    frame = lambda ab: sum(v for n, v in ab.items() if n not in per_step) + sum(ab.get(n, 0) for n in per_step) / k
+    deferred = bench.algorithmic_bytes(P, P, L, N, T, M, k=k, deferred_sh=True)
+    both = bench.algorithmic_bytes(P, P, L, N, T, M, k=k, deferred_sh=True, sh_forward=True)
+    assert frame(both) < frame(deferred) < frame(base)
+    assert both["preprocess_fwd"] < base["preprocess_fwd"] and "sh_colors_batched" in both
