@@ -571,7 +571,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   }
 
   // accumulate_grads: add to what the buffers hold (gradient accumulation over several views of one optimizer
-  // step); dL/dmeans2D is a per-view statistic and is always overwritten
+  // step); dL/dmeans2D (a per-view statistic) and dL/dcolors_precomp (the gradient of a view's colours) are always
+  // overwritten
   constexpr bool acc = ACC;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   out.dL_dopacity[idx] = d_op + (acc ? out.dL_dopacity[idx] : 0.f);
   if (out.dL_dcolors) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) out.dL_dcolors[idx * 3 + j] = d_col[j] + (acc ? out.dL_dcolors[idx * 3 + j] : 0.f);
+    for (int j = 0; j < 3; ++j) out.dL_dcolors[idx * 3 + j] = d_col[j];   // per view, like dL/dmeans2D: never accumulated
   }
   if (out.dL_dscales) {
 #pragma unroll

@@ -13,19 +13,20 @@ from hgs import _lib
 
 
 def _require_gpu(t: torch.Tensor, name: str):
+    """Device / dtype checks; returns the tensor made contiguous (a sliced or expanded input, e.g. an override_color
+    broadcast, is copied once -- the upstream extension calls .contiguous() on its inputs in the same way)."""
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA/HIP tensor (got {t.device}); this op has no CPU path")
     if t.dtype != torch.float32:
         raise RuntimeError(f"{name} must be float32 (got {t.dtype})")
-    if not t.is_contiguous():
-        raise RuntimeError(f"{name} must be contiguous")
+    return t.contiguous()
 
 
 def _opt(t, name, P, inner):
-    """None for an absent/empty optional input, else the validated tensor."""
+    """None for an absent/empty optional input, else the validated (contiguous) tensor."""
     if t is None or t.numel() == 0:
         return None
-    _require_gpu(t, name)
+    t = _require_gpu(t, name)
     if t.shape[0] != P or t.numel() != P * inner:
         raise RuntimeError(f"{name} has shape {tuple(t.shape)}, expected [{P}, ...] with {inner} values per Gaussian")
     return t
@@ -61,23 +62,24 @@ class _Call:
     __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device", "scratch", "deferred")
 
 
-# Instance count of the previous forward per device: lets the next forward size its binning workspace
-# speculatively (1.25 x) and enqueue the whole pipeline without waiting for the host (hgs_raster_fwd).
+# Instance count of the previous forward per (device, width, height, Gaussians): lets the next forward of the same
+# shape size its binning workspace speculatively (1.25 x) and enqueue the whole pipeline without waiting for the host
+# (hgs_raster_fwd).  A render at another resolution (the viewer's, train_single.py:76-78) has its own entry.
 _last_L = {}
 SPECULATIVE = True
 
 
 def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                 viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
-                debug, interpolation_weights, num_node_kids, do_depth, variant=0, sh_rest=None, activations=0):
-    _require_gpu(means3D, "means3D")
+                debug, interpolation_weights, num_node_kids, do_depth, sh_rest=None, activations=0):
+    means3D = _require_gpu(means3D, "means3D")
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     P = means3D.shape[0]
     if sh is not None and sh.numel() == 0:
         sh = None
     if sh is not None:
-        _require_gpu(sh, "shs")
+        sh = _require_gpu(sh, "shs")
         if sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3:
             raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
     colors = _opt(colors, "colors_precomp", P, 3)
@@ -85,7 +87,7 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     rotations = _opt(rotations, "rotations", P, 4)
     cov3D_precomp = _opt(cov3D_precomp, "cov3D_precomp", P, 6)
     if P > 0:
-        _require_gpu(opacity, "opacities")
+        opacity = _require_gpu(opacity, "opacities")
         if opacity.numel() != P:
             raise RuntimeError(f"opacities must hold {P} values")
         if (sh is None) == (colors is None):
@@ -98,7 +100,7 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
         sh_rest = None
     if sh_rest is not None:
         # raw-parameter path: sh = features_dc [P,1,3], sh_rest = features_rest [P,M-1,3]
-        _require_gpu(sh_rest, "shs_rest")
+        sh_rest = _require_gpu(sh_rest, "shs_rest")
         if sh is None or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P or sh_rest.shape[2] != 3:
             raise RuntimeError("split SH storage needs features_dc (num_points, 1, 3) and features_rest (num_points, M-1, 3)")
         M = 1 + sh_rest.shape[1]
@@ -111,7 +113,7 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     a.P, a.M, a.sh_degree = P, M, int(degree)
     a.width, a.height = int(image_width), int(image_height)
     a.tanfovx, a.tanfovy, a.scale_modifier = float(tanfovx), float(tanfovy), float(scale_modifier)
-    a.do_depth, a.debug, a.variant, a.accumulate_grads = int(bool(do_depth)), int(bool(debug)), int(variant), 0
+    a.do_depth, a.debug, a.accumulate_grads = int(bool(do_depth)), int(bool(debug)), 0
     p = _lib.ptr
     a.bg, a.viewmatrix, a.projmatrix, a.campos = p(bg), p(vm), p(pm), p(cp)
     a.means3D, a.shs, a.colors_precomp, a.opacities = p(means3D), p(sh), p(colors), p(opacity)
@@ -129,7 +131,7 @@ def _stream(device):
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                        num_node_kids, do_depth, variant=0, sh_rest=None, activations=0, prepare_backward=False):
+                        num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False):
     """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
     invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward.  ``prepare_backward``: allocate
     the backward's scratch now and let the forward's compositing kernel zero-fill it on the side
@@ -142,7 +144,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     a, keep, P, M = _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
                                 image_width, sh, degree, campos, debug, interpolation_weights, num_node_kids,
-                                do_depth, variant, sh_rest, activations)
+                                do_depth, sh_rest, activations)
     dev = means3D.device
     H, W = int(image_height), int(image_width)
     u8 = dict(dtype=torch.uint8, device=dev)
@@ -160,7 +162,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     binb = None
     scratch = None
     L_ws = 0
-    prev = _last_L.get(devi) if SPECULATIVE else None
+    shape_key = (devi, W, H, P)
+    prev = _last_L.get(shape_key) if SPECULATIVE else None
     if prev is not None and P > 0:
         # no-bubble path: everything is enqueued before the host learns L
         L_ws = int(prev * 1.25) + 65536
@@ -190,7 +193,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
-    _last_L[devi] = L.value
+    if len(_last_L) > 64:
+        _last_L.clear()
+    _last_L[shape_key] = L.value
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
@@ -228,7 +233,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
         return torch.empty(*shape, **f32)
 
     d_m3 = buf("means3D", (P, 3))
-    d_m2 = torch.empty(P, 3, **f32)
+    d_m2 = buf("means2D", (P, 3))
     d_op = buf("opacities", (P, 1))
     d_sh = buf("shs", tuple(sh.shape)) if sh is not None else None
     d_shr = buf("shs_rest", tuple(sh_rest.shape)) if sh_rest is not None else None
@@ -310,8 +315,8 @@ def sh_colors_batched(means3D, shs, sh_degree, campos_list):
     """Colours of the same Gaussians seen from several cameras, one pass over the SH coefficients: the batched HIP
     form of the reference's convert_SHs_python branch (gaussian_renderer/__init__.py:84-89).  Returns (rgbs, clamps):
     per view a [P,3] float32 tensor to pass as ``colors_precomp`` and the uint8 clamp mask the backward needs."""
-    _require_gpu(means3D, "means3D")
-    _require_gpu(shs, "shs")
+    means3D = _require_gpu(means3D, "means3D")
+    shs = _require_gpu(shs, "shs")
     P, M = means3D.shape[0], shs.shape[1]
     dev = means3D.device
     rgbs = [torch.empty(P, 3, dtype=torch.float32, device=dev) for _ in campos_list]
@@ -331,8 +336,10 @@ def sh_colors_batched_backward(means3D, shs, sh_degree, campos_list, clamps, d_r
     P, M = means3D.shape[0], shs.shape[1]
     dev = means3D.device
     d_rgbs = [g.to(torch.float32).contiguous() for g in d_rgbs]
-    for t, name in ((d_shs, "d_shs"), (d_means3D, "d_means3D")):
-        _require_gpu(t, name)
+    means3D, shs = _require_gpu(means3D, "means3D"), _require_gpu(shs, "shs")
+    for t, name in ((d_shs, "d_shs"), (d_means3D, "d_means3D")):     # written in place
+        if _require_gpu(t, name) is not t:
+            raise RuntimeError(f"{name} must be contiguous (it is written in place)")
     B = _lib.MAX_DEFERRED_VIEWS
     for i in range(0, len(campos_list), B):
         arr, keep = _color_views(campos_list[i:i + B], None, clamps[i:i + B], d_rgbs[i:i + B])
@@ -372,7 +379,7 @@ def raster_views(call):
 
 def mark_visible(means3D, viewmatrix, projmatrix):
     """Frustum test used by the upstream API (z > 0.2 in view space)."""
-    _require_gpu(means3D, "means3D")
+    means3D = _require_gpu(means3D, "means3D")
     vm = viewmatrix.to(torch.float32)
     z = means3D @ vm[:3, 2] + vm[3, 2]
     return z > 0.2
@@ -396,7 +403,7 @@ def lod_gather(render_indices, parent_indices, weights, means3D, scales, rotatio
         if t is None:
             ins.append(None); outs.append(None)
             continue
-        _require_gpu(t, name)
+        t = _require_gpu(t, name)
         ins.append(t)
         outs.append(torch.empty((n,) + tuple(t.shape[1:]), dtype=torch.float32, device=dev))
     M = shs.shape[1] if shs is not None else 0

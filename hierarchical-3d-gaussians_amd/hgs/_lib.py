@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 INST_GRAD_STRIDE = 12
 ERR_CAPACITY = 5
 
@@ -22,7 +22,7 @@ class RasterArgs(C.Structure):
         ("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32),
         ("width", C.c_int32), ("height", C.c_int32),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
-        ("do_depth", C.c_int32), ("debug", C.c_int32), ("variant", C.c_int32), ("accumulate_grads", C.c_int32),
+        ("do_depth", C.c_int32), ("debug", C.c_int32), ("accumulate_grads", C.c_int32),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),

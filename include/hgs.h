@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 2
+#define HGS_ABI_VERSION 3
 #define HGS_TILE 16
 #define HGS_INST_GRAD_STRIDE 12 /* floats per (tile, Gaussian) instance in the backward scratch */
 
@@ -71,8 +71,9 @@ typedef struct hgs_raster_args {
   float scale_modifier;
   int32_t do_depth;   /* write the inverse-depth channel */
   int32_t debug;      /* synchronise + check after every launch */
-  int32_t variant;    /* 0 = library default; >0 selects a render-kernel variant (bench/tuning only) */
-  int32_t accumulate_grads; /* backward: add into the gradient buffers instead of overwriting them */
+  int32_t accumulate_grads; /* backward: add into the gradient buffers instead of overwriting them (accumulation over
+                             * the views of one optimizer step); dL_dmeans2D and dL_dcolors are per-view quantities
+                             * and are always overwritten */
   const float* bg;          /* device [3] */
   const float* viewmatrix;  /* device [16] */
   const float* projmatrix;  /* device [16] */

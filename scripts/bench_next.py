@@ -222,40 +222,35 @@ def leg_trainstep(args, dev):
         params[n].grad = bucket.views[n]
     opt = Adam([dict(params=[params[n]], lr=lrs[n], name=n) for n in names], lr=0.0, eps=1e-15)
     rasts, campos = [], []
+    m2_grad = torch.empty(scene.P, 3, device=dev)
+    d_rgbs = [torch.empty(scene.P, 3, device=dev) for _ in cams]
+    rc = dgr.RasterContext(grad_buffers=dict(bucket.views, means2D=m2_grad),
+                           backward_stream=torch.cuda.Stream(device=dev))   # backwards next to the following view's forward + loss
     for c in cams:
-        rasts.append(dgr.GaussianRasterizer(settings(dgr, c, dev)))
+        rasts.append(dgr.GaussianRasterizer(settings(dgr, c, dev), context=rc))
         campos.append(c.camera_center)
     g = torch.Generator(device=dev).manual_seed(1)
     targets = [(torch.rand(3, H, W, device=dev, generator=g), torch.rand(1, H, W, device=dev, generator=g) * 0.3)
                for _ in range(k)]
     means2D = torch.zeros(scene.P, 3, device=dev, requires_grad=True)
-    raster_names = [n for n in names if n != "shs"]
-    cls = dgr._RasterizeGaussians
-    cls.grad_buffers = bucket.views
-    cls.backward_stream = torch.cuda.Stream(device=dev)     # backwards next to the following view's forward + loss
 
     def step():
         with torch.no_grad():
             rgbs, clamps = dgr.sh_colors_batched(params["means3D"], params["shs"], 3, campos)
-        d_rgbs = []
         for j, rast in enumerate(rasts):
-            cls.grad_accumulate = j > 0
-            rgb = rgbs[j].requires_grad_(True)
-            color, radii, invd = rast(means3D=params["means3D"], means2D=means2D, colors_precomp=rgb,
-                                      opacities=params["opacities"], scales=params["scales"],
-                                      rotations=params["rotations"])
+            rc.grad_accumulate = j > 0
+            rc.grad_buffers["colors_precomp"] = d_rgbs[j]
+            color, radii, invd = rast(means3D=params["means3D"], means2D=means2D,
+                                      colors_precomp=rgbs[j].requires_grad_(True), opacities=params["opacities"],
+                                      scales=params["scales"], rotations=params["rotations"])
             loss = (color - targets[j][0]).abs().mean() + 0.1 * (invd - targets[j][1]).abs().mean()
-            gr = torch.autograd.grad(loss, [params[n] for n in raster_names] + [means2D, rgb])
-            d_rgbs.append(gr[-1])
-        dgr.sh_colors_batched_backward(params["means3D"], params["shs"], 3, campos, clamps, d_rgbs,
-                                       bucket.views["shs"], bucket.views["means3D"])
-        dgr.wait_backward_stream()
+            loss.backward()                                  # every gradient lands in a buffer
+        rc.sh_colors_batched_backward(params["means3D"], params["shs"], 3, campos, clamps, d_rgbs,
+                                      bucket.views["shs"], bucket.views["means3D"])
+        rc.wait_backward_stream()
         opt.step(None)
 
-    try:
-        t = timed(step, args.warmup, args.steps)
-    finally:
-        cls.grad_buffers, cls.grad_accumulate, cls.backward_stream = None, False, None
+    t = timed(step, args.warmup, args.steps)
     return dict(leg="training step (4 views fwd+bwd with L1 + inverse-depth loss, batched SH ends, two streams, fused Adam)",
                 gaussians=scene.P, image=[W, H], views_per_step=k, ms_per_step=t, steps_per_s=1e3 / t,
                 views_per_s=k * 1e3 / t)

@@ -60,9 +60,8 @@ def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=Non
 
 
 def run_hip(scene, cam, bg, gc, gd, device, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
-            interpolation_weights=None, num_node_kids=None, do_depth=True, variant=0, debug=True):
+            interpolation_weights=None, num_node_kids=None, do_depth=True, debug=True):
     import diff_gaussian_rasterization as dgr
-    dgr._RasterizeGaussians.variant = variant
     req = lambda t: None if t is None else t.clone().to(device).requires_grad_(True)
     m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
     sh = req(scene.shs) if colors_precomp is None else None
@@ -91,7 +90,6 @@ def run_hip(scene, cam, bg, gc, gd, device, *, colors_precomp=None, cov3D_precom
     if col is not None: grads["colors_precomp"] = col.grad
     if sc is not None: grads["scales"] = sc.grad; grads["rotations"] = rot.grad
     if cov is not None: grads["cov3D_precomp"] = cov.grad
-    dgr._RasterizeGaussians.variant = 0
     return dict(color=color.detach().cpu(), radii=radii.cpu(), invdepth=invd.detach().cpu(), views=views_cpu, L=L,
                 grads={k: v.detach().cpu() for k, v in grads.items()})
 

@@ -107,12 +107,19 @@ def test_opt_in_fast_paths_fail_loudly_on_cpu_tensors():
                                                opacity_activation="tanh")
 
 
-def test_stream_and_deferral_switches_default_off():
+def test_training_loop_extras_live_on_a_context_object():
+    """grad_buffers / backward_stream / deferred SH backward are per RasterContext, never process-global state on the
+    autograd class (two models or a viewer render in one process must not share them)."""
     cls = dgr._RasterizeGaussians
-    assert cls.backward_stream is None and cls.defer_sh_backward is False and cls.grad_buffers is None
-    assert cls.grad_accumulate is False and cls.pending_sh == []
-    dgr.wait_backward_stream()              # no-op without a backward stream
-    dgr.finish_deferred_sh_backward()       # no-op without pending views
+    for name in ("grad_buffers", "grad_accumulate", "defer_sh_backward", "pending_sh", "backward_stream", "variant"):
+        assert not hasattr(cls, name), name
+    a, b = dgr.RasterContext(), dgr.RasterContext(defer_sh_backward=True)
+    assert a.grad_buffers is None and a.backward_stream is None and a.defer_sh_backward is False
+    assert a.grad_accumulate is False and a.pending_sh == [] and a.pending_sh is not b.pending_sh
+    a.wait_backward_stream()              # no-op without a backward stream
+    a.finish_deferred_sh_backward()       # no-op without pending views
+    rs = dgr.GaussianRasterizationSettings(*([None] * 16))
+    assert dgr.GaussianRasterizer(rs).context is None and dgr.GaussianRasterizer(rs, context=b).context is b
 
 
 def test_bench_byte_model_is_consistent():

@@ -18,7 +18,7 @@ def test_documented_ctypes_binding_renders_the_same_image(gpu):
         _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("width", C.c_int32),
                     ("height", C.c_int32), ("tanfovx", C.c_float), ("tanfovy", C.c_float),
                     ("scale_modifier", C.c_float), ("do_depth", C.c_int32), ("debug", C.c_int32),
-                    ("variant", C.c_int32), ("accumulate_grads", C.c_int32)] + \
+                    ("accumulate_grads", C.c_int32)] + \
                    [(n, C.c_void_p) for n in ("bg", "viewmatrix", "projmatrix", "campos", "means3D", "shs",
                     "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp",
                     "interpolation_weights", "num_node_kids", "shs_rest")] + \

@@ -28,7 +28,7 @@ class _OracleC:
     def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                             viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
                             prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                            num_node_kids, do_depth, variant=0, sh_rest=None, activations=0, prepare_backward=False):
+                            num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False):
         from oracle import raster_oracle as ro
         assert render_indices.numel() == 0 and parent_indices.numel() == 0
         ins = dict(means3D=means3D, shs=sh, colors_precomp=colors, opacities=opacity, scales=scales,
