@@ -1,8 +1,9 @@
 // K9 (expand_to_size) and K10 (get_interpolation_weights): the per-view hierarchy LOD cut.
 //
 // Replaces gaussian_hierarchy._C.expand_to_size / get_interpolation_weights
-// (train_post.py:91-113, render_hierarchy.py:58-80; reference source absent, semantics
-// in oracle/lod_oracle.py and DESIGN.md).  Top-down frontier expansion: work is
+// (train_post.py:91-113, render_hierarchy.py:58-80; the reference checkout does not vendor the submodule that
+// implements them -- semantics restated in include/hgs.h, oracle/lod_oracle.py and DESIGN.md section 4).
+// Top-down frontier expansion: work is
 // proportional to the nodes ABOVE the cut, not to the hierarchy size; the only
 // full-size pass is the flag compaction (4 B per node), which also makes the output
 // order deterministic (ascending node index) despite the atomic frontier appends.
@@ -51,11 +52,14 @@ __global__ __launch_bounds__(256) void lod_expand_level_kernel(const int32_t* __
     const int32_t* nd = nodes + (size_t)n * kNodeInts;
     const int nch = nd[6];
     const float s = node_size(boxes, n, vp);
-    if (s > tau && nch > 0) {
-      const uint32_t base = atomicAdd(count_out, (uint32_t)nch);
-      const int c0 = nd[5];
-      for (int k = 0; k < nch; ++k) fout[base + k] = c0 + k;
-    } else {
+    if (s >= tau) {            // too coarse for this view: only the Gaussians no child stands for, then the children
+      emit_cnt[n] = (uint32_t)nd[3];
+      if (nch > 0) {
+        const uint32_t base = atomicAdd(count_out, (uint32_t)nch);
+        const int c0 = nd[5];
+        for (int k = 0; k < nch; ++k) fout[base + k] = c0 + k;
+      }
+    } else {                   // fine enough (and its parent was not): the node as a whole
       emit_cnt[n] = (uint32_t)(nd[3] + nd[4]);
     }
   }
@@ -151,12 +155,18 @@ __global__ __launch_bounds__(256) void lod_weights_kernel(const int32_t* __restr
   float w = 1.0f;
   int kids = 1;
   if (par >= 0) {
-    const float sp = node_size(boxes, par, vp);
+    // restated from the public gaussian-hierarchy source (not vendored in the reference checkout): the transition
+    // runs while the parent's size falls from 2 tau to tau
+    const float two_tau = 2.0f * tau;
+    float sp = node_size(boxes, par, vp);
+    if (sp > two_tau) sp = two_tau;
     const float sn = node_size(boxes, nd, vp);
     kids = nodes[(size_t)par * kNodeInts + 6];
-    if (sp < kFltMax && sp > sn) {
-      const float t = (sp - tau) / (sp - sn);
-      w = fminf(1.0f, fmaxf(0.0f, t));
+    const float start = fmaxf(0.5f * sp, sn);
+    const float diff = sp - start;
+    if (diff > 0.0f) {
+      const float tdiff = fmaxf(0.0f, tau - start);
+      w = fmaxf(1.0f - tdiff / diff, 0.0f);
     }
   }
   weights[i] = w;

@@ -113,7 +113,8 @@ def write_hierarchy(path: str, xyz, shs, alpha, log_scales, rots, nodes, boxes) 
     if a_nodes.size != N * 7 or a_boxes.size != N * 8:
         raise RuntimeError("write_hierarchy: nodes must be [N,7] and boxes [N,2,4]")
     h = _lib.HierHost()
-    h.P, h.N, h.M, h.reserved = P, N, M, 0
+    # the upstream tools' layout whenever it can express the data (16 SH coefficients), else the private one
+    h.P, h.N, h.M, h.reserved = P, N, M, (_lib.HIER_UPSTREAM if M == 16 else _lib.HIER_PRIVATE)
     vp = lambda a: a.ctypes.data_as(C.c_void_p)
     h.xyz, h.shs, h.alpha, h.log_scales, h.rots = vp(a_xyz), vp(a_shs), vp(a_alpha), vp(a_sc), vp(a_rot)
     h.nodes, h.boxes = vp(a_nodes), vp(a_boxes)

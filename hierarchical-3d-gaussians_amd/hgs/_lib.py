@@ -63,6 +63,7 @@ class ShColorView(C.Structure):
 
 
 MAX_DEFERRED_VIEWS = 8
+HIER_UPSTREAM, HIER_PRIVATE, HIER_UPSTREAM_HALF = 0, 1, 2
 
 
 class AdamTensor(C.Structure):

@@ -276,3 +276,70 @@ def build_hierarchy_on_device(P, cam, device, seed=0, sh_degree=3, s_px=(0.5, 4.
     boxes[:, 0, 3] = (bmax - bmin).max(1).values
     return Hierarchy(xyz=mu, shs=sh, alpha=op[:, None].contiguous(), log_scales=scales.log(), rots=rots, nodes=nodes,
                      boxes=boxes)
+
+
+def merge_hierarchies(chunks) -> Hierarchy:
+    """Several per-chunk hierarchies under one common root -- the shape the reference's GaussianHierarchyMerger
+    produces from its chunks (scripts/full_train.py:240-250; BASELINE config 3 'merged 2-chunk toy hierarchy').
+    New numbering: node 0 = the new root, nodes 1..k = the chunks' roots (contiguous children of the new root), then
+    every chunk's remaining nodes in their own order, so children stay contiguous and 'Gaussian index == node index'
+    still holds.  The new root's Gaussian is the moment-matched merge of the chunk roots (weights alpha * volume) with
+    an axis-aligned covariance; its box is the union.  Works on whatever device the chunks live on."""
+    k = len(chunks)
+    assert k >= 1
+    dev = chunks[0].nodes.device
+    sizes = [int(c.num_nodes) for c in chunks]
+    bases, b = [], 1 + k
+    for n in sizes:
+        bases.append(b)
+        b += n - 1
+    N = b
+
+    def remap(c, ids):           # old node id of chunk c -> new id (negative ids stay negative)
+        out = torch.where(ids == 0, torch.full_like(ids, 1 + c), ids + (bases[c] - 1))
+        return torch.where(ids < 0, ids, out)
+
+    new_of = [remap(c, torch.arange(sizes[c], device=dev, dtype=torch.int64)) for c in range(k)]
+    perm = torch.empty(N, dtype=torch.int64, device=dev)         # new id -> row of the concatenated chunk arrays
+    offs = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    for c in range(k):
+        perm[new_of[c]] = torch.arange(sizes[c], device=dev, dtype=torch.int64) + int(offs[c])
+    perm[0] = 0                                                   # placeholder row, overwritten below
+    cat = lambda name: torch.cat([getattr(c, name) for c in chunks])[perm].clone()
+    xyz, shs, alpha, log_scales, rots = (cat(n) for n in ("xyz", "shs", "alpha", "log_scales", "rots"))
+    boxes = cat("boxes")
+    nodes = torch.zeros(N, 7, dtype=torch.int32, device=dev)
+    for c, ch in enumerate(chunks):
+        nd = ch.nodes.to(torch.int64)
+        ids = new_of[c]
+        row = torch.stack([nd[:, 0] + 1,                                              # one level deeper
+                           torch.where(nd[:, 1] < 0, torch.zeros_like(nd[:, 1]), remap(c, nd[:, 1])),
+                           ids, nd[:, 3], nd[:, 4],
+                           torch.where(nd[:, 6] > 0, remap(c, nd[:, 5]), torch.zeros_like(nd[:, 5])), nd[:, 6]], 1)
+        nodes[ids] = row.to(torch.int32)
+    nodes[0] = torch.tensor([0, -1, 0, 0, 1, 1, k], dtype=torch.int32, device=dev)
+    # the new root's Gaussian and box
+    r = torch.arange(1, 1 + k, device=dev)
+    sc = log_scales[r].double().exp()
+    w = (alpha[r, 0].double() * sc.prod(1)).clamp_min(1e-30)
+    f = (w / w.sum())[:, None]
+    m = (f * xyz[r].double()).sum(0)
+    # axis-aligned second moments of the children: diag(R diag(s^2) R^T) + spread of the means
+    q = rots[r].double()
+    q = q / q.norm(dim=1, keepdim=True)
+    qr, qx, qy, qz = q.unbind(1)
+    R = torch.stack([1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qr * qz), 2 * (qx * qz + qr * qy),
+                     2 * (qx * qy + qr * qz), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qr * qx),
+                     2 * (qx * qz - qr * qy), 2 * (qy * qz + qr * qx), 1 - 2 * (qx * qx + qy * qy)], 1).reshape(-1, 3, 3)
+    var = ((R * R) * (sc ** 2)[:, None, :]).sum(2)
+    var = (f * (var + (xyz[r].double() - m) ** 2)).sum(0)
+    xyz[0] = m.float()
+    log_scales[0] = var.clamp_min(1e-12).sqrt().log().float()
+    rots[0] = torch.tensor([1.0, 0.0, 0.0, 0.0], device=dev)
+    shs[0] = (f[:, :, None] * shs[r].double()).sum(0).float()
+    alpha[0, 0] = float((f[:, 0] * alpha[r, 0].double()).sum().clamp(0.0, 1.0))
+    boxes[0, 0, :3] = boxes[r, 0, :3].min(0).values
+    boxes[0, 1, :3] = boxes[r, 1, :3].max(0).values
+    boxes[0, 0, 3] = (boxes[0, 1, :3] - boxes[0, 0, :3]).max()
+    boxes[0, 1, 3] = 0.0
+    return Hierarchy(xyz=xyz, shs=shs, alpha=alpha, log_scales=log_scales, rots=rots, nodes=nodes, boxes=boxes)

@@ -238,6 +238,13 @@ int hgs_timing_read(double* ms_out, uint32_t* calls_out, int reset);
  * get_interpolation_weights (train_post.py:91-113, render_hierarchy.py:58-80).
  *   nodes int32 [N,7] = depth,parent,start,count_leafs,count_merged,start_children,count_children
  *   boxes f32  [N,2,4] = min.xyz + extent, max.xyz + pad
+ * size(n, v) = extent(n) / dist(v, AABB(n)), FLT_MAX for v inside the box.
+ * Cut (top-down from the root): a reached node with size >= tau is too coarse -- its count_leafs own Gaussians
+ * [start, start + count_leafs) are drawn and its children are reached; a reached node with size < tau is drawn as
+ * a whole (count_leafs + count_merged Gaussians from start).  parent index = nodes[parent].start (own index at the
+ * root).  Output in ascending node order.
+ * Weight of a cut node: 1 at the root; else with p = min(size(parent), 2 tau), s0 = max(p / 2, size(n)):
+ * t = 1 if p <= s0, else max(1 - max(0, tau - s0) / (p - s0), 0); num_siblings = count_children of the parent.
  * ------------------------------------------------------------------------- */
 size_t hgs_expand_tmp_bytes(int32_t N);
 /* Fills render_indices / parent_indices / nodes_for_render_indices (device, capacity
@@ -308,11 +315,17 @@ int hgs_dist2_knn3(const float* xyz, int32_t P, float* out_mean_d2, void* tmp,
  * .hier files.  Replaces gaussian_hierarchy._C.load_hierarchy / write_hierarchy
  * (scene/gaussian_model.py:329,420-427).  Host memory only.
  * ------------------------------------------------------------------------- */
+enum {
+  HGS_HIER_UPSTREAM = 0,      /* header-less layout of the gaussian-hierarchy tools: int P, pos, rot, log-scale, alpha,
+                               * sh[16][3], int N, nodes, boxes (restated from the public repository; see hier_io.cpp) */
+  HGS_HIER_PRIVATE = 1,       /* "HGSHIER1" + P, N, M: any SH count */
+  HGS_HIER_UPSTREAM_HALF = 2  /* upstream layout with P < 0: rot / scale / alpha / sh stored as IEEE half (read only) */
+};
 typedef struct hgs_hier_host {
   int32_t P;      /* Gaussians */
   int32_t N;      /* nodes */
   int32_t M;      /* SH coefficients per Gaussian (16) */
-  int32_t reserved;
+  int32_t reserved; /* layout: hgs_hier_write takes HGS_HIER_UPSTREAM or HGS_HIER_PRIVATE; hgs_hier_load reports what it found */
   float* xyz;         /* [P,3] */
   float* shs;         /* [P,M,3] */
   float* alpha;       /* [P] activated opacity */

@@ -15,16 +15,22 @@ restated here is fixed by the call sites and by the consumer's semantics:
 * render_hierarchy.py:55-56 -- the threshold is a tangent-space angular size
   (``(2 tau + 1)`` pixels).
 
-Data model (documented in DESIGN.md, '.hier layout'):
+Data model (documented in DESIGN.md, section 4; the node record and the box layout are those of the public
+gaussian-hierarchy repository, which the reference checkout does not vendor):
   nodes  int32 [N,7]  = (depth, parent, start, count_leafs, count_merged,
                          start_children, count_children); root is node 0 with
-                         parent -1; children of a node are contiguous.
+                         parent -1; children of a node are contiguous.  A node's Gaussians are
+                         [start, start + count_leafs) leaves it holds itself, then count_merged merged ones.
   boxes  f32 [N,2,4]  = [n,0,:3] AABB min, [n,1,:3] AABB max,
                         [n,0,3] node extent (world units), [n,1,3] unused.
-  size(n, v) = extent(n) / dist(v, AABB(n)); +inf (FLT_MAX) when v is inside.
-Cut: top-down from the root; a visited node with size > tau and children is
-replaced by its children, otherwise it is emitted.  Output is ordered by
-ascending node index (then by Gaussian offset inside the node).
+  size(n, v) = extent(n) / dist(v, AABB(n)); FLT_MAX when v is inside.
+Cut: top-down from the root.  A reached node with size >= tau is too coarse: its count_leafs own Gaussians are
+drawn and its children are reached; a reached node with size < tau is drawn as a whole (leafs + merged).  With
+sizes that shrink from parent to child this equals the per-node test "size < tau <= size(parent)" of the upstream
+tools.  Output is ordered by ascending node index (then by Gaussian offset inside the node).
+Weight t of a cut node (1 = the node itself, 0 = looks like its parent): 1 at the root; else with
+p = min(size(parent), 2 tau) and s0 = max(p / 2, size(n)): t = 1 if p <= s0 else max(1 - max(0, tau - s0)/(p - s0), 0)
+-- the transition runs while the parent's size falls from 2 tau to tau.
 """
 from __future__ import annotations
 
@@ -53,24 +59,25 @@ def expand_to_size(nodes, boxes, size, viewpoint, viewdir=None):
     boxes = np.asarray(boxes, dtype=np.float32)
     tau = F(size)
     N = nodes.shape[0]
-    selected = np.zeros(N, dtype=bool)
+    count = np.zeros(N, dtype=np.int64)
     frontier = np.array([0], dtype=np.int64) if N else np.zeros(0, dtype=np.int64)
     while frontier.size:
         s = node_size(boxes, frontier, viewpoint)
         nchild = nodes[frontier, 6]
-        expand = (s > tau) & (nchild > 0)
-        selected[frontier[~expand]] = True
-        ex = frontier[expand]
+        coarse = s >= tau
+        count[frontier[coarse]] = nodes[frontier[coarse], 3]
+        count[frontier[~coarse]] = nodes[frontier[~coarse], 3] + nodes[frontier[~coarse], 4]
+        ex = frontier[coarse & (nchild > 0)]
         if ex.size == 0:
             break
         starts = nodes[ex, 5].astype(np.int64)
         cnts = nodes[ex, 6].astype(np.int64)
         frontier = np.concatenate([np.arange(a, a + c) for a, c in zip(starts, cnts)])
-    sel = np.nonzero(selected)[0]
+    sel = np.nonzero(count)[0]
     r, p, nn = [], [], []
     for n in sel:
         start = int(nodes[n, 2])
-        cnt = int(nodes[n, 3] + nodes[n, 4])
+        cnt = int(count[n])
         par = int(nodes[n, 1])
         pg = int(nodes[par, 2]) if par >= 0 else -1
         for k in range(cnt):
@@ -89,12 +96,14 @@ def get_interpolation_weights(node_indices, size, nodes, boxes, viewpoint, viewd
     par = nodes[ni, 1].astype(np.int64)
     has_par = par >= 0
     ps = np.where(has_par, par, 0)
-    sp = node_size(boxes, ps, viewpoint)
+    two_tau = F(2.0) * tau
+    sp = np.minimum(node_size(boxes, ps, viewpoint), two_tau)
     sn = node_size(boxes, ni, viewpoint)
+    start = np.maximum(F(0.5) * sp, sn)
+    diff = sp - start
+    tdiff = np.maximum(F(0.0), tau - start)
     with np.errstate(divide="ignore", invalid="ignore"):
-        w = (sp - tau) / (sp - sn)
-    w = np.minimum(F(1.0), np.maximum(F(0.0), w))
-    degenerate = (~has_par) | (sp >= FLT_MAX) | ~(sp > sn)
-    w = np.where(degenerate, F(1.0), w).astype(np.float32)
+        t = np.maximum(F(1.0) - tdiff / diff, F(0.0))
+    w = np.where(has_par & (diff > F(0.0)), t, F(1.0)).astype(np.float32)
     kids = np.where(has_par, nodes[ps, 6], 1).astype(np.int32)
     return w, kids

@@ -14,10 +14,14 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s -> %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 typedef float f2 __attribute__((ext_vector_type(2)));
-enum Kind { FMA = 0, PK_FMA, PK_MUL, EXP, RCP, CNDMASK, DPP_ADD, PERMLANE_SWAP, MIX_K7, NKIND };
+enum Kind { FMA = 0, PK_FMA, PK_MUL, EXP, RCP, CNDMASK, DPP_ADD, PERMLANE_SWAP, MIX_K7, CMP_VCC, CMP_SGPR, CND_SGPR_MIX, FMA_CND_MIX,
+            FMA_CMP_MIX, MAXF, FMA_CLAMP, PK_ADD, MOV, NKIND };
 static const char* kNames[NKIND] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32", "v_exp_f32", "v_rcp_f32",
                                     "v_cndmask_b32", "v_add_f32 row_shr:1 (DPP)", "v_permlane32_swap",
-                                    "K7 mix (8 pk_fma : 2 exp : 2 rcp : 4 cndmask : 16 fma)"};
+                                    "K7 mix (8 pk_fma : 2 exp : 2 rcp : 4 cndmask : 16 fma)",
+                                    "v_cmp_ge_f32 -> vcc", "v_cmp_ge_f32_e64 -> s[n:n+1]",
+                                    "1 v_cndmask_e64 (sgpr mask) : 3 v_fma", "1 v_cndmask (vcc) : 3 v_fma",
+                                    "1 v_cmp_e64 -> sgpr : 3 v_fma", "v_max_f32", "v_fma_f32 clamp", "v_pk_add_f32", "v_mov_b32"};
 
 #define REP4(x) x x x x
 #define REP8(x) REP4(x) REP4(x)
@@ -65,6 +69,44 @@ __global__ __launch_bounds__(256) void issue_kernel(float* out, uint64_t* cycles
       REP4(asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
                         "v_permlane32_swap_b32 %1, %2\n v_permlane32_swap_b32 %3, %4\n v_permlane32_swap_b32 %5, %6\n v_permlane32_swap_b32 %7, %0\n"
                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+    } else if (KIND == CMP_VCC) {
+      REP4(asm volatile("v_cmp_ge_f32 vcc, %0, %8\n v_cmp_ge_f32 vcc, %1, %8\n v_cmp_ge_f32 vcc, %2, %8\n v_cmp_ge_f32 vcc, %3, %8\n"
+                        "v_cmp_ge_f32 vcc, %4, %8\n v_cmp_ge_f32 vcc, %5, %8\n v_cmp_ge_f32 vcc, %6, %8\n v_cmp_ge_f32 vcc, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x) : "vcc");)
+    } else if (KIND == CMP_SGPR) {
+      REP4(asm volatile("v_cmp_ge_f32_e64 s[20:21], %0, %8\n v_cmp_ge_f32_e64 s[22:23], %1, %8\n v_cmp_ge_f32_e64 s[24:25], %2, %8\n v_cmp_ge_f32_e64 s[26:27], %3, %8\n"
+                        "v_cmp_ge_f32_e64 s[28:29], %4, %8\n v_cmp_ge_f32_e64 s[30:31], %5, %8\n v_cmp_ge_f32_e64 s[32:33], %6, %8\n v_cmp_ge_f32_e64 s[34:35], %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x)
+                        : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35");)
+    } else if (KIND == CND_SGPR_MIX) {
+      REP4(asm volatile("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_cndmask_b32_e64 %4, %4, %8, s[22:23]\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+    } else if (KIND == FMA_CND_MIX) {
+      REP4(asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_cndmask_b32 %4, %4, %8, vcc\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y) : "vcc");)
+    } else if (KIND == FMA_CMP_MIX) {
+      REP4(asm volatile("v_cmp_ge_f32_e64 s[20:21], %0, %8\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                        "v_cmp_ge_f32_e64 s[22:23], %4, %8\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y)
+                        : "s20", "s21", "s22", "s23");)
+    } else if (KIND == MAXF) {
+      REP4(asm volatile("v_max_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_max_f32 %2, %2, %8\n v_max_f32 %3, %3, %8\n"
+                        "v_max_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_max_f32 %6, %6, %8\n v_max_f32 %7, %7, %8\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x));)
+    } else if (KIND == FMA_CLAMP) {
+      REP4(asm volatile("v_fma_f32 %0, %0, %8, %9 clamp\n v_fma_f32 %1, %1, %8, %9 clamp\n v_fma_f32 %2, %2, %8, %9 clamp\n v_fma_f32 %3, %3, %8, %9 clamp\n"
+                        "v_fma_f32 %4, %4, %8, %9 clamp\n v_fma_f32 %5, %5, %8, %9 clamp\n v_fma_f32 %6, %6, %8, %9 clamp\n v_fma_f32 %7, %7, %8, %9 clamp\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(x), "v"(y));)
+    } else if (KIND == PK_ADD) {
+      REP4(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                        "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                        : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(px));)
+    } else if (KIND == MOV) {
+      REP4(asm volatile("v_mov_b32 %0, %1\n v_mov_b32 %1, %2\n v_mov_b32 %2, %3\n v_mov_b32 %3, %4\n"
+                        "v_mov_b32 %4, %5\n v_mov_b32 %5, %6\n v_mov_b32 %6, %7\n v_mov_b32 %7, %0\n"
+                        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
     } else {   // the instruction mix of K7's live path, 32 instructions
       asm volatile("v_pk_fma_f32 %8, %8, %16, %17\n v_pk_fma_f32 %9, %9, %16, %17\n v_pk_fma_f32 %10, %10, %16, %17\n v_pk_fma_f32 %11, %11, %16, %17\n"
                    "v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n"
@@ -88,7 +130,7 @@ __global__ __launch_bounds__(256) void issue_kernel(float* out, uint64_t* cycles
 template <int KIND>
 static int run(float* out, uint64_t* cyc, int cus, hipEvent_t a, hipEvent_t b) {
   const int iters = 4096;
-  for (int wps : {1, 2, 3, 4, 5, 6, 8}) {
+  for (int wps : {1, 2, 4, 5, 8}) {
     // one workgroup of 256 lanes = one wave on each of a CU's four SIMDs; wps workgroups per CU
     const int blocks = cus * wps;
     float best = 1e9f;
@@ -132,5 +174,14 @@ int main() {
   if (run<DPP_ADD>(out, cyc, cus, a, b)) return 1;
   if (run<PERMLANE_SWAP>(out, cyc, cus, a, b)) return 1;
   if (run<MIX_K7>(out, cyc, cus, a, b)) return 1;
+  if (run<CMP_VCC>(out, cyc, cus, a, b)) return 1;
+  if (run<CMP_SGPR>(out, cyc, cus, a, b)) return 1;
+  if (run<CND_SGPR_MIX>(out, cyc, cus, a, b)) return 1;
+  if (run<FMA_CND_MIX>(out, cyc, cus, a, b)) return 1;
+  if (run<FMA_CMP_MIX>(out, cyc, cus, a, b)) return 1;
+  if (run<MAXF>(out, cyc, cus, a, b)) return 1;
+  if (run<FMA_CLAMP>(out, cyc, cus, a, b)) return 1;
+  if (run<PK_ADD>(out, cyc, cus, a, b)) return 1;
+  if (run<MOV>(out, cyc, cus, a, b)) return 1;
   return 0;
 }

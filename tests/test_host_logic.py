@@ -69,12 +69,58 @@ def test_hier_roundtrip(tmp_path):
         load_hierarchy(str(tmp_path / "missing.hier"))
     bad = tmp_path / "bad.hier"
     bad.write_bytes(b"NOTAHIER" + b"\0" * 64)
-    with pytest.raises(RuntimeError, match="HGSHIER1"):
+    with pytest.raises(RuntimeError, match="neither an upstream .hier file"):
         load_hierarchy(str(bad))
     trunc = tmp_path / "trunc.hier"
     trunc.write_bytes(open(path, "rb").read()[:200])
-    with pytest.raises(RuntimeError, match="truncated"):
+    with pytest.raises(RuntimeError, match="neither an upstream .hier file"):
         load_hierarchy(str(trunc))
+
+
+def test_hier_upstream_layout_bytes(tmp_path):
+    """The default on-disk layout is the header-less one of the upstream gaussian-hierarchy tools (int P, pos, rot,
+    log-scale, alpha, sh[16][3], int N, nodes[7], boxes[2][4]) -- checked byte for byte against a file assembled here
+    with numpy, in both directions; the half-precision variant (P < 0) is read; other SH counts use the private
+    layout."""
+    import numpy as np
+    from gaussian_hierarchy._C import load_hierarchy, write_hierarchy
+    rng = np.random.default_rng(0)
+    P, N = 5, 3
+    pos, rot = rng.normal(size=(P, 3)).astype("<f4"), rng.normal(size=(P, 4)).astype("<f4")
+    ls, al = rng.normal(size=(P, 3)).astype("<f4"), rng.random((P, 1)).astype("<f4")
+    sh = rng.normal(size=(P, 16, 3)).astype("<f4")
+    nodes = rng.integers(-1, 9, size=(N, 7)).astype("<i4")
+    boxes = rng.normal(size=(N, 2, 4)).astype("<f4")
+    blob = b"".join([np.int32(P).tobytes(), pos.tobytes(), rot.tobytes(), ls.tobytes(), al.tobytes(), sh.tobytes(),
+                     np.int32(N).tobytes(), nodes.tobytes(), boxes.tobytes()])
+    up = tmp_path / "upstream.hier"
+    up.write_bytes(blob)
+    got = load_hierarchy(str(up))
+    for a, b in zip(got, (pos, sh, al, ls, rot, nodes, boxes)):
+        assert np.array_equal(a.numpy(), b)
+    mine = tmp_path / "mine.hier"
+    write_hierarchy(str(mine), *(torch.from_numpy(np.ascontiguousarray(t)) for t in (pos, sh, al, ls, rot, nodes, boxes)))
+    assert mine.read_bytes() == blob
+    # half-precision variant: P stored negative, everything but the positions as IEEE half
+    h16 = lambda t: t.astype("<f2").tobytes()
+    half = tmp_path / "half.hier"
+    half.write_bytes(b"".join([np.int32(-P).tobytes(), pos.tobytes(), h16(rot), h16(ls), h16(al), h16(sh),
+                               np.int32(N).tobytes(), nodes.tobytes(), boxes.tobytes()]))
+    got = load_hierarchy(str(half))
+    assert np.array_equal(got[0].numpy(), pos) and np.array_equal(got[5].numpy(), nodes)
+    for a, b in zip((got[1], got[2], got[3], got[4]), (sh, al, ls, rot)):
+        assert np.array_equal(a.numpy(), b.astype("<f2").astype("<f4"))
+    # a size that does not add up is rejected (there is no magic to go by)
+    (tmp_path / "odd.hier").write_bytes(blob + b"\0")
+    with pytest.raises(RuntimeError, match="declared sizes do not match"):
+        load_hierarchy(str(tmp_path / "odd.hier"))
+    # 4 SH coefficients (a degree-1 model): private layout, still round-trips
+    sh4 = torch.from_numpy(np.ascontiguousarray(sh[:, :4]))
+    p4 = tmp_path / "m4.hier"
+    write_hierarchy(str(p4), torch.from_numpy(pos), sh4, torch.from_numpy(al), torch.from_numpy(ls),
+                    torch.from_numpy(rot), torch.from_numpy(nodes), torch.from_numpy(boxes))
+    assert p4.read_bytes()[:8] == b"HGSHIER1"
+    assert torch.equal(load_hierarchy(str(p4))[1], sh4)
 
 
 def test_opt_in_fast_paths_fail_loudly_on_cpu_tensors():
