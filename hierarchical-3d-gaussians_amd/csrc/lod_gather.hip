@@ -37,6 +37,9 @@ __global__ __launch_bounds__(256) void lod_gather_kernel(const int32_t* __restri
                                                          const int32_t* __restrict__ parent_indices,
                                                          const float* __restrict__ weights, int n, int M,
                                                          LodPtrs in, LodOut out) {
+  // contraction off: w * a + u * b rounds exactly like the reference glue's torch expression t * x[r] + (1 - t) * x[p]
+  // (two rounded products, one rounded sum), so the in-op path feeds the rasterizer bit-identical rows
+#pragma clang fp contract(off)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const size_t r = (size_t)render_indices[i], p = (size_t)parent_indices[i];
@@ -55,9 +58,21 @@ __global__ __launch_bounds__(256) void lod_gather_kernel(const int32_t* __restri
     float4 b = reinterpret_cast<const float4*>(in.rots)[p];
     const float dot = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
     const float sgn = dot < 0.0f ? -1.0f : 1.0f;
-    reinterpret_cast<float4*>(out.rots)[i] = make_float4(w * a.x + u * sgn * b.x, w * a.y + u * sgn * b.y,
-                                                         w * a.z + u * sgn * b.z, w * a.w + u * sgn * b.w);
+    b.x *= sgn; b.y *= sgn; b.z *= sgn; b.w *= sgn;      // exact
+    reinterpret_cast<float4*>(out.rots)[i] = make_float4(w * a.x + u * b.x, w * a.y + u * b.y,
+                                                         w * a.z + u * b.z, w * a.w + u * b.w);
   }
+}
+
+// w * a + u * b with every operation rounded on its own (see lod_gather_kernel)
+__device__ __forceinline__ float lerp_rounded(float a, float b, float w, float u) {
+#pragma clang fp contract(off)
+  const float x = w * a, y = u * b;
+  return x + y;
+}
+__device__ __forceinline__ float4 lerp_rounded(float4 a, float4 b, float w, float u) {
+  return make_float4(lerp_rounded(a.x, b.x, w, u), lerp_rounded(a.y, b.y, w, u), lerp_rounded(a.z, b.z, w, u),
+                     lerp_rounded(a.w, b.w, w, u));
 }
 
 // SH rows (3M floats, 192 B at M = 16) are moved by their own kernels with one lane per 16-byte (or 4-byte) chunk:
@@ -68,13 +83,14 @@ __global__ __launch_bounds__(256) void lod_gather_sh_kernel(const int32_t* __res
                                                             const int32_t* __restrict__ parent_indices,
                                                             const float* __restrict__ weights, int n, int cpr,
                                                             const V* __restrict__ in, V* __restrict__ out) {
+#pragma clang fp contract(off)
   const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= (size_t)n * cpr) return;
   const int i = (int)(e / cpr), c = (int)(e - (size_t)i * cpr);
   const float w = weights[i], u = 1.0f - w;
   const V a = in[(size_t)render_indices[i] * cpr + c];
   const V b = in[(size_t)parent_indices[i] * cpr + c];
-  out[e] = w * a + u * b;
+  out[e] = lerp_rounded(a, b, w, u);
 }
 
 __global__ __launch_bounds__(256) void lod_monotone_kernel(const int32_t* __restrict__ parent_indices, int n,

@@ -44,12 +44,13 @@ class Adam(Optimizer):
         super().__init__(params, defaults)
 
     # -- one fused launch per <= ADAM_MAX_TENSORS tensors with the same row count -------------------------------
-    def _collect(self):
+    def _collect(self, only=None):
         todo = []
+        only = None if only is None else {id(p) for p in only}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or (only is not None and id(p) not in only):
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients")
@@ -113,9 +114,11 @@ class Adam(Optimizer):
         return loss
 
     @torch.no_grad()
-    def step_masked(self, row_grad):
-        """Update row r of every parameter iff row_grad.flatten()[r] != 0 (train_single.py:171 without nonzero())."""
+    def step_masked(self, row_grad, params=None):
+        """Update row r of every parameter iff row_grad.flatten()[r] != 0 (train_single.py:171 without nonzero()).
+        ``params``: restrict the step to these parameters (a step may be issued in several parts, e.g. while the rest of
+        a gradient all-reduce is still on the wire; every parameter must be stepped exactly once per optimizer step)."""
         mask = row_grad.reshape(-1)
         if not mask.is_cuda or mask.dtype != torch.float32:
             raise RuntimeError("row_grad must be a float32 GPU tensor")
-        self._launch(self._collect(), None, mask.contiguous())
+        self._launch(self._collect(params), None, mask.contiguous())

@@ -1,0 +1,97 @@
+"""Synthetic COLMAP scene + hierarchy on disk for the acceptance harness -- TEST FIXTURE.
+
+    <dir>/sparse/0/cameras.txt   one PINHOLE camera
+    <dir>/sparse/0/images.txt    n views on a small circle, COLMAP world->camera poses (qw qx qy qz tx ty tz)
+    <dir>/sparse/0/points3D.ply  the Gaussians' centres as an SfM point cloud (x y z nx ny nz red green blue)
+    <dir>/images/view_XX.png     the 'ground truth': oracle renders of the same Gaussians
+    <dir>/chunks.hier            two chunk hierarchies (left / right half of the points) merged under one root, in the
+                                 upstream .hier layout, written by gaussian_hierarchy._C.write_hierarchy
+Everything is seeded; the images are rendered with the CPU oracle (test infrastructure)."""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+for p in (ROOT, os.path.join(ROOT, "hierarchical-3d-gaussians_amd"), os.path.join(ROOT, "tests", "shims")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def rotmat2qvec(R):
+    """COLMAP's convention (w, x, y, z); same formula as scene/colmap_loader.py:277-291."""
+    Rxx, Ryx, Rzx, Rxy, Ryy, Rzy, Rxz, Ryz, Rzz = R.flat
+    K = np.array([[Rxx - Ryy - Rzz, 0, 0, 0], [Ryx + Rxy, Ryy - Rxx - Rzz, 0, 0],
+                  [Rzx + Rxz, Rzy + Ryz, Rzz - Rxx - Ryy, 0], [Ryz - Rzy, Rzx - Rxz, Rxy - Ryx, Rxx + Ryy + Rzz]]) / 3.0
+    vals, vecs = np.linalg.eigh(K)
+    q = vecs[[3, 0, 1, 2], np.argmax(vals)]
+    return -q if q[0] < 0 else q
+
+
+def make(path, n_points=240, n_views=6, W=64, H=48, seed=0, hier=True):
+    from PIL import Image
+    from plyfile import PlyData, PlyElement
+    from hgs import hierarchy, synth
+    from oracle import raster_oracle as ro
+    os.makedirs(os.path.join(path, "sparse", "0"), exist_ok=True)
+    os.makedirs(os.path.join(path, "images"), exist_ok=True)
+    base = synth.make_camera(W, H)
+    scene = synth.make_scene(n_points, base, seed=seed, s_px=(1.0, 4.0), z_range=(3.0, 8.0))
+    fx = W / (2 * base.tanfovx)
+    fy = H / (2 * base.tanfovy)
+    with open(os.path.join(path, "sparse", "0", "cameras.txt"), "w") as f:
+        f.write("# Camera list with one line of data per camera:\n")
+        f.write(f"1 PINHOLE {W} {H} {fx:.9f} {fy:.9f} {W / 2:.4f} {H / 2:.4f}\n")
+    lines = ["# Image list with two lines of data per image:\n"]
+    bg = torch.zeros(3)
+    for k in range(n_views):
+        ang = 2 * math.pi * k / n_views
+        c = np.array([0.4 * math.cos(ang), 0.3 * math.sin(ang), 0.0])
+        yaw, pitch = 0.04 * math.cos(ang), 0.04 * math.sin(ang)
+        Ry = np.array([[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]])
+        Rx = np.array([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]])
+        Rc2w = Ry @ Rx
+        T = -Rc2w.T @ c
+        q = rotmat2qvec(Rc2w.T)                       # COLMAP stores world -> camera
+        name = f"view_{k:02d}.png"
+        lines.append(f"{k + 1} {q[0]:.12f} {q[1]:.12f} {q[2]:.12f} {q[3]:.12f} {T[0]:.12f} {T[1]:.12f} {T[2]:.12f} 1 {name}\n\n")
+        cam = synth.make_camera(W, H, R=Rc2w, T=T)
+        with torch.no_grad():
+            out = ro.rasterize(scene.means3D, None, scene.shs, None, scene.opacities, scene.scales, scene.rotations, None,
+                               image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg,
+                               scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                               projmatrix=cam.full_proj_transform, sh_degree=3, campos=cam.camera_center)
+        img = (out.color.clamp(0, 1).permute(1, 2, 0).numpy() * 255 + 0.5).astype(np.uint8)
+        Image.fromarray(img).save(os.path.join(path, "images", name))
+    with open(os.path.join(path, "sparse", "0", "images.txt"), "w") as f:
+        f.writelines(lines)
+    xyz = scene.means3D.numpy()
+    rgb = np.clip((0.5 + ro.SH_C0 * scene.shs[:, 0].numpy()) * 255, 0, 255).astype(np.uint8)
+    dt = [("x", "f4"), ("y", "f4"), ("z", "f4"), ("nx", "f4"), ("ny", "f4"), ("nz", "f4"),
+          ("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    el = np.empty(n_points, dtype=dt)
+    for i, n in enumerate("xyz"):
+        el[n] = xyz[:, i]
+        el["n" + n] = 0
+    el["red"], el["green"], el["blue"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    PlyData([PlyElement.describe(el, "vertex")]).write(os.path.join(path, "sparse", "0", "points3D.ply"))
+    hier_path = None
+    if hier:
+        from gaussian_hierarchy._C import write_hierarchy
+        left = scene.means3D[:, 0] < scene.means3D[:, 0].median()
+        chunks = []
+        for sel in (left, ~left):
+            sub = synth.Scene(scene.means3D[sel], scene.scales[sel], scene.rotations[sel], scene.opacities[sel],
+                              scene.shs[sel], 3)
+            chunks.append(hierarchy.build_hierarchy(sub))
+        h = hierarchy.merge_hierarchies(chunks)
+        hier_path = os.path.join(path, "chunks.hier")
+        write_hierarchy(hier_path, h.xyz, h.shs, h.alpha, h.log_scales, h.rots, h.nodes, h.boxes)
+    return hier_path
+
+
+if __name__ == "__main__":
+    print(make(sys.argv[1]))

@@ -1,0 +1,110 @@
+"""The data-parallel STEP (hgs.dp.DataParallelStep + DensifyStats) on CPU: 2 processes, gloo.  The per-view renderer is
+the CPU oracle and the optimizer a CPU stand-in (both test infrastructure: the HIP op and the fused Adam have no CPU
+path -- tests/test_dp_step_gpu.py runs the same protocol through them); what is tested here is the protocol of
+SURVEY.md section 8(e):
+  * the split SUM all-reduce of the gradient bucket,
+  * the three densification reductions (MAX of |means2D.grad|, SUM of the visibility count, MAX of the radii:
+    /root/reference/scene/gaussian_model.py:687-689, train_single.py:147),
+  * ``relevant`` taken from the REDUCED opacity gradient (train_single.py:170-174),
+  * every rank ends the step with bit-identical parameters, equal to one process stepping through all views."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class _Ctx:           # what DataParallelStep needs of a RasterContext when the op itself is not in play
+    def __init__(self, grad_buffers=None, backward_stream=None):
+        self.grad_buffers, self.backward_stream, self.grad_accumulate = grad_buffers, backward_stream, False
+
+    def wait_backward_stream(self):
+        pass
+
+
+def _run_steps(rank, world, n_steps, views_per_rank):
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    import parity as pa
+    from hgs import dp
+    torch.set_num_threads(1)
+    n_views = world * views_per_rank
+    scene, cams, targets = dc.scene_and_cams(n_views)
+    params = {k: getattr(scene, k).clone() for k in dc.NAMES}
+    opt = dc.OracleAdam([dict(params=[params[k]], lr=dc.LRS[k]) for k in dc.NAMES])
+    step = dp.DataParallelStep(params, opt, make_context=_Ctx)
+    accum = dict(xyz_gradient_accum=torch.zeros(dc.P, 1), denom=torch.zeros(dc.P, 1), max_radii2D=torch.zeros(dc.P))
+    for _ in range(n_steps):
+        step.begin()
+        for j in dp.shard_views(n_views, rank, world):
+            cur = type(scene)(params["means3D"], params["scales"], params["rotations"], params["opacities"],
+                              params["shs"], 3)
+            oo, g = pa.run_oracle(cur, cams[j], torch.zeros(3), *_upstream(targets[j]), dtype=torch.float32)
+            for k in dc.NAMES:                       # what the op's backward does with grad_buffers / grad_accumulate
+                buf = step.context.grad_buffers[k]
+                buf.copy_(g[k].float().view_as(buf) + (buf if step.context.grad_accumulate else 0))
+            step.context.grad_buffers["means2D"].copy_(g["means2D"].float())
+            step.view_done(oo.radii)
+        step.finish()
+        step.stats.apply(accum["xyz_gradient_accum"], accum["denom"], accum["max_radii2D"])
+    return {k: v.detach().clone() for k, v in params.items()}, accum
+
+
+def _upstream(target):
+    """Fixed seeded dL/dcolor, dL/dinvdepth per view (a loss would need the forward first; for the protocol test a
+    fixed upstream gradient does the same job)."""
+    return target[0] - 0.5, target[1] - 0.15
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    from hgs import dp
+    dp.init_from_env(backend="gloo")
+    params, accum = _run_steps(rank, world, 2, 2)
+    q.put((rank, params, accum))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_dp_step_ranks_agree_and_match_one_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, params, accum = q.get(timeout=500)
+        got[r] = (params, accum)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref_params, ref_accum = _run_steps(0, 1, 2, 4)          # one process, the same 4 views per step
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    for k in dc.NAMES:
+        assert torch.equal(got[0][0][k], got[1][0][k]), f"{k}: ranks diverged"
+        scale = float(ref_params[k].abs().max())
+        assert float((got[0][0][k] - ref_params[k]).abs().max()) <= 1e-6 * scale, k
+    # rows no view ever saw were left alone by every rank (the row selection uses the REDUCED opacity gradient)
+    scene, _, _ = dc.scene_and_cams(4)
+    hidden = slice(dc.P // 2, dc.P)
+    assert torch.equal(got[0][0]["means3D"][hidden], scene.means3D[hidden])
+    assert not torch.equal(got[0][0]["means3D"][:dc.P // 2], scene.means3D[:dc.P // 2])
+    for k, v in ref_accum.items():
+        assert torch.equal(got[0][1][k], got[1][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
+    assert float(ref_accum["denom"].max()) == 8.0 and float(ref_accum["denom"][hidden].max()) == 0.0

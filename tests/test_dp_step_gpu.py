@@ -1,0 +1,107 @@
+"""The data-parallel STEP through the real pieces: HIP rasterizer (RasterContext: gradient bucket, accumulation,
+backwards on a second stream), batched SH backward, hgs.dp.DataParallelStep (split all-reduce, densification
+reductions, row selection from the reduced opacity gradient) and the fused hgs.optim.Adam.
+
+Only one GPU is available to the test, so the 2 ranks SHARE it and talk over gloo (HGS_DP_BACKEND semantics of
+bench.py); the protocol, the buffers and every kernel are those of the RCCL run.  Checked after 3 steps of 2 views per
+rank: both ranks hold bit-identical parameters, equal (<= 1e-6 of the tensor's magnitude) to ONE process accumulating
+all 4 views of a step itself; the densification statistics agree exactly."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    import parity as pa
+    import diff_gaussian_rasterization as dgr
+    from hgs import dp
+    from hgs.optim import Adam
+    dev = torch.device("cuda:0")
+    n_views = world * views_per_rank
+    scene, cams, targets = dc.scene_and_cams(n_views)
+    params = {k: getattr(scene, k).clone().to(dev).requires_grad_(True) for k in dc.NAMES}
+    opt = Adam([dict(params=[params[k]], lr=dc.LRS[k], name=k) for k in dc.NAMES], lr=0.0, eps=1e-15)
+    step = dp.DataParallelStep(params, opt, backward_stream=torch.cuda.Stream(device=dev) if two_streams else None)
+    accum = dict(xyz_gradient_accum=torch.zeros(dc.P, 1, device=dev), denom=torch.zeros(dc.P, 1, device=dev),
+                 max_radii2D=torch.zeros(dc.P, device=dev))
+    bg = torch.zeros(3)
+    for _ in range(n_steps):
+        step.begin()
+        for j in dp.shard_views(n_views, rank, world):
+            rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cams[j], bg, 3, device=dev))
+            m2 = torch.zeros(dc.P, 3, device=dev, requires_grad=True)
+            color, radii, invd = dgr.GaussianRasterizer(rs, context=step.context)(
+                means3D=params["means3D"], means2D=m2, shs=params["shs"], opacities=params["opacities"],
+                scales=params["scales"], rotations=params["rotations"])
+            tc, td = (t.to(dev) for t in targets[j])
+            loss = (color - tc).abs().mean() + 0.1 * (invd - td).abs().mean()
+            loss.backward()
+            step.view_done(radii)
+        step.finish()
+        step.stats.apply(accum["xyz_gradient_accum"], accum["denom"], accum["max_radii2D"])
+    torch.cuda.synchronize()
+    return {k: v.detach().cpu() for k, v in params.items()}, {k: v.cpu() for k, v in accum.items()}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "hierarchical-3d-gaussians_amd"))
+    sys.path.insert(0, os.path.dirname(HERE))
+    from hgs import dp
+    dp.init_from_env(backend="gloo")
+    params, accum = _run_steps(rank, world, 3, 2)
+    q.put((rank, params, accum))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, params, accum = q.get(timeout=800)
+        got[r] = (params, accum)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    ref_params, ref_accum = _run_steps(0, 1, 3, 4)            # one process, all 4 views of every step, two streams
+    one_stream, _ = _run_steps(0, 1, 3, 4, two_streams=False)
+    scene, _, _ = dc.scene_and_cams(4)
+    hidden = slice(dc.P // 2, dc.P)
+    for k in dc.NAMES:
+        assert torch.equal(got[0][0][k], got[1][0][k]), f"{k}: ranks diverged"
+        assert torch.equal(ref_params[k], one_stream[k]), f"{k}: the second stream changed the result"
+        scale = float(ref_params[k].abs().max())
+        err = float((got[0][0][k] - ref_params[k]).abs().max())
+        assert err <= 1e-6 * scale, (k, err, scale)
+        assert torch.equal(got[0][0][k][hidden], getattr(scene, k)[hidden]), f"{k}: unseen rows must not move"
+    assert not torch.equal(got[0][0]["means3D"][:dc.P // 2], scene.means3D[:dc.P // 2])
+    for k, v in ref_accum.items():
+        assert torch.equal(got[0][1][k], got[1][1][k]), k
+        assert torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
+    assert float(ref_accum["denom"].max()) == 12.0 and float(ref_accum["denom"][hidden].max()) == 0.0

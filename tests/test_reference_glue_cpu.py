@@ -21,44 +21,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "gaussian_re
                                 reason="reference checkout not present (GPU box)")
 
 
-class _OracleC:
-    """Stand-in for diff_gaussian_rasterization._C with the same two entry points."""
-
-    @staticmethod
-    def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
-                            viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
-                            prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                            num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False):
-        from oracle import raster_oracle as ro
-        assert render_indices.numel() == 0 and parent_indices.numel() == 0
-        ins = dict(means3D=means3D, shs=sh, colors_precomp=colors, opacities=opacity, scales=scales,
-                   rotations=rotations, cov3D_precomp=cov3D_precomp)
-        leaves = {k: (v.detach().clone().requires_grad_(True) if v is not None and v.numel() else None)
-                  for k, v in ins.items()}
-        m2 = torch.zeros(means3D.shape[0], 3, requires_grad=True)
-        with torch.enable_grad():
-            out = ro.rasterize(leaves["means3D"], m2, leaves["shs"], leaves["colors_precomp"], leaves["opacities"],
-                               leaves["scales"], leaves["rotations"], leaves["cov3D_precomp"],
-                               image_height=image_height, image_width=image_width, tanfovx=tanfovx, tanfovy=tanfovy,
-                               bg=background, scale_modifier=scale_modifier, viewmatrix=viewmatrix,
-                               projmatrix=projmatrix, sh_degree=degree, campos=campos,
-                               interpolation_weights=interpolation_weights, num_node_kids=num_node_kids)
-        call = types.SimpleNamespace(out=out, leaves=leaves, m2=m2, do_depth=do_depth)
-        invd = out.invdepth.detach().float() if do_depth else torch.zeros(1, image_height, image_width)
-        return out.binning.num_rendered, out.color.detach().float(), out.radii.clone(), None, None, None, invd, call
-
-    @staticmethod
-    def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False,
-                                     defer_sh=False):
-        with torch.enable_grad():
-            loss = (call.out.color * dL_dcolor.double()).sum()
-            if call.do_depth and dL_dinvdepth is not None:
-                loss = loss + (call.out.invdepth * dL_dinvdepth.double()).sum()
-        names = [k for k, v in call.leaves.items() if v is not None]
-        grads = torch.autograd.grad(loss, [call.leaves[k] for k in names] + [call.m2], allow_unused=True)
-        g = {k: (None if t is None else t.float()) for k, t in zip(names + ["m2"], grads)}
-        return (g["m2"], g.get("colors_precomp"), g.get("opacities"), g.get("means3D"), g.get("cov3D_precomp"),
-                g.get("shs"), g.get("scales"), g.get("rotations"))
+from harness.cpu_backends import OracleRasterC as _OracleC   # oracle-backed extension layer (test only)
 
 
 @pytest.fixture()
