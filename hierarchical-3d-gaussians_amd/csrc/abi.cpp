@@ -110,7 +110,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
   const size_t tmp_sort = sort_tmp_bytes(L ? L : 1), tmp_bin = tile_bin_tmp_bytes(L, T);
-  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) +
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) + align_up((size_t)T * 4) +
          (tmp_sort > tmp_bin ? tmp_sort : tmp_bin) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
@@ -123,6 +123,7 @@ BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   b.vals_out = carve<uint32_t>(c, l);
   b.ranges = carve<uint32_t>(c, (size_t)T * 2);
   b.big_tiles = carve<uint32_t>(c, (size_t)T * 3 + 3);
+  b.tile_order = carve<uint32_t>(c, (size_t)T);
   b.sort_tmp = c;
   return b;
 }
@@ -223,6 +224,7 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
     if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
   }
   if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
+  if ((rc = launch_tile_order(b, T, s, a->debug))) return rc;     // ~3 us; counted with the compositing stage it serves
   float* zero_ws = static_cast<float*>(a->bwd_ws_prezero);
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, zero_ws,
                                                        zero_ws ? (size_t)L * kInstStride : 0, s));

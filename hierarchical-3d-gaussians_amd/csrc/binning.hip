@@ -444,4 +444,46 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   return HGS_OK;
 }
 
+// Launch order of the one-wave-per-tile kernels (K6, K7): tile ids by DESCENDING instance count, as a counting sort
+// over 1024 quantised counts (count / 4, everything above 4092 in the first bucket) done by one workgroup.  The order
+// inside a bucket is whatever the LDS atomics produce: it only permutes which SIMD renders which tile, never a result.
+namespace {
+__global__ __launch_bounds__(1024) void tile_order_kernel(const uint32_t* __restrict__ ranges, int T,
+                                                          uint32_t* __restrict__ order) {
+  __shared__ uint32_t hist[1024];
+  __shared__ uint32_t wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const uint32_t c = ranges[2 * t + 1] - ranges[2 * t];
+    atomicAdd(&hist[1023u - min(c >> 2, 1023u)], 1u);
+  }
+  __syncthreads();
+  const uint32_t v = hist[tid];
+  uint32_t inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t u = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += u;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wave_tot[w];
+  hist[tid] = base + inc - v;          // exclusive prefix = first output slot of the bucket
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const uint32_t c = ranges[2 * t + 1] - ranges[2 * t];
+    order[atomicAdd(&hist[1023u - min(c >> 2, 1023u)], 1u)] = (uint32_t)t;
+  }
+}
+}  // namespace
+
+int launch_tile_order(const BinWs& b, int32_t T, hipStream_t s, bool debug) {
+  hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, b.ranges, T, b.tile_order);
+  HGS_LAUNCH_CHECK("tile_order", s, debug);
+  return HGS_OK;
+}
+
 }  // namespace hgs

@@ -69,6 +69,7 @@ struct BinWs {
   uint32_t* vals_out;  // [L] per tile ascending id after the tile sort; point_list after the per-tile depth sort
   uint32_t* ranges;    // [T,2]
   uint32_t* big_tiles; // [3 + 3T] counters + lists of the tiles too crowded for the one-wave register sort
+  uint32_t* tile_order; // [T] tile ids by descending instance count: launch order of the one-wave-per-tile kernels
   void* sort_tmp;
   static size_t bytes(uint32_t L, int32_t T);
   static BinWs carve_from(void* base, uint32_t L, int32_t T);
@@ -94,6 +95,8 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
 int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug);
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s);
 int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug);
+// b.tile_order from the final b.ranges (one small workgroup; counting sort over quantised instance counts)
+int launch_tile_order(const BinWs& b, int32_t T, hipStream_t s, bool debug);
 // fill_tile_ids: also write every instance's tile id into b.keys_out (the tile-binning path does not produce it)
 int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
                            bool fill_tile_ids, hipStream_t s);

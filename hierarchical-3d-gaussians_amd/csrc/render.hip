@@ -26,7 +26,7 @@
 //    (every term relatively accurate; a front-to-back variant using V - prefix was measured 10-80x
 //    less accurate on pixels with capped alphas and was dropped).
 //  * the 10 per-(tile,Gaussian) partial sums are reduced over the 4 strips in registers, over the
-//    wave with DPP row reductions + row_bcast, and lane 63 stores the 48-byte instance record to
+//    wave with permlane swaps + DPP row reductions, and four lanes store the 48-byte instance record to
 //    its EMISSION slot; K8 sums each Gaussian's contiguous run.  No LDS accumulator, no atomics
 //    of any kind, bit-reproducible.
 #include "common.h"
@@ -51,14 +51,6 @@ __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_mov<0x140>(v);   // row_mirror
   return v;
 }
-// wave total in lane 63
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-  v = row_sum16(v);
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));  // row_bcast:15
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xC, 0xF, false));  // row_bcast:31
-  return v;
-}
-
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct TileGeom {
@@ -68,10 +60,21 @@ struct TileGeom {
 // XCD-aware block -> tile map: consecutive blocks land on different XCDs (b % 8), so give
 // every XCD a contiguous band of tiles; neighbouring tiles share Gaussians and therefore
 // share that XCD's L2.
-__device__ __forceinline__ bool block_to_tile(int T, int gx, TileGeom& tg) {
+//
+// With `order` (tile_order_kernel: tiles by descending instance count): block b takes order[b].  The hardware
+// dispatches workgroups in block order, so the crowded tiles start first and the tail of the launch is made of light
+// tiles -- the one-wave-per-tile kernels run 1.6 rounds of waves, and an unsorted launch ends with a few waves of the
+// heaviest tiles keeping a handful of SIMDs busy while the rest of the chip idles.
+__device__ __forceinline__ bool block_to_tile(int T, int gx, const uint32_t* __restrict__ order, TileGeom& tg) {
   const int per = (T + 7) >> 3;
   const int b = blockIdx.x;
-  const int tile = (b & 7) * per + (b >> 3);
+  int tile;
+  if (order) {
+    if (b >= T) return false;
+    tile = (int)order[b];
+  } else {
+    tile = (b & 7) * per + (b >> 3);
+  }
   if (tile >= T) return false;
   tg.tile = tile;
   tg.ty = tile / gx;
@@ -95,6 +98,13 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 
+// min(x, 0) as exactly one v_min_f32 (fminf adds a canonicalising v_max x, x in front of it)
+__device__ __forceinline__ float min_zero(float x) {
+  float r;
+  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
 template <bool DEPTH>
 struct FwdPair {
   f2 fly, T, Cr, Cg, Cb, Dd;
@@ -104,12 +114,15 @@ struct FwdPair {
 template <bool DEPTH>
 __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const float4& q1,
                                               const float4& q2, uint32_t idx1) {
-  const f2 G = {fast_exp2(pw.x), fast_exp2(pw.y)};
+  // min(pw, 0): the conic is positive definite (0.3 px^2 was added to the covariance's diagonal), so the exponent is
+  // <= 0 up to rounding; clamping replaces the reference lineage's "power > 0 -> skip" test, which in exact arithmetic
+  // never fires, by the value the exact exponent would give (and costs no compare)
+  const f2 G = {fast_exp2(min_zero(pw.x)), fast_exp2(min_zero(pw.y))};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band)
-  const bool live0 = (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);
-  const bool live1 = (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
+  const bool live0 = alpha.x >= kAlphaMin;
+  const bool live1 = alpha.y >= kAlphaMin;
   const f2 Tn = p.T * (1.0f - alpha);
   const bool stop0 = live0 && (Tn.x < kTEps), stop1 = live1 && (Tn.y < kTEps);
   const bool blend0 = live0 && !stop0, blend1 = live1 && !stop1;
@@ -131,13 +144,14 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_ws, uint32_t zero_vecs) {
+    uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_ws, uint32_t zero_vecs,
+    const uint32_t* __restrict__ order) {
   constexpr int BATCH = 64;
   constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
   __shared__ float4 lrec[BATCH * kLds];
 
   TileGeom tg;
-  if (!block_to_tile(T, gx, tg)) return;
+  if (!block_to_tile(T, gx, order, tg)) return;
   const int lane = threadIdx.x;
   const int lx = lane & 15, ly0 = lane >> 4;
   const int px = tg.tx * kTile + lx;
@@ -159,7 +173,8 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
   bool wave_done = (__ballot(inside[0] || inside[1] || inside[2] || inside[3]) == 0);
 
   for (uint32_t base = r0; base < r1 && !wave_done; base += BATCH) {
-    const uint32_t n = min((uint32_t)BATCH, r1 - base);
+    // wave-uniform by construction; readfirstlane tells the compiler so (loop counter and LDS address in scalar registers)
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)BATCH, r1 - base));
     __syncthreads();
     if ((uint32_t)lane < n) {
       const uint32_t gid = point_list[base + lane];
@@ -240,23 +255,16 @@ struct BwdSums {
   f2 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
 };
 
-// min(x, 0) as exactly one v_min_f32 (fminf adds a canonicalising v_max x, x in front of it)
-__device__ __forceinline__ float min_zero(float x) {
-  float r;
-  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
-
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
                                                   const float4& q1, const float4& q2) {
-  // min(pw, 0): identical for live lanes (they require pw <= 0) and keeps G finite on the others,
-  // whose contributions are multiplied by an exact 0 below
+  // min(pw, 0): as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also keeps G
+  // finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
   const f2 G = {fast_exp2(min_zero(pw.x)), fast_exp2(min_zero(pw.y))};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-  const bool live0 = c0 && (pw.x <= 0.0f) && (alpha.x >= kAlphaMin);   // = blended by the forward
-  const bool live1 = c1 && (pw.y <= 0.0f) && (alpha.y >= kAlphaMin);
+  const bool live0 = c0 && (alpha.x >= kAlphaMin);   // = blended by the forward
+  const bool live1 = c1 && (alpha.y >= kAlphaMin);
   // (no wave-level "nobody live" exit: the candidate test already is the alpha test up to its 1e-3 guard band)
   // non-live lanes take part with alpha = 0: identity for T, for the A recurrence and for every sum
   const f2 ae = {live0 ? alpha.x : 0.0f, live1 ? alpha.y : 0.0f};
@@ -303,12 +311,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
-    const float* __restrict__ dL_dinvdepth, float* __restrict__ inst) {
+    const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order) {
   constexpr int BATCH = 64;
   __shared__ float4 lrec[BATCH * kRecVec];
 
   TileGeom tg;
-  if (!block_to_tile(T, gx, tg)) return;
+  if (!block_to_tile(T, gx, order, tg)) return;
   const int lane = threadIdx.x;
   const int lx = lane & 15, ly0 = lane >> 4;
   const int px = tg.tx * kTile + lx;
@@ -340,6 +348,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
+  maxnc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxnc);   // uniform: loop counters live in scalar registers
   if (maxnc == 0) return;
   BwdPair P0, P1;
   P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
@@ -352,9 +361,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   P0.A = P0.la = P0.lq = P1.A = P1.la = P1.lq = splat(0.0f);
   P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
   const uint32_t r0 = ranges[tg.tile * 2 + 0];
-  // value index held by this lane's row after the swap reduction (see below): row r -> {0,2,1,3}[r]
+  // value index held by this lane's row after the swap reduction (see below): row r -> {0,2,1,3}[r]; the third
+  // register holds s8 / s9 in rows 1 / 3 (rows 0 / 2 carry partial sums that go to the record's two pad floats)
   const int row = lane >> 4;
   const int slot = ((row & 1) << 1) | (row >> 1);
+  const int slot2 = (((row & 1) ^ 1) << 1) | (row >> 1);
 
   for (int bstart = (int)((maxnc - 1) / BATCH) * BATCH; bstart >= 0; bstart -= BATCH) {
     const int n = min(BATCH, (int)maxnc - bstart);
@@ -403,9 +414,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       if (b0) any_blend |= bwd_pair_live<DEPTH>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
       if (b1) any_blend |= bwd_pair_live<DEPTH>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
       if (any_blend != 0) {   // wave-uniform
-        // 10 sums x 64 lanes -> 12 slots in 28 VALU: fold the two strips of each pair, then halve the
-        // lane count twice with permlane32/16 swaps (two values share a register afterwards), then
-        // DPP row reductions.  v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7), v2 rows = (s8,-,s9,-).
+        // 10 sums x 64 lanes -> 12 slots: fold the two strips of each pair, then halve the lane count twice with
+        // permlane32/16 swaps (two values share a register afterwards), then DPP row reductions.
+        // v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7).  s8 / s9 occupy one half-wave each after the first
+        // halving: their two rows are reduced separately and joined by ONE row_bcast:15 add (a permlane16 swap with
+        // zero + add costs three times as much): v2 rows = (s8 partial, s8, s9 partial, s9).
         const float u0 = swap32_add(S.s0.x + S.s0.y, S.s1.x + S.s1.y);
         const float u1 = swap32_add(S.s2.x + S.s2.y, S.s3.x + S.s3.y);
         const float u2 = swap32_add(S.s4.x + S.s4.y, S.s5.x + S.s5.y);
@@ -413,7 +426,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const float u4 = swap32_add(S.s8.x + S.s8.y, DEPTH ? (S.s9.x + S.s9.y) : 0.0f);
         const float v0 = row_sum16(swap16_add(u0, u1));
         const float v1 = row_sum16(swap16_add(u2, u3));
-        const float v2 = row_sum16(swap16_add(u4, 0.0f));
+        float v2 = row_sum16(u4);
+        v2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
         if ((lane & 15) == 0) {
           const uint32_t off = __float_as_uint(q2.z);
           const uint32_t rb = __float_as_uint(q2.w);
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
           float* dst = inst + (size_t)e * kInstStride + slot;
           dst[0] = v0;
           dst[4] = v1;
-          dst[8] = v2;
+          dst[8 + slot2 - slot] = v2;
         }
       }
     }
@@ -444,7 +458,7 @@ int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
                      out_invdepth, im.final_T, im.n_contrib, reinterpret_cast<float4*>(zero_ws),
-                     (uint32_t)(zero_floats >> 2));
+                     (uint32_t)(zero_floats >> 2), b.tile_order);
   HGS_LAUNCH_CHECK("render_fwd_packed", s, a.debug);
   return HGS_OK;
 }
@@ -459,7 +473,7 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   auto kern = depth ? render_bwd_packed_kernel<true> : render_bwd_packed_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
-                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads);
+                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order);
   HGS_LAUNCH_CHECK("render_bwd_packed", s, a.debug);
   return HGS_OK;
 }

@@ -72,7 +72,8 @@ def _worker(rank, world, port, q):
     from hgs import dp
     dp.init_from_env(backend="gloo")
     params, accum = _run_steps(rank, world, 2, 2)
-    q.put((rank, params, accum))
+    # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
+    q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -89,7 +90,7 @@ def test_dp_step_ranks_agree_and_match_one_process():
     got = {}
     for _ in range(world):
         r, params, accum = q.get(timeout=500)
-        got[r] = (params, accum)
+        got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -66,7 +66,8 @@ def _worker(rank, world, port, q):
     from hgs import dp
     dp.init_from_env(backend="gloo")
     params, accum = _run_steps(rank, world, 3, 2)
-    q.put((rank, params, accum))
+    # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
+    q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,7 +84,7 @@ def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu):
     got = {}
     for _ in range(world):
         r, params, accum = q.get(timeout=800)
-        got[r] = (params, accum)
+        got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
