@@ -319,12 +319,28 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
       rec[0] = make_float4(gx_hi, gy_hi, A2, B2);
       rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
-      rec[2] = make_float4(rgb[2], (float)(1.0 / pd.tz), 0.0f, __uint_as_float(rectbits));
       // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
       // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
       // never a candidate, exactly like the exact test)
       const float thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
-      rec[3] = make_float4(gx_lo, gy_lo, thr, 0.0f);
+      // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
+      //   A dx^2 + 2 B dx dy + C dy^2 <= 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T C / det), |dy| <= sqrt(T A / det).
+      // The compositing kernels use them to decide, once per (tile, Gaussian) and in scalar registers, which half of
+      // the tile can be touched at all; they are inflated (same 1e-3 guard in the exponent, 1e-4 relative, 5e-3 px)
+      // so that the box contains every pixel the exact alpha test could accept.  -1: no pixel ever (o <= ~1/255).
+      float ext_x = -1.0f, ext_y = -1.0f;
+      {
+        const double T2 = 2.0 * (log(255.0 * (double)opac) + 1.0e-3 * 0.6931471805599453);
+        const double det = pd.conA * pd.conC - pd.conB * pd.conB;
+        if (T2 > 0.0 && det > 0.0) {
+          ext_x = (float)(sqrt(T2 * pd.conC / det) * 1.0001 + 5.0e-3);
+          ext_y = (float)(sqrt(T2 * pd.conA / det) * 1.0001 + 5.0e-3);
+        } else if (T2 > 0.0) {
+          ext_x = ext_y = 1.0e9f;       // degenerate conic: never skip on the box
+        }
+      }
+      rec[2] = make_float4(rgb[2], (float)(1.0 / pd.tz), ext_x, __uint_as_float(rectbits));
+      rec[3] = make_float4(gx_lo, gy_lo, thr, ext_y);
     }
     // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
     reinterpret_cast<uint2*>(g.rects)[idx] =

@@ -173,9 +173,12 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
   bool wave_done = (__ballot(inside[0] || inside[1] || inside[2] || inside[3]) == 0);
 
   for (uint32_t base = r0; base < r1 && !wave_done; base += BATCH) {
-    // wave-uniform by construction; readfirstlane tells the compiler so (loop counter and LDS address in scalar registers)
+    // wave-uniform by construction; readfirstlane tells the compiler so
     const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)BATCH, r1 - base));
     __syncthreads();
+    // staging lane = one Gaussian of the batch: besides copying its record it decides which HALF of the tile (rows
+    // 0-7 = pair 0, rows 8-15 = pair 1) the Gaussian's alpha >= 1/255 box (K1: ext_x, ext_y) can reach at all
+    bool half0 = false, half1 = false;
     if ((uint32_t)lane < n) {
       const uint32_t gid = point_list[base + lane];
       const float4* r = records + (size_t)gid * kRecVec;
@@ -183,13 +186,21 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       const float4 a3 = r[3];
       a0.x = (a0.x - tile_x0) + a3.x;       // tile-relative pixel centre, once per (tile, Gaussian)
       a0.y = (a0.y - tile_y0) + a3.y;
+      const float ex = a2.z, ey = a3.w;
+      const bool xok = (a0.x - ex <= 15.0f) && (a0.x + ex >= 0.0f);
+      half0 = xok && (a0.y - ey <= 7.0f) && (a0.y + ey >= 0.0f);
+      half1 = xok && (a0.y - ey <= 15.0f) && (a0.y + ey >= 8.0f);
       a2.z = a3.z;                           // skip threshold
       lrec[lane * kLds + 0] = a0;
       lrec[lane * kLds + 1] = r[1];
       lrec[lane * kLds + 2] = a2;
     }
+    const uint64_t m0 = __ballot(half0), m1 = __ballot(half1);   // scalar registers: one bit per Gaussian of the batch
     __syncthreads();
-    for (uint32_t j = 0; j < n; ++j) {
+    // only Gaussians whose box reaches the tile are visited (22 % of the instances of the benchmark scene do not:
+    // their 3-sigma rectangle touches the tile, their alpha >= 1/255 region does not), and only for the half they reach
+    for (uint64_t todo = m0 | m1; todo != 0; todo &= todo - 1) {
+      const uint32_t j = (uint32_t)__builtin_ctzll(todo);
       const float4 q0 = lrec[j * kLds + 0];
       const float4 q1 = lrec[j * kLds + 1];
       const float4 q2 = lrec[j * kLds + 2];
@@ -198,17 +209,19 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
       const float thr = q2.z;
-      const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
-      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
-      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-      // candidate tests as "max of the pair >= thr": one plain compare per ballot (a ballot of an OR of compares
-      // costs two more vector instructions), and one for the whole tile on the most common path -- no candidate
-      const float m0 = fmaxf(pw0.x, pw0.y), m1 = fmaxf(pw1.x, pw1.y);
-      if (__ballot(fmaxf(m0, m1) >= thr) == 0) continue;
-      const bool b0 = __ballot(m0 >= thr) != 0, b1 = __ballot(m1 >= thr) != 0;   // wave-uniform
       const uint32_t idx1 = base - r0 + j + 1;
-      if (b0) fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
-      if (b1) fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
+      // per flagged half: exponents of its two strips, then the exact wave-wide candidate test ("max of the pair >=
+      // thr": one compare per ballot); a finished / outside pixel sits at y = kBig and is never a candidate
+      if ((m0 >> j) & 1) {
+        const f2 dy0 = gyt - P0.fly;
+        const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+        if (__ballot(fmaxf(pw0.x, pw0.y) >= thr) != 0) fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
+      }
+      if ((m1 >> j) & 1) {
+        const f2 dy1 = gyt - P1.fly;
+        const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+        if (__ballot(fmaxf(pw1.x, pw1.y) >= thr) != 0) fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
+      }
     }
     // every pixel saturated?  (finished pixels sit at y = kBig: the rest of a batch costs them only the
     // no-candidate path above)
@@ -370,6 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   for (int bstart = (int)((maxnc - 1) / BATCH) * BATCH; bstart >= 0; bstart -= BATCH) {
     const int n = min(BATCH, (int)maxnc - bstart);
     __syncthreads();
+    bool half0 = false, half1 = false;          // see the forward kernel: which half of the tile the Gaussian can reach
     if (lane < n) {
       const uint32_t gid = point_list[r0 + bstart + lane];
       const float4* r = records + (size_t)gid * kRecVec;
@@ -377,37 +391,52 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       const float4 a3 = r[3];
       a0.x = (a0.x - tile_x0) + a3.x;           // tile-relative pixel centre, once per (tile, Gaussian)
       a0.y = (a0.y - tile_y0) + a3.y;
+      const float ex = a2.z, ey = a3.w;
+      const bool xok = (a0.x - ex <= 15.0f) && (a0.x + ex >= 0.0f);
+      half0 = xok && (a0.y - ey <= 7.0f) && (a0.y + ey >= 0.0f);
+      half1 = xok && (a0.y - ey <= 15.0f) && (a0.y + ey >= 8.0f);
       a2.z = __uint_as_float(offsets[gid]);     // emission offset of this Gaussian's instance run
       lrec[lane * kRecVec + 0] = a0;
       lrec[lane * kRecVec + 1] = r[1];
       lrec[lane * kRecVec + 2] = a2;
       lrec[lane * kRecVec + 3] = a3;
     }
+    const uint64_t m0 = __ballot(half0), m1 = __ballot(half1);
     __syncthreads();
-    for (int j = n - 1; j >= 0; --j) {
+    // back to front over the Gaussians whose box reaches the tile
+    for (uint64_t todo = m0 | m1; todo != 0;) {
+      const int j = 63 - __builtin_clzll(todo);
+      todo &= ~(1ull << j);
       const uint32_t rel = (uint32_t)(bstart + j);
       const float4 q0 = lrec[j * kRecVec + 0];
       const float4 q1 = lrec[j * kRecVec + 1];
-      const float4 q2 = lrec[j * kRecVec + 2];
       const float4 q3 = lrec[j * kRecVec + 3];
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
       const float thr = q3.z;
-      const f2 dy0 = gyt - P0.fly, dy1 = gyt - P1.fly;
-      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
-      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-      // cheapest exit first: no pixel of the tile passes the alpha threshold (one max tree + one compare)
-      if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) continue;
-      const bool c0 = (pw0.x >= thr) && (rel < P0.nc0), c1 = (pw0.y >= thr) && (rel < P0.nc1);
-      const bool c2 = (pw1.x >= thr) && (rel < P1.nc0), c3 = (pw1.y >= thr) && (rel < P1.nc1);
-      // wave-uniform "pair has a candidate": ballots of the PLAIN compares (one v_cmp each, the mask lands in scalar
-      // registers) combined with scalar and / or -- a ballot of the combined predicate costs two more vector
-      // instructions per pair
-      const bool b0 = ((__ballot(pw0.x >= thr) & __ballot(rel < P0.nc0)) | (__ballot(pw0.y >= thr) & __ballot(rel < P0.nc1))) != 0;
-      const bool b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
-      if (!(b0 || b1)) continue;   // candidates only on pixels that had stopped before this Gaussian
+      // per flagged half: exponents, per-strip candidate predicates (log-domain alpha test AND "the forward blended
+      // this Gaussian into the pixel", i.e. rel < n_contrib) and the wave-uniform "half has a candidate" from the
+      // ballots of the plain compares combined in scalar registers
+      f2 dy0 = splat(0.0f), dy1 = splat(0.0f), pw0 = splat(0.0f), pw1 = splat(0.0f);
+      bool c0 = false, c1 = false, c2 = false, c3 = false, b0 = false, b1 = false;
+      if ((m0 >> j) & 1) {
+        dy0 = gyt - P0.fly;
+        pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+        c0 = (pw0.x >= thr) && (rel < P0.nc0);
+        c1 = (pw0.y >= thr) && (rel < P0.nc1);
+        b0 = ((__ballot(pw0.x >= thr) & __ballot(rel < P0.nc0)) | (__ballot(pw0.y >= thr) & __ballot(rel < P0.nc1))) != 0;
+      }
+      if ((m1 >> j) & 1) {
+        dy1 = gyt - P1.fly;
+        pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+        c2 = (pw1.x >= thr) && (rel < P1.nc0);
+        c3 = (pw1.y >= thr) && (rel < P1.nc1);
+        b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
+      }
+      if (!(b0 || b1)) continue;
+      const float4 q2 = lrec[j * kRecVec + 2];
       BwdSums S;
       S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
       uint64_t any_blend = 0;

@@ -64,9 +64,13 @@ class RasterContext:
                        went into ``grad_buffers`` are valid ON THAT STREAM until ``wait_backward_stream()``; gradients
                        returned to autograd are made safe by letting the forward's stream wait for the backward
                        (correct, but it serialises the two streams -- buffer every input to get the overlap).
+    skybox_points      in-op LOD interpolation only (non-empty ``render_indices``): the last ``skybox_points`` rows of
+                       the attribute tensors are the skybox (scene/gaussian_model.py:371-383); they are appended to
+                       the interpolated rows with weight 1 / 1 sibling, as gaussian_renderer/__init__.py:220-234 does.
     """
 
-    def __init__(self, grad_buffers=None, backward_stream=None, defer_sh_backward=False):
+    def __init__(self, grad_buffers=None, backward_stream=None, defer_sh_backward=False, skybox_points=0):
+        self.skybox_points = int(skybox_points)
         self.grad_buffers = grad_buffers
         self.grad_accumulate = False
         self.defer_sh_backward = bool(defer_sh_backward)
@@ -309,11 +313,20 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
             raise RuntimeError("grad_buffers hold gradients of the op's direct inputs; with in-op LOD interpolation "
                                "those are the gathered rows, not the hierarchy's parameters")
         n = rs.render_indices.numel()
-        means3D, scales, rotations, sh, opacities = _LodGather.apply(
-            rs.render_indices, rs.parent_indices, rs.interpolation_weights, means3D, scales, rotations, sh, opacities)
-        means2D = means2D[:n]
+        ri, pi, w, kids = rs.render_indices, rs.parent_indices[:n], rs.interpolation_weights[:n], rs.num_node_kids[:n]
+        K = context.skybox_points if context is not None else 0
+        if K > 0:
+            # the skybox rows ride along as their own parents with weight 1 and one sibling
+            # (gaussian_renderer/__init__.py:220-234); the caller's tensors are left untouched
+            sky = torch.arange(means3D.shape[0] - K, means3D.shape[0], dtype=ri.dtype, device=ri.device)
+            ri, pi = torch.cat((ri, sky)), torch.cat((pi, sky))
+            w = torch.cat((w, torch.ones(K, dtype=w.dtype, device=w.device)))
+            kids = torch.cat((kids, torch.ones(K, dtype=kids.dtype, device=kids.device)))
+        means3D, scales, rotations, sh, opacities = _LodGather.apply(ri, pi, w, means3D, scales, rotations, sh, opacities)
+        means2D = means2D[:n + K]
         empty = rs.render_indices.new_empty(0)
-        raster_settings = rs._replace(render_indices=empty, parent_indices=empty)
+        raster_settings = rs._replace(render_indices=empty, parent_indices=empty, interpolation_weights=w,
+                                      num_node_kids=kids)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, context)
 

@@ -137,31 +137,38 @@ def test_million_leaf_hierarchy_cut_and_render(gpu):
         print(f"tau={tau_px}px: cut {n} of {G} nodes, mean colour {float(color.mean()):.4f}")
 
 
-def test_in_op_lod_interpolation_matches_python_glue(gpu):
+@pytest.mark.parametrize("skybox", [0, 37])
+def test_in_op_lod_interpolation_matches_python_glue(gpu, skybox):
     """render_indices / parent_indices passed NON-empty to the op must reproduce exactly what
-    render_post's Python block (gaussian_renderer/__init__.py:199-218, restated here in torch) feeds it,
-    forward and backward (gradients land on node AND parent rows)."""
+    render_post's Python block (gaussian_renderer/__init__.py:199-234, restated here in torch) feeds it,
+    forward and backward (gradients land on node AND parent rows) -- including the skybox rows the reference appends
+    from the TAIL of the arrays with weight 1 / 1 sibling (:220-234; RasterContext.skybox_points here)."""
     import diff_gaussian_rasterization as dgr
     import parity as pa
     from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
     h, cam, nodes, boxes = _setup(4000, gpu, seed=9)
-    G = h.xyz.shape[0]
+    Gh = h.xyz.shape[0]
+    G = Gh + skybox
     ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
     w = torch.zeros(G, device=gpu); ns = torch.zeros(G, dtype=torch.int32, device=gpu)
     tau = (2 * (4 + 0.5)) * cam.tanfovx / (0.5 * cam.image_width)
     n = expand_to_size(nodes, boxes, tau, cam.camera_center.to(gpu), torch.zeros(3), ri, pi, ni)
-    assert 0 < n < G
+    assert 0 < n < Gh
     get_interpolation_weights(ni[:n], tau, nodes, boxes, cam.camera_center.cpu(), torch.zeros(3), w, ns)
     gc, gd = synth.upstream_grads(cam.image_height, cam.image_width)
     gc = gc.to(gpu)
+    sky = synth.make_scene(max(skybox, 1), cam, seed=77, s_px=(6.0, 20.0), z_range=(25.0, 40.0))   # far, large
 
     def leaves():
+        tail = lambda a, b: torch.cat((a, b[:skybox].to(a)))
         mk = lambda t: t.to(gpu).clone().requires_grad_(True)
-        return dict(xyz=mk(h.xyz), sc=mk(torch.exp(h.log_scales)), rot=mk(torch.nn.functional.normalize(h.rots)),
-                    shs=mk(h.shs), op=mk(h.alpha.abs()))
+        return dict(xyz=mk(tail(h.xyz, sky.means3D)), sc=mk(tail(torch.exp(h.log_scales), sky.scales)),
+                    rot=mk(tail(torch.nn.functional.normalize(h.rots), sky.rotations)), shs=mk(tail(h.shs, sky.shs)),
+                    op=mk(tail(h.alpha.abs(), sky.opacities)))
 
-    def settings(render_indices, parent_indices):
-        kw = pa.settings_kwargs(cam, torch.zeros(3), 3, do_depth=False, device=gpu, interpolation_weights=w, num_node_kids=ns)
+    def settings(render_indices, parent_indices, weights, kids):
+        kw = pa.settings_kwargs(cam, torch.zeros(3), 3, do_depth=False, device=gpu, interpolation_weights=weights,
+                                num_node_kids=kids)
         kw["render_indices"], kw["parent_indices"] = render_indices, parent_indices
         return dgr.GaussianRasterizationSettings(**kw)
 
@@ -172,30 +179,40 @@ def test_in_op_lod_interpolation_matches_python_glue(gpu):
     parents, rots = A["rot"][p], A["rot"][r]
     dots = torch.bmm(rots.unsqueeze(1), parents.unsqueeze(2)).flatten()
     parents = torch.where((dots < 0)[:, None], -parents, parents)
-    m2a = torch.zeros(n, 3, device=gpu, requires_grad=True)
+    sk = torch.arange(G - skybox, G, device=gpu)
+    cat = lambda base, full: torch.cat((base, full[sk])).contiguous()
+    wa, ka = w.clone(), ns.clone()                       # gaussian_renderer/__init__.py:232-234
+    wa[n:n + skybox] = 1.0
+    ka[n:n + skybox] = 1
+    m2a = torch.zeros(n + skybox, 3, device=gpu, requires_grad=True)
     e = torch.empty(0, dtype=torch.int32, device=gpu)
-    ca, ra, _ = dgr.GaussianRasterizer(settings(e, e))(
-        means3D=(t * A["xyz"][r] + ti * A["xyz"][p]).contiguous(), means2D=m2a,
-        shs=(t.unsqueeze(2) * A["shs"][r] + ti.unsqueeze(2) * A["shs"][p]).contiguous(),
-        opacities=(t * A["op"][r] + ti * A["op"][p]).contiguous(),
-        scales=(t * A["sc"][r] + ti * A["sc"][p]).contiguous(), rotations=(t * rots + ti * parents).contiguous())
+    ca, ra, _ = dgr.GaussianRasterizer(settings(e, e, wa, ka))(
+        means3D=cat(t * A["xyz"][r] + ti * A["xyz"][p], A["xyz"]), means2D=m2a,
+        shs=cat(t.unsqueeze(2) * A["shs"][r] + ti.unsqueeze(2) * A["shs"][p], A["shs"]),
+        opacities=cat(t * A["op"][r] + ti * A["op"][p], A["op"]),
+        scales=cat(t * A["sc"][r] + ti * A["sc"][p], A["sc"]), rotations=cat(t * rots + ti * parents, A["rot"]))
     (ca * gc).sum().backward()
-    # (b) in-op: full arrays + index tensors
+    # (b) in-op: full arrays + index tensors (+ the skybox count on the context)
     B = leaves()
     m2b = torch.zeros(G, 3, device=gpu, requires_grad=True)
-    cb, rb, _ = dgr.GaussianRasterizer(settings(ri[:n].contiguous(), pi))(
+    ctx = dgr.RasterContext(skybox_points=skybox) if skybox else None
+    cb, rb, _ = dgr.GaussianRasterizer(settings(ri[:n].contiguous(), pi, w, ns), context=ctx)(
         means3D=B["xyz"], means2D=m2b, shs=B["shs"], opacities=B["op"], scales=B["sc"], rotations=B["rot"])
     (cb * gc).sum().backward()
-    assert torch.equal(ra, rb)
+    assert rb.shape[0] == n + skybox and torch.equal(ra, rb)
+    if skybox:
+        assert int((rb[n:] > 0).sum()) > 0, "the skybox must be on screen for the case to mean anything"
     # the in-op lerp rounds exactly like the torch expression (two rounded products, one rounded sum): same rows in,
     # same pixels out -- bit for bit, so no blend decision can flip between the two routes
     assert torch.equal(ca.detach(), cb.detach())
+    touched = torch.zeros(G, dtype=torch.bool, device=gpu); touched[r] = True; touched[p] = True; touched[sk] = True
     for k in A:
         ga, gb = A[k].grad, B[k].grad
         scale = float(ga.abs().max())
         assert float((ga - gb).abs().max()) <= 2e-5 * scale, (k, float((ga - gb).abs().max()), scale)
-        touched = torch.zeros(G, dtype=torch.bool, device=gpu); touched[r] = True; touched[p] = True
         assert float(gb[~touched].abs().sum()) == 0.0
+        if skybox:
+            assert float(gb[sk].abs().sum()) > 0.0
 
 
 def test_config5_scale_50m_node_hierarchy_4k(gpu):

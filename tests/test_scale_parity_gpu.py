@@ -53,13 +53,17 @@ def _tile_mask(tiles, W, H):
     return m
 
 
-def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, bg=(0.05, 0.1, 0.15)):
+def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, bg=(0.05, 0.1, 0.15), prepared=None):
     cam = synth.make_camera(W, H)
-    scene = synth.make_scene(P, cam, seed=seed)
     gc, gd = synth.upstream_grads(H, W, seed=seed + 1)
     bg = torch.tensor(bg)
     w = kids = None
-    if lod:                      # render_post's call shape: [>= P] weights / sibling counts, opacities may exceed 1
+    if prepared is not None:     # (scene, interpolation_weights, num_node_kids) built by the caller
+        scene, w, kids = prepared
+        P = scene.P
+    else:
+        scene = synth.make_scene(P, cam, seed=seed)
+    if lod and prepared is None:  # render_post's call shape: [>= P] weights / sibling counts, opacities may exceed 1
         g = torch.Generator().manual_seed(seed + 2)
         scene.opacities = scene.opacities * 1.3
         w = torch.rand(P + 100, generator=g)
@@ -166,3 +170,54 @@ def test_config3_shape_lod_tensors_1080p(gpu):
 def test_4k_8m_backward(gpu):
     """8 M Gaussians at 3840x2160 (L ~ 21 M): the backward at 4K, which round 1 never compared."""
     _run_case("4k_8m", gpu, 8_000_000, 3840, 2160, 96, seed=0)
+
+
+def test_config3_merged_two_chunk_hierarchy_1080p(gpu):
+    """BASELINE.json configs[2] for real: a merged 2-chunk hierarchy (hgs.hierarchy.merge_hierarchies -- the shape
+    GaussianHierarchyMerger produces, scripts/full_train.py:240-250), cut by expand_to_size at a train_post-range
+    threshold (train_post.py:66-74), weights from get_interpolation_weights, attribute lerp as render_post does it
+    (gaussian_renderer/__init__.py:204-218), then the op at 1080p with do_depth False.  Cut and weights are compared
+    bit-exactly with the LOD oracle; pixels and every gradient w.r.t. the interpolated rows tile-sampled against the
+    raster oracle."""
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    from hgs import hierarchy
+    from oracle import lod_oracle as lo
+    W, H = 1920, 1080
+    cam = synth.make_camera(W, H)
+    full = synth.make_scene(300_000, cam, seed=21)
+    left = full.means3D[:, 0] < 0
+    chunks = [hierarchy.build_hierarchy(synth.Scene(full.means3D[m], full.scales[m], full.rotations[m],
+                                                    full.opacities[m], full.shs[m], 3)) for m in (left, ~left)]
+    h = hierarchy.merge_hierarchies(chunks)
+    G = h.num_nodes
+    assert G == 1 + sum(c.num_nodes for c in chunks)
+    nodes, boxes = h.nodes.to(gpu), h.boxes.to(gpu)
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    wt = torch.zeros(G, device=gpu); ns = torch.zeros(G, dtype=torch.int32, device=gpu)
+    tau = 0.006                                   # inside train_post's log-uniform [0.005, 0.1] range: a fine cut
+    vp = cam.camera_center
+    n = expand_to_size(nodes, boxes, tau, vp.to(gpu), torch.zeros(3), ri, pi, ni)
+    get_interpolation_weights(ni[:n], tau, nodes, boxes, vp.cpu(), torch.zeros(3), wt, ns)
+    r_o, p_o, n_o = lo.expand_to_size(h.nodes.numpy(), h.boxes.numpy(), tau, vp.numpy())
+    w_o, k_o = lo.get_interpolation_weights(n_o, tau, h.nodes.numpy(), h.boxes.numpy(), vp.numpy())
+    assert n == len(r_o) and 50_000 < n < G
+    assert np.array_equal(ri[:n].cpu().numpy(), r_o) and np.array_equal(pi[:n].cpu().numpy(), p_o)
+    assert np.array_equal(ni[:n].cpu().numpy(), n_o)
+    assert np.array_equal(wt[:n].cpu().numpy().view(np.uint32), w_o.view(np.uint32))
+    assert np.array_equal(ns[:n].cpu().numpy(), k_o)
+    frac = float(((w_o > 0) & (w_o < 1)).mean())
+    assert frac > 0.02, f"only {frac:.3f} of the cut is in transition: the case would not exercise the LOD opacity"
+    # the rows render_post hands to the op (float32, torch's rounding)
+    r, p = torch.from_numpy(r_o).long(), torch.from_numpy(p_o).long()
+    t = torch.from_numpy(w_o).unsqueeze(1); ti = 1 - t
+    rots_n, rots_p = torch.nn.functional.normalize(h.rots)[r], torch.nn.functional.normalize(h.rots)[p]
+    flip = (rots_n * rots_p).sum(1) < 0
+    rots_p = torch.where(flip[:, None], -rots_p, rots_p)
+    sc = torch.exp(h.log_scales)
+    rows = synth.Scene((t * h.xyz[r] + ti * h.xyz[p]).contiguous(), (t * sc[r] + ti * sc[p]).contiguous(),
+                       (t * rots_n + ti * rots_p).contiguous(), (t * h.alpha.abs()[r] + ti * h.alpha.abs()[p]).contiguous(),
+                       (t.unsqueeze(2) * h.shs[r] + ti.unsqueeze(2) * h.shs[p]).contiguous(), 3)
+    weights = torch.zeros(G); weights[:n] = torch.from_numpy(w_o)            # [P_total] arrays, first n valid
+    kids = torch.ones(G, dtype=torch.int32); kids[:n] = torch.from_numpy(k_o)
+    _run_case("config3_merged_2chunk_hierarchy_1080p", gpu, n, W, H, 96, do_depth=False, seed=21, bg=(0.0, 0.0, 0.0),
+              prepared=(rows, weights, kids))
