@@ -110,7 +110,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
 size_t BinWs::bytes(uint32_t L, int32_t T) {
   const size_t l = L ? L : 1;
   const size_t tmp_sort = sort_tmp_bytes(L ? L : 1), tmp_bin = tile_bin_tmp_bytes(L, T);
-  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) + align_up((size_t)T * 4) +
+  return 4 * align_up(l * 4) + align_up((size_t)T * 8) + align_up(((size_t)T * 3 + 3) * 4) + align_up(((size_t)T + 8) * 4) +
          (tmp_sort > tmp_bin ? tmp_sort : tmp_bin) + kAlign;
 }
 BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
@@ -123,7 +123,7 @@ BinWs BinWs::carve_from(void* base, uint32_t L, int32_t T) {
   b.vals_out = carve<uint32_t>(c, l);
   b.ranges = carve<uint32_t>(c, (size_t)T * 2);
   b.big_tiles = carve<uint32_t>(c, (size_t)T * 3 + 3);
-  b.tile_order = carve<uint32_t>(c, (size_t)T);
+  b.tile_order = carve<uint32_t>(c, (size_t)T + 8);    // 8 * ceil(T / 8) entries
   b.sort_tmp = c;
   return b;
 }

@@ -69,7 +69,7 @@ struct BinWs {
   uint32_t* vals_out;  // [L] per tile ascending id after the tile sort; point_list after the per-tile depth sort
   uint32_t* ranges;    // [T,2]
   uint32_t* big_tiles; // [3 + 3T] counters + lists of the tiles too crowded for the one-wave register sort
-  uint32_t* tile_order; // [T] tile ids by descending instance count: launch order of the one-wave-per-tile kernels
+  uint32_t* tile_order; // [8 * ceil(T/8)] tile of workgroup b: XCD bands, heavy tiles first inside a band (binning.hip)
   void* sort_tmp;
   static size_t bytes(uint32_t L, int32_t T);
   static BinWs carve_from(void* base, uint32_t L, int32_t T);

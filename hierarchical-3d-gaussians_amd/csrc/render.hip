@@ -61,21 +61,13 @@ struct TileGeom {
 // every XCD a contiguous band of tiles; neighbouring tiles share Gaussians and therefore
 // share that XCD's L2.
 //
-// With `order` (tile_order_kernel: tiles by descending instance count): block b takes order[b].  The hardware
-// dispatches workgroups in block order, so the crowded tiles start first and the tail of the launch is made of light
-// tiles -- the one-wave-per-tile kernels run 1.6 rounds of waves, and an unsorted launch ends with a few waves of the
-// heaviest tiles keeping a handful of SIMDs busy while the rest of the chip idles.
+// With `order` (tile_order_kernel, binning.hip): the same bands, but inside its band every XCD takes the tiles by
+// descending instance count (heavy tiles first, light tiles fill the tail of the launch).
 __device__ __forceinline__ bool block_to_tile(int T, int gx, const uint32_t* __restrict__ order, TileGeom& tg) {
   const int per = (T + 7) >> 3;
   const int b = blockIdx.x;
-  int tile;
-  if (order) {
-    if (b >= T) return false;
-    tile = (int)order[b];
-  } else {
-    tile = (b & 7) * per + (b >> 3);
-  }
-  if (tile >= T) return false;
+  const int tile = order ? (int)order[b] : (b & 7) * per + (b >> 3);
+  if ((uint32_t)tile >= (uint32_t)T) return false;
   tg.tile = tile;
   tg.ty = tile / gx;
   tg.tx = tile - tg.ty * gx;

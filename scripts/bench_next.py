@@ -150,6 +150,56 @@ def leg_lod(args, dev):
                 speedup=t_glue / t_inop)
 
 
+def leg_post(args, dev):
+    """A train_post.py-shaped step (train_post.py:66-191) on a merged 2-chunk hierarchy: threshold log-uniform in
+    [0.005, 0.1] (:66-74), expand_to_size + get_interpolation_weights (:91-113), render_post with the interpolation
+    done IN the op (render_indices / parent_indices non-empty), L1 loss, backward (gather-lerp's scatter lands the
+    gradients on node and parent rows), dense Adam over all hierarchy Gaussians (torch.optim.Adam, :37,191)."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    from hgs.optim import Adam
+    W, H = 1920, 1080
+    cam = synth.make_camera(W, H)
+    full = synth.make_scene(args.leaves, cam, seed=0)
+    left = full.means3D[:, 0] < 0
+    h = hierarchy.merge_hierarchies([hierarchy.build_hierarchy(
+        synth.Scene(full.means3D[m], full.scales[m], full.rotations[m], full.opacities[m], full.shs[m], 3))
+        for m in (left, ~left)])
+    nodes, boxes = h.nodes.to(dev), h.boxes.to(dev)
+    G = h.xyz.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+    attrs = dict(xyz=h.xyz, shs=h.shs, op=h.alpha.abs().reshape(-1, 1), sc=torch.exp(h.log_scales),
+                 rot=torch.nn.functional.normalize(h.rots))
+    params = {k: torch.nn.Parameter(v.to(dev).contiguous()) for k, v in attrs.items()}
+    lrs = dict(xyz=1.6e-5, shs=2.5e-3, op=1e-3, sc=1e-6, rot=1e-5)
+    opt = Adam([dict(params=[params[k]], lr=lrs[k], name=k) for k in params], lr=0.0, eps=1e-15)
+    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    mfull = torch.zeros(G, 3, device=dev, requires_grad=True)
+    g = torch.Generator().manual_seed(3)
+    vp_gpu, vp_cpu, zero3 = cam.camera_center.to(dev), cam.camera_center.cpu(), torch.zeros(3)
+    cuts = []
+
+    def step():
+        limit = math.pow(2, torch.rand(1, generator=g).item() * (math.log2(0.1) - math.log2(0.005)) + math.log2(0.005))
+        n = expand_to_size(nodes, boxes, limit, vp_gpu, zero3, ri, pi, ni)
+        get_interpolation_weights(ni[:n], limit, nodes, boxes, vp_cpu, zero3, w, ns)
+        cuts.append(n)
+        rs = settings(dgr, cam, dev, do_depth=False, interpolation_weights=w, num_node_kids=ns,
+                      render_indices=ri[:n], parent_indices=pi)
+        color, _, _ = dgr.GaussianRasterizer(rs)(means3D=params["xyz"], means2D=mfull, shs=params["shs"],
+                                                 opacities=params["op"], scales=params["sc"], rotations=params["rot"])
+        loss = (color - target).abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step(None)                       # dense, as torch.optim.Adam in train_post.py:191
+
+    t = timed(step, args.warmup, max(args.steps, 20))
+    return dict(leg="train_post-shaped step (log-uniform tau, cut + weights, in-op LOD render, L1, backward, dense fused Adam)",
+                hierarchy_nodes=G, chunks=2, image=[W, H], mean_cut=sum(cuts) / len(cuts), min_cut=min(cuts),
+                max_cut=max(cuts), ms_per_step=t, steps_per_s=1e3 / t)
+
+
 def leg_adam(args, dev):
     from hgs.optim import Adam
     P = args.gaussians
@@ -262,13 +312,13 @@ def main():
     ap.add_argument("--leaves", type=int, default=500_000)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--legs", default="raw,lod,adam,train")
+    ap.add_argument("--legs", default="raw,lod,adam,train,post")
     args = ap.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("bench_next.py needs a GPU (no CPU fallback)")
     dev = torch.device("cuda:0")
     for name in args.legs.split(","):
-        res = {"raw": leg_raw, "lod": leg_lod, "adam": leg_adam, "train": leg_trainstep}[name](args, dev)
+        res = {"raw": leg_raw, "lod": leg_lod, "adam": leg_adam, "train": leg_trainstep, "post": leg_post}[name](args, dev)
         print(json.dumps(res), flush=True)
 
 

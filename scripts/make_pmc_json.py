@@ -1,14 +1,17 @@
 #!/usr/bin/env python
 """Derive profiles/pmc_traffic.json (HBM bytes per launch) and profiles/pmc_valu.json (vector-ALU view) from the
-per-kernel PMC summary written by scripts/pmc_summary.py.
+per-kernel PMC summary written by scripts/pmc_summary.py, and stamp them with the run they come from.
 
-    python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db ... > profiles/r01_runNN_pmc.json
-    python scripts/make_pmc_json.py profiles/r01_runNN_pmc.json
+    python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db ... > profiles/r02_runNN_pmc.json
+    python scripts/make_pmc_json.py profiles/r02_runNN_pmc.json r02_runNN [profiles/r02_microbench_valu_issue.txt]
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and gfx950's
-FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section)."""
+FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+The VALU roof (``_peak_ginst_s``) is taken from the issue-rate microbenchmark (scripts/microbench/valu_issue.hip): the
+line of K7's instruction mix at 5 waves per SIMD, the occupancy K7 runs at."""
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +27,9 @@ PER_FRAME = {}   # launches per frame of one kernel symbol when it is not 1
 
 def main():
     d = json.load(open(sys.argv[1]))
-    traffic, valu = {}, {}
+    run = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
+    traffic, valu = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT)}, {"_run": run,
+                                                                                   "_source": os.path.relpath(sys.argv[1], ROOT)}
     for stage, pats in STAGES.items():
         tot = 0.0
         for p in pats:      # template variants of one kernel (accumulate on / off ...) are averaged, not added
@@ -38,9 +43,17 @@ def main():
         for k, cs in d.items():
             if STAGES[stage][0] in k and "SQ_INSTS_VALU" in cs:
                 w = cs.get("SQ_WAVES", 0.0) or 1.0
-                valu[stage] = {"valu_insts_per_launch": cs["SQ_INSTS_VALU"], "waves": cs.get("SQ_WAVES"),
+                valu[stage] = {"valu_insts_per_launch": cs["SQ_INSTS_VALU"], "salu_insts_per_launch": cs.get("SQ_INSTS_SALU"),
+                               "waves": cs.get("SQ_WAVES"),
                                "valu_active_quadcycles_per_wave": cs.get("SQ_ACTIVE_INST_VALU", 0.0) / w,
                                "wave_quadcycles_per_wave": cs.get("SQ_WAVE_CYCLES", 0.0) / w}
+    if len(sys.argv) > 3:
+        txt = open(sys.argv[3]).read()
+        m = re.search(r"K7 mix.*waves/SIMD=5\s+[\d.]+ us\s+([\d.]+) G wave-inst/s", txt)
+        if m:
+            valu["_peak_ginst_s"] = float(m.group(1))
+            valu["_peak_source"] = (f"{os.path.relpath(sys.argv[3], ROOT)}: measured issue rate of K7's instruction mix "
+                                    "(8 pk_fma : 2 exp : 2 rcp : 4 cndmask : 16 fma) at 5 waves per SIMD on this chip")
     json.dump(traffic, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
     json.dump(valu, open(os.path.join(ROOT, "profiles", "pmc_valu.json"), "w"), indent=1)
     print(json.dumps({"traffic": traffic, "valu": valu}, indent=1))
