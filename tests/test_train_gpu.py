@@ -16,20 +16,28 @@ PSNR_TOL_DB = 0.01
 
 
 @pytest.mark.gpu
-def test_short_optimisation_psnr_matches_oracle(gpu):
-    cams, scene = tl.make_problem(P=1000, size=128, n_views=4, seed=0)
+@pytest.mark.parametrize("case", ["toy_l1", "multi_tile_l1_dssim"])
+def test_short_optimisation_psnr_matches_oracle(gpu, case):
+    """toy_l1: 1 000 Gaussians, 128x128, 40 steps, L1 + inverse depth.  multi_tile_l1_dssim: 12 000 Gaussians, 320x192
+    (240 tiles, lists of ~150 instances), 6 views, 40 steps, the reference's colour loss 0.8 L1 + 0.2 (1 - SSIM)
+    (train_single.py:101-108) + inverse depth."""
+    if case == "toy_l1":
+        cams, scene = tl.make_problem(P=1000, size=128, n_views=4, seed=0)
+        steps, dssim = 40, 0.0
+    else:
+        cams, scene = tl.make_problem(P=12000, size=320, height=192, n_views=6, seed=1)
+        steps, dssim = 40, 0.2
     bg = torch.zeros(3)
     oracle = tl.oracle_render_fn(bg, 3, torch.float64)
     hip = tl.hip_render_fn(bg, 3, gpu)
     with torch.no_grad():
         gt = {k: v.detach() for k, v in tl.activate(tl.raw_params_from_scene(scene, "cpu")).items()}
         targets = [oracle(c, gt) for c in cams]
-    steps = 40
     raw_o = tl.raw_params_from_scene(scene, "cpu", jitter_seed=5)
     raw_h = tl.raw_params_from_scene(scene, gpu, jitter_seed=5)
     p0 = tl.evaluate(oracle, raw_o, cams, targets)
-    loss_o = tl.optimise(oracle, raw_o, cams, targets, steps)
-    loss_h = tl.optimise(hip, raw_h, cams, targets, steps)
+    loss_o = tl.optimise(oracle, raw_o, cams, targets, steps, lambda_dssim=dssim)
+    loss_h = tl.optimise(hip, raw_h, cams, targets, steps, lambda_dssim=dssim)
     p_o = tl.evaluate(oracle, raw_o, cams, targets)
     p_h = tl.evaluate(hip, raw_h, cams, targets)
     # the HIP-trained parameters rendered by the oracle: renderer-independent PSNR
@@ -42,7 +50,7 @@ def test_short_optimisation_psnr_matches_oracle(gpu):
     try:
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_log.jsonl"), "a") as f:
-            f.write(json.dumps({"case": "psnr_short_optimisation", "steps": steps, "psnr_start_db": p0,
+            f.write(json.dumps({"case": "psnr_short_optimisation_" + case, "steps": steps, "psnr_start_db": p0,
                                 "psnr_oracle_db": p_o, "psnr_hip_db": p_h, "psnr_hip_via_oracle_db": p_h_via_oracle,
                                 "delta_db": p_h - p_o}) + "\n")
     except OSError:

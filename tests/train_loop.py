@@ -38,16 +38,37 @@ def activate(raw):
 LRS = dict(xyz=1.6e-3, f_dc=2.5e-2, f_rest=2.5e-2 / 20.0, opacity=5e-2, scaling=5e-3, rotation=1e-3)
 
 
-def optimise(render_fn, raw, cams, targets, steps, depth_weight=0.1):
+def ssim(img1, img2, window_size=11, sigma=1.5):
+    """Mean SSIM with an 11x11 Gaussian window (sigma 1.5), C1 = 0.01^2, C2 = 0.03^2, zero padding -- the standard
+    definition, the one the reference's loss uses (utils/loss_utils.py:33-63)."""
+    x = torch.arange(window_size, dtype=img1.dtype, device=img1.device) - window_size // 2
+    g = torch.exp(-(x ** 2) / (2 * sigma ** 2))
+    g = g / g.sum()
+    c = img1.shape[-3]
+    win = (g[:, None] * g[None, :]).expand(c, 1, window_size, window_size).contiguous()
+    conv = lambda t: torch.nn.functional.conv2d(t[None], win, padding=window_size // 2, groups=c)[0]
+    mu1, mu2 = conv(img1), conv(img2)
+    s1, s2, s12 = conv(img1 * img1) - mu1 * mu1, conv(img2 * img2) - mu2 * mu2, conv(img1 * img2) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))).mean()
+
+
+def optimise(render_fn, raw, cams, targets, steps, depth_weight=0.1, lambda_dssim=0.0):
     """render_fn(cam, activated dict) -> (color [3,H,W], invdepth [1,H,W]) on the parameters' device.
-    targets: list of (color, invdepth) per camera.  Returns the per-step loss list."""
+    targets: list of (color, invdepth) per camera.  ``lambda_dssim`` > 0: the reference's colour loss
+    (1 - l) * L1 + l * (1 - SSIM) (train_single.py:101-108, arguments/__init__.py:98: l = 0.2).
+    Returns the per-step loss list."""
     opt = torch.optim.Adam([dict(params=[raw[k]], lr=LRS[k], name=k) for k in LRS], eps=1e-15)
     losses = []
     for it in range(steps):
         k = it % len(cams)
         color, invd = render_fn(cams[k], activate(raw))
         tc, td = targets[k]
-        loss = (color - tc.to(color)).abs().mean() + depth_weight * (invd - td.to(invd)).abs().mean()
+        tc = tc.to(color)
+        l1 = (color - tc).abs().mean()
+        if lambda_dssim > 0:
+            l1 = (1.0 - lambda_dssim) * l1 + lambda_dssim * (1.0 - ssim(color, tc))
+        loss = l1 + depth_weight * (invd - td.to(invd)).abs().mean()
         opt.zero_grad(set_to_none=True)
         loss.backward()
         opt.step()
@@ -92,7 +113,8 @@ def hip_render_fn(bg, sh_degree, device):
     return fn
 
 
-def make_problem(P=1000, size=128, n_views=4, seed=0):
-    cams = [synth.orbit_camera(size, size, k, n_views) for k in range(n_views)]
-    scene = synth.make_scene(P, synth.make_camera(size, size), seed=seed)
+def make_problem(P=1000, size=128, n_views=4, seed=0, height=None):
+    height = size if height is None else height
+    cams = [synth.orbit_camera(size, height, k, n_views) for k in range(n_views)]
+    scene = synth.make_scene(P, synth.make_camera(size, height), seed=seed)
     return cams, scene
