@@ -18,8 +18,9 @@ backward, preprocess backward) through the C ABI with inputs resident in HBM:
   bucket, SH colours of the k views from ONE pass over the coefficients (hgs_sh_colors_batched -- the HIP form of the
   reference's convert_SHs_python route, gaussian_renderer/__init__.py:84-89) and dL/dSH from ONE pass
   (hgs_sh_colors_batched_bwd), backwards on a second HIP stream next to the following view's forward.  With N > 1
-  every rank renders different views of the same replicated Gaussians and the step ends with ONE RCCL all-reduce of
-  that bucket (per-view data parallelism with gradient accumulation).  Per-rank work is the same for
+  every rank renders different views of the same replicated Gaussians and the step ends with the RCCL all-reduce of
+  that bucket, issued in two parts ((opacity, scale, rotation) while the batched SH backward still runs, then
+  (position, SH)) -- per-view data parallelism with gradient accumulation, SURVEY.md §8(e).  Per-rank work is the same for
   every N (weak scaling); value = N * views_per_step * steps / max-over-ranks time.
 
 At N = 1 ``value`` is the DROP-IN number and ``batched.value`` the other one; at N > 1 ``value`` == ``batched.value``
@@ -275,8 +276,12 @@ def main():
                                           scales=params["scales"], rotations=params["rotations"])
                 info["L"], info["radii"] = color.grad_fn.num_rendered, radii
                 torch.autograd.backward([color, invd], [gc, gd])        # every gradient lands in a buffer
+            # N > 1: the (opacity, scale, rotation) slice of the bucket is final once the last view's per-Gaussian backward
+            # has run -- it goes on the wire (ordered after that backward) while the batched SH backward still runs
+            early = _reduce_async(rc, bucket, dp.DataParallelStep.EARLY)
             rc.sh_colors_batched_backward(params["means3D"], params["shs"], scene.sh_degree, state["campos"], clamps,
                                           d_rgbs, bucket.views["shs"], bucket.views["means3D"])
+            late = _reduce_async(rc, bucket, dp.DataParallelStep.LATE)
         else:
             for j, rast in enumerate(rasts):
                 rc.grad_accumulate = j > 0
@@ -285,11 +290,33 @@ def main():
                                           rotations=params["rotations"])
                 info["L"], info["radii"] = color.grad_fn.num_rendered, radii
                 torch.autograd.backward([color, invd], [gc, gd])
+            early = None
             if rc.defer_sh_backward:
+                early = _reduce_async(rc, bucket, dp.DataParallelStep.EARLY)
                 rc.finish_deferred_sh_backward()
+                late = _reduce_async(rc, bucket, dp.DataParallelStep.LATE)
+            else:
+                late = _reduce_async(rc, bucket, bucket.names)
+        for work in (early, late):
+            if work is not None:
+                work.wait()
         rc.wait_backward_stream()
-        if world > 1:
-            bucket.all_reduce()
+
+    def _reduce_async(rc, bucket, names):
+        """SUM all-reduce of one contiguous group of the bucket, issued on the stream the backwards run on."""
+        if world == 1:
+            return None
+        sb = rc.backward_stream
+        if sb is None:
+            return bucket.all_reduce_async(names)
+        with torch.cuda.stream(sb):
+            work = bucket.all_reduce_async(names)
+
+        class _OnStream:                      # wait() must order the BACKWARD stream (wait_backward_stream does the rest)
+            def wait(self_inner):
+                with torch.cuda.stream(sb):
+                    work.wait()
+        return _OnStream()
 
     def measure(step, steps, warmup, dominant_timing):
         for _ in range(warmup):
@@ -361,7 +388,7 @@ def main():
                         (", SH backward batched over the views" if defer_sh else "") +
                         (", SH colours and their backward batched over the views" if sh_fwd else "") +
                         (", backwards on a second HIP stream" if overlap else "") +
-                        (", one RCCL all-reduce of the 59P-float grad bucket per step" if world > 1 else ""))
+                        (", RCCL all-reduce of the 59P-float grad bucket per step in two parts, the first overlapping the SH backward" if world > 1 else ""))
         dropin_desc = ("one view per step, GaussianRasterizer(raster_settings)(means3D, means2D, shs, opacities, scales, "
                        "rotations) + backward exactly as train_single.py:97,123 / gaussian_renderer/__init__.py:105-113, "
                        "one stream, no opt-in API" + (", all-reduce of the gradients every step" if world > 1 else ""))
