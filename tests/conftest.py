@@ -12,6 +12,11 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run under gpurun)")
+    # The oracle issues thousands of small per-tile tensor ops; on a 256-thread host torch's default thread pool turns
+    # each of them into a fork-join over every core (the 40-step PSNR case took 8 minutes that way, 1 minute with 8
+    # threads).
+    import torch
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, 16)))
 
 
 @pytest.fixture(scope="session")
