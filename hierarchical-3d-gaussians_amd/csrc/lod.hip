@@ -65,6 +65,48 @@ __global__ __launch_bounds__(256) void lod_expand_level_kernel(const int32_t* __
   }
 }
 
+// Single-pass cut for hierarchies whose boxes NEST (child AABB inside the parent's, child extent <= parent extent --
+// checked once per hierarchy by lod_nested_kernel): then size(parent) >= size(child) from every viewpoint, "all
+// ancestors are too coarse" collapses to "the parent is too coarse", and every node decides for itself -- one launch
+// over the N nodes instead of one launch per tree level (24 levels x ~8 us at 1 M nodes).
+__global__ __launch_bounds__(256) void lod_mark_kernel(const int32_t* __restrict__ nodes, const float* __restrict__ boxes,
+                                                       int N, float tau, Vec3 vp, uint32_t* __restrict__ emit_cnt,
+                                                       uint32_t* __restrict__ block_sums) {
+  __shared__ uint32_t wave_tot[4];
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  uint32_t cnt = 0;
+  if (n < N) {
+    const int32_t* nd = nodes + (size_t)n * kNodeInts;
+    const int par = nd[1];
+    const bool reached = par < 0 || node_size(boxes, par, vp) >= tau;
+    if (reached) cnt = node_size(boxes, n, vp) >= tau ? (uint32_t)nd[3] : (uint32_t)(nd[3] + nd[4]);
+    emit_cnt[n] = cnt;
+  }
+  uint32_t v = cnt;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+}
+
+// flag[0] = 1 if some node's box is not inside its parent's or has a larger extent (view independent)
+__global__ __launch_bounds__(256) void lod_nested_kernel(const int32_t* __restrict__ nodes, const float* __restrict__ boxes,
+                                                         int N, uint32_t* __restrict__ flag) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int par = nodes[(size_t)n * kNodeInts + 1];
+  if (par < 0) return;
+  if (par >= N) { *flag = 1u; return; }
+  const float4 cmn = reinterpret_cast<const float4*>(boxes)[(size_t)n * 2 + 0];
+  const float4 cmx = reinterpret_cast<const float4*>(boxes)[(size_t)n * 2 + 1];
+  const float4 pmn = reinterpret_cast<const float4*>(boxes)[(size_t)par * 2 + 0];
+  const float4 pmx = reinterpret_cast<const float4*>(boxes)[(size_t)par * 2 + 1];
+  const bool ok = cmn.x >= pmn.x && cmn.y >= pmn.y && cmn.z >= pmn.z && cmx.x <= pmx.x && cmx.y <= pmx.y &&
+                  cmx.z <= pmx.z && cmn.w <= pmn.w && cmn.x <= cmx.x && cmn.y <= cmx.y && cmn.z <= cmx.z;
+  if (!ok) *flag = 1u;      // benign race: every writer stores 1 (NaNs fail the comparisons and land here too)
+}
+
 // per-workgroup sums of emit_cnt (256 nodes per workgroup)
 __global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __restrict__ emit_cnt, int N,
                                                              uint32_t* __restrict__ block_sums) {
@@ -205,6 +247,26 @@ size_t hgs_expand_tmp_bytes(int32_t N) {
   return 3 * align_up(n * 4) + align_up((kMaxLevels + 2) * 4) + align_up(((n + 255) / 256 + 1) * 4) + kAlign;
 }
 
+static int expand_finish(const int32_t* nodes, const ExpandTmp& t, int32_t N, int32_t* render_indices,
+                         int32_t* parent_indices, int32_t* nodes_for_render_indices, int32_t capacity,
+                         int32_t* count_out_host, hipStream_t s) {
+  const int nblk = (N + 255) / 256;
+  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(1), dim3(1024), 0, s, t.block_sums, nblk);
+  HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
+  hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,
+                     render_indices, parent_indices, nodes_for_render_indices, capacity);
+  HGS_LAUNCH_CHECK("lod_emit", s, false);
+  uint32_t total = 0;
+  HGS_HIP(hipMemcpyAsync(&total, t.block_sums + nblk, 4, hipMemcpyDeviceToHost, s));
+  HGS_HIP(hipStreamSynchronize(s));
+  if (total > (uint32_t)capacity) {
+    set_error("expand_to_size: %u entries exceed the output capacity %d", total, capacity);
+    return HGS_ERR_INVALID;
+  }
+  *count_out_host = (int32_t)total;
+  return HGS_OK;
+}
+
 int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, float size, const float viewpoint[3],
                        const float viewdir[3], int32_t* render_indices, int32_t* parent_indices,
                        int32_t* nodes_for_render_indices, int32_t capacity, void* tmp, int32_t* count_out_host,
@@ -250,19 +312,47 @@ int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, floa
   const int nblk = (N + 255) / 256;
   hipLaunchKernelGGL(lod_block_sums_kernel, dim3(nblk), dim3(256), 0, s, t.emit_cnt, N, t.block_sums);
   HGS_LAUNCH_CHECK("lod_block_sums", s, false);
-  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(1), dim3(1024), 0, s, t.block_sums, nblk);
-  HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
-  hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,
-                     render_indices, parent_indices, nodes_for_render_indices, capacity);
-  HGS_LAUNCH_CHECK("lod_emit", s, false);
-  uint32_t total = 0;
-  HGS_HIP(hipMemcpyAsync(&total, t.block_sums + nblk, 4, hipMemcpyDeviceToHost, s));
-  HGS_HIP(hipStreamSynchronize(s));
-  if (total > (uint32_t)capacity) {
-    set_error("expand_to_size: %u entries exceed the output capacity %d", total, capacity);
+  return expand_finish(nodes, t, N, render_indices, parent_indices, nodes_for_render_indices, capacity, count_out_host, s);
+}
+
+int hgs_expand_to_size_nested(const int32_t* nodes, const float* boxes, int32_t N, float size, const float viewpoint[3],
+                              const float viewdir[3], int32_t* render_indices, int32_t* parent_indices,
+                              int32_t* nodes_for_render_indices, int32_t capacity, void* tmp, int32_t* count_out_host,
+                              hgs_stream_t stream, int device) {
+  (void)viewdir;
+  if (!count_out_host) { set_error("null count_out_host"); return HGS_ERR_INVALID; }
+  *count_out_host = 0;
+  if (N <= 0) return HGS_OK;
+  if (!nodes || !boxes || !viewpoint || !render_indices || !parent_indices || !nodes_for_render_indices || !tmp) {
+    set_error("null argument");
     return HGS_ERR_INVALID;
   }
-  *count_out_host = (int32_t)total;
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const ExpandTmp t = carve_expand(tmp, N);
+  const Vec3 vp = {viewpoint[0], viewpoint[1], viewpoint[2]};
+  hipLaunchKernelGGL(lod_mark_kernel, dim3((N + 255) / 256), dim3(256), 0, s, nodes, boxes, N, size, vp, t.emit_cnt,
+                     t.block_sums);
+  HGS_LAUNCH_CHECK("lod_mark", s, false);
+  return expand_finish(nodes, t, N, render_indices, parent_indices, nodes_for_render_indices, capacity, count_out_host, s);
+}
+
+int hgs_hier_boxes_nested(const int32_t* nodes, const float* boxes, int32_t N, void* tmp, int32_t* nested_out_host,
+                          hgs_stream_t stream, int device) {
+  if (!nested_out_host) { set_error("null nested_out_host"); return HGS_ERR_INVALID; }
+  *nested_out_host = 1;
+  if (N <= 0) return HGS_OK;
+  if (!nodes || !boxes || !tmp) { set_error("null argument"); return HGS_ERR_INVALID; }
+  HGS_HIP(hipSetDevice(device));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint32_t* flag = static_cast<uint32_t*>(tmp);
+  HGS_HIP(hipMemsetAsync(flag, 0, 4, s));
+  hipLaunchKernelGGL(lod_nested_kernel, dim3((N + 255) / 256), dim3(256), 0, s, nodes, boxes, N, flag);
+  HGS_LAUNCH_CHECK("lod_nested", s, false);
+  uint32_t bad = 0;
+  HGS_HIP(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, s));
+  HGS_HIP(hipStreamSynchronize(s));
+  *nested_out_host = bad ? 0 : 1;
   return HGS_OK;
 }
 

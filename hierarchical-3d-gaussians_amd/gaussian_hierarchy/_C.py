@@ -30,10 +30,32 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+# (nodes ptr, boxes ptr, N, nodes version, boxes version) -> do the boxes nest?  (view independent: checked once per
+# hierarchy; an in-place edit of either tensor bumps its version and triggers a re-check)
+_nested_cache = {}
+
+
+def _boxes_nested(nodes, boxes) -> bool:
+    key = (nodes.data_ptr(), boxes.data_ptr(), nodes.shape[0], nodes._version, boxes._version)
+    hit = _nested_cache.get(key)
+    if hit is None:
+        lib = _lib.lib()
+        dev = nodes.device
+        tmp = torch.empty(4, dtype=torch.uint8, device=dev)
+        out = C.c_int32(0)
+        _lib.check(lib.hgs_hier_boxes_nested(_lib.ptr(nodes), _lib.ptr(boxes), nodes.shape[0], _lib.ptr(tmp),
+                                             C.byref(out), _stream(dev), dev.index or 0), "hgs_hier_boxes_nested")
+        if len(_nested_cache) > 16:
+            _nested_cache.clear()
+        hit = _nested_cache[key] = bool(out.value)
+    return hit
+
+
 def expand_to_size(nodes, boxes, size, viewpoint, viewdir, render_indices, parent_indices,
                    nodes_for_render_indices) -> int:
     """LOD cut for one view (train_post.py:91-99, render_hierarchy.py:58-66).  Fills the three
-    preallocated int32 GPU arrays and returns how many entries are valid."""
+    preallocated int32 GPU arrays and returns how many entries are valid.  Hierarchies whose boxes nest (every one
+    built by bounding-box union) take the single-pass kernel, anything else the level-by-level expansion."""
     _check_hier(nodes, boxes)
     for t in (render_indices, parent_indices, nodes_for_render_indices):
         if not t.is_cuda or t.dtype != torch.int32 or not t.is_contiguous():
@@ -45,9 +67,10 @@ def expand_to_size(nodes, boxes, size, viewpoint, viewdir, render_indices, paren
     tmp = torch.empty(lib.hgs_expand_tmp_bytes(N), dtype=torch.uint8, device=dev)
     count = C.c_int32(0)
     p = _lib.ptr
-    _lib.check(lib.hgs_expand_to_size(p(nodes), p(boxes), N, float(size), _vec3(viewpoint), _vec3(viewdir),
-                                      p(render_indices), p(parent_indices), p(nodes_for_render_indices), cap,
-                                      p(tmp), C.byref(count), _stream(dev), dev.index or 0), "hgs_expand_to_size")
+    fn = lib.hgs_expand_to_size_nested if (N > 0 and _boxes_nested(nodes, boxes)) else lib.hgs_expand_to_size
+    _lib.check(fn(p(nodes), p(boxes), N, float(size), _vec3(viewpoint), _vec3(viewdir),
+                  p(render_indices), p(parent_indices), p(nodes_for_render_indices), cap,
+                  p(tmp), C.byref(count), _stream(dev), dev.index or 0), "hgs_expand_to_size")
     return int(count.value)
 
 

@@ -101,6 +101,9 @@ SIGNATURES = {
     "hgs_expand_tmp_bytes": (C.c_size_t, [C.c_int32]),
     "hgs_expand_to_size": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                      _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int32), _P, C.c_int]),
+    "hgs_expand_to_size_nested": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                            _P, _P, _P, C.c_int32, _P, C.POINTER(C.c_int32), _P, C.c_int]),
+    "hgs_hier_boxes_nested": (C.c_int, [_P, _P, C.c_int32, _P, C.POINTER(C.c_int32), _P, C.c_int]),
     "hgs_interp_weights": (C.c_int, [_P, C.c_int32, C.c_float, _P, _P, C.c_int32, C.POINTER(C.c_float),
                                      C.POINTER(C.c_float), _P, _P, _P, C.c_int]),
     "hgs_lod_gather": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),

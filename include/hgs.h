@@ -254,6 +254,18 @@ int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, floa
                        int32_t* render_indices, int32_t* parent_indices,
                        int32_t* nodes_for_render_indices, int32_t capacity, void* tmp,
                        int32_t* count_out_host, hgs_stream_t stream, int device);
+/* Same cut in ONE pass over the nodes instead of one launch per tree level -- valid when the boxes NEST (every
+ * child's AABB inside its parent's, child extent <= parent extent): then size(parent) >= size(child) from every
+ * viewpoint and a node only has to look at its parent.  hgs_hier_boxes_nested checks the precondition (view
+ * independent: once per hierarchy; tmp >= 4 bytes of device memory); the Python binding caches the answer per
+ * (nodes, boxes) pair and falls back to hgs_expand_to_size when it is 0.  Same arguments, same outputs. */
+int hgs_expand_to_size_nested(const int32_t* nodes, const float* boxes, int32_t N, float size,
+                              const float viewpoint[3], const float viewdir[3],
+                              int32_t* render_indices, int32_t* parent_indices,
+                              int32_t* nodes_for_render_indices, int32_t capacity, void* tmp,
+                              int32_t* count_out_host, hgs_stream_t stream, int device);
+int hgs_hier_boxes_nested(const int32_t* nodes, const float* boxes, int32_t N, void* tmp, int32_t* nested_out_host,
+                          hgs_stream_t stream, int device);
 int hgs_interp_weights(const int32_t* node_indices, int32_t n, float size, const int32_t* nodes,
                        const float* boxes, int32_t N, const float viewpoint[3], const float viewdir[3],
                        float* interpolation_weights, int32_t* num_siblings,

@@ -41,6 +41,45 @@ def test_expand_to_size_and_weights_match_oracle(gpu, P):
             assert np.array_equal(w[:n].cpu().numpy().view(np.uint32), w_o.view(np.uint32)), "weights must be bit-exact"
 
 
+def test_single_pass_and_level_by_level_cuts_agree(gpu):
+    """Hierarchies whose boxes nest take the single-pass kernel (hgs_expand_to_size_nested), anything else the
+    level-by-level expansion; both must give the oracle's cut.  A hierarchy is made non-nested by letting one box stick
+    out of its parent's (in place: the cached answer of the nesting check must be invalidated by the edit)."""
+    import ctypes as C
+    from gaussian_hierarchy import _C as gh
+    from gaussian_hierarchy._C import expand_to_size
+    from hgs import _lib
+    h, cam, nodes, boxes = _setup(20_000, gpu, seed=4)
+    G = h.xyz.shape[0]
+    assert gh._boxes_nested(nodes, boxes)
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    vp = torch.tensor([0.3, -0.2, -0.5])
+    lib = _lib.lib()
+    tmp = torch.empty(lib.hgs_expand_tmp_bytes(G), dtype=torch.uint8, device=gpu)
+    p = _lib.ptr
+    v3 = lambda t: (C.c_float * 3)(*[float(x) for x in t])
+    for tau in (0.0, 0.004, 0.03, 0.4, 1e4):
+        r_o, p_o, n_o = lo.expand_to_size(h.nodes.numpy(), h.boxes.numpy(), tau, vp.numpy())
+        for fn in (lib.hgs_expand_to_size_nested, lib.hgs_expand_to_size):
+            cnt = C.c_int32(0)
+            ri.fill_(-7); pi.fill_(-7); ni.fill_(-7)
+            _lib.check(fn(p(nodes), p(boxes), G, float(tau), v3(vp), v3(torch.zeros(3)), p(ri), p(pi), p(ni), G, p(tmp),
+                          C.byref(cnt), C.c_void_p(torch.cuda.current_stream().cuda_stream), 0), "expand")
+            n = cnt.value
+            assert n == len(r_o)
+            assert np.array_equal(ri[:n].cpu().numpy(), r_o) and np.array_equal(pi[:n].cpu().numpy(), p_o)
+            assert np.array_equal(ni[:n].cpu().numpy(), n_o)
+    # a child box that sticks out of its parent's: the sizes are no longer monotone for every viewpoint
+    child = int(torch.nonzero(h.nodes[:, 1] > 0)[5])
+    boxes[child, 1, :3] += 50.0
+    hb = h.boxes.clone(); hb[child, 1, :3] += 50.0
+    assert not gh._boxes_nested(nodes, boxes)
+    for tau in (0.004, 0.03, 0.4):
+        n = expand_to_size(nodes, boxes, tau, vp.to(gpu), torch.zeros(3), ri, pi, ni)     # picks the general path
+        r_o, p_o, n_o = lo.expand_to_size(h.nodes.numpy(), hb.numpy(), tau, vp.numpy())
+        assert n == len(r_o) and np.array_equal(ri[:n].cpu().numpy(), r_o) and np.array_equal(ni[:n].cpu().numpy(), n_o)
+
+
 def test_dist_knn3_matches_brute_force(gpu):
     from simple_knn._C import distCUDA2
     g = torch.Generator().manual_seed(3)
