@@ -90,7 +90,7 @@ size_t GeomWs::bytes(int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
   const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
   return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
-         align_up((nblk + 1) * 4) + kAlign;
+         align_up((nblk + 1) * 4) + align_up(p * 9 * 4) + kAlign;
 }
 GeomWs GeomWs::carve_from(void* base, int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -104,6 +104,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
   g.offsets = carve<uint32_t>(c, p);
   g.flags = carve<uint32_t>(c, p);
   g.block_sums = carve<uint32_t>(c, nblk + 1);
+  g.shjac = carve<float>(c, p * 9);
   return g;
 }
 

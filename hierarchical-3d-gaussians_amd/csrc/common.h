@@ -58,6 +58,7 @@ struct GeomWs {
   uint32_t* offsets;       // [P] exclusive
   uint32_t* flags;         // [P] bit0..2 colour clamp, bit3 tx clamped, bit4 ty clamped
   uint32_t* block_sums;    // [nblk+1] exclusive scan of per-workgroup instance counts (index order); [nblk] = L
+  float* shjac;            // [P,9] d(rgb)/d(view direction), rows = direction component (hgs_raster_args.prepare_backward)
   static size_t bytes(int32_t P);
   static GeomWs carve_from(void* base, int32_t P);
 };

@@ -286,6 +286,27 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
             r2 += b[k] * sh[k * 3 + 2];
           }
         }
+        if (a.prepare_backward) {
+          // d(rgb)/d(direction) for the backward's SH kernel (it would otherwise read the 3M coefficients again just to
+          // form these nine sums): J[d][c] = sum_k db_k/d(dir_d) * sh[k][c]
+          float dbx[16], dby[16], dbz[16];
+          sh_basis_grad(a.sh_degree, dx, dy, dz, dbx, dby, dbz);
+          float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            if (k < nb) {
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                J[0 + c] += dbx[k] * sh[k * 3 + c];
+                J[3 + c] += dby[k] * sh[k * 3 + c];
+                J[6 + c] += dbz[k] * sh[k * 3 + c];
+              }
+            }
+          }
+          float* jd = g.shjac + (size_t)idx * 9;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) jd[i] = J[i];
+        }
         r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
         if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
         if (r1 < 0.f) { r1 = 0.f; flags |= 2u; }
@@ -620,7 +641,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 // K8b: SH part of the backward.  Pure streaming kernel (192 B of coefficients in, 192 B of gradients out
 // per Gaussian at M = 16), split from the double-precision geometry chain of K8a so that it runs at high
 // occupancy.  Adds the view-direction term to dL/dmeans3D written by K8a.
-template <bool ACC>
+template <bool ACC, bool JAC>   // JAC: d(rgb)/d(direction) was stored by K1 (prepare_backward): the coefficients are not read
 __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                            const float* __restrict__ drgb, hgs_raster_grads out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -632,7 +653,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   const int idx = block_first + threadIdx.x;
   const bool valid = idx < a.P;
   const bool active = valid && g.tiles_touched[idx] != 0;
-  if (coop) {
+  if (!JAC && coop) {
     if (split) {
       coop_load_seg(a.shs, block_first, a.P, 3, 0, sh_row_stride(n), lds);
       coop_load_seg(a.shs_rest, block_first, a.P, n - 3, 3, sh_row_stride(n), lds);
@@ -644,30 +665,44 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   float dsh[48];
 #pragma unroll
   for (int i = 0; i < 48; ++i) dsh[i] = 0.f;
-  float sh[48];
-  if (active) {
-    if (coop) lds_row_read(lds, n, sh);
-    else if (split) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
-    else load_sh(a.shs, idx, a.M, sh);
+  float sh[JAC ? 1 : 48];
+  if constexpr (!JAC) {
+    if (active) {
+      if (coop) lds_row_read(lds, n, sh);
+      else if (split) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
+      else load_sh(a.shs, idx, a.M, sh);
+    }
   }
-  if (coop) __syncthreads();                      // every row has been read: the buffer becomes the output stage
+  if (!JAC && coop) __syncthreads();              // every row has been read: the buffer becomes the output stage
   if (active) {
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
     const float px = a.means3D[idx * 3 + 0], py = a.means3D[idx * 3 + 1], pz = a.means3D[idx * 3 + 2];
     const float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
-    float b[16], dbx[16], dby[16], dbz[16];
+    float b[16];
     sh_basis(a.sh_degree, ux, uy, uz, b);
-    sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
     float gdx = 0.f, gdy = 0.f, gdz = 0.f;
+    if constexpr (JAC) {
+      const float* J = g.shjac + (size_t)idx * 9;
+      gdx = gr[0] * J[0] + gr[1] * J[1] + gr[2] * J[2];
+      gdy = gr[0] * J[3] + gr[1] * J[4] + gr[2] * J[5];
+      gdz = gr[0] * J[6] + gr[1] * J[7] + gr[2] * J[8];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k < nb) {
-        dsh[k * 3 + 0] = b[k] * gr[0]; dsh[k * 3 + 1] = b[k] * gr[1]; dsh[k * 3 + 2] = b[k] * gr[2];
-        const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
-        gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
+      for (int k = 0; k < 16; ++k) {
+        if (k < nb) { dsh[k * 3 + 0] = b[k] * gr[0]; dsh[k * 3 + 1] = b[k] * gr[1]; dsh[k * 3 + 2] = b[k] * gr[2]; }
+      }
+    } else {
+      float dbx[16], dby[16], dbz[16];
+      sh_basis_grad(a.sh_degree, ux, uy, uz, dbx, dby, dbz);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < nb) {
+          dsh[k * 3 + 0] = b[k] * gr[0]; dsh[k * 3 + 1] = b[k] * gr[1]; dsh[k * 3 + 2] = b[k] * gr[2];
+          const float dotc = gr[0] * sh[k * 3 + 0] + gr[1] * sh[k * 3 + 1] + gr[2] * sh[k * 3 + 2];
+          gdx += dbx[k] * dotc; gdy += dby[k] * dotc; gdz += dbz[k] * dotc;
+        }
       }
     }
     // through the normalisation dir = d/|d|
@@ -931,7 +966,8 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-      auto k8b = a.accumulate_grads ? sh_bwd_kernel<true> : sh_bwd_kernel<false>;
+      auto k8b = a.prepare_backward ? (a.accumulate_grads ? sh_bwd_kernel<true, true> : sh_bwd_kernel<false, true>)
+                                    : (a.accumulate_grads ? sh_bwd_kernel<true, false> : sh_bwd_kernel<false, false>);
       hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
       HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);
     }

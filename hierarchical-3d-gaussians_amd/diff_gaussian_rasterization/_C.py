@@ -145,6 +145,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
                                 image_width, sh, degree, campos, debug, interpolation_weights, num_node_kids,
                                 do_depth, sh_rest, activations)
+    a.prepare_backward = int(bool(prepare_backward))
     dev = means3D.device
     H, W = int(image_height), int(image_width)
     u8 = dict(dtype=torch.uint8, device=dev)

@@ -28,6 +28,7 @@ class RasterArgs(C.Structure):
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
         ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
+        ("prepare_backward", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

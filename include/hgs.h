@@ -100,6 +100,13 @@ typedef struct hgs_raster_args {
    * that kernel is ALU-bound and leaves HBM idle, so the 48 B per instance of zeroes cost nothing there -- and the
    * backward, seeing the same pointer, skips its own memset.  NULL: the backward clears the scratch itself. */
   void* bwd_ws_prezero;
+  /* The caller will run hgs_raster_bwd on the workspaces of this forward (must hold the SAME value in the forward and
+   * in the backward call).  The forward's per-Gaussian kernel then also stores, next to the colour, the 3x3 Jacobian
+   * d(rgb)/d(view direction) (36 bytes per Gaussian, in geom_ws): it has the SH coefficients in registers anyway, and
+   * the backward's SH kernel no longer has to read them again (192 of its 396 bytes per Gaussian at M = 16).
+   * 0: nothing extra is stored (inference), the backward recomputes from the coefficients. */
+  int32_t prepare_backward;
+  int32_t reserved0;
 } hgs_raster_args;
 
 enum {
