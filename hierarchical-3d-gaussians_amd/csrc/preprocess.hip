@@ -210,6 +210,8 @@ __device__ __forceinline__ void load_sh_split(const float* __restrict__ dc, cons
     if (i < nr) sh[3 + i] = src[i];
 }
 
+template <bool JAC>   // JAC: also store d(rgb)/d(direction) for the backward (its own instantiation: the nine extra
+                      // accumulators and the basis-gradient arrays would cost every other caller of K1 its occupancy)
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -286,7 +288,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
             r2 += b[k] * sh[k * 3 + 2];
           }
         }
-        if (a.prepare_backward) {
+        if constexpr (JAC) {
           // d(rgb)/d(direction) for the backward's SH kernel (it would otherwise read the 3M coefficients again just to
           // form these nine sums): J[d][c] = sum_k db_k/d(dir_d) * sh[k][c]
           float dbx[16], dby[16], dbz[16];
@@ -944,7 +946,8 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     const size_t lds_bytes = a.shs ? (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float) : 0;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii);
+    auto k1 = (a.prepare_backward && a.shs) ? preprocess_fwd_kernel<true> : preprocess_fwd_kernel<false>;
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii);
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
   }
   return HGS_OK;
@@ -966,7 +969,7 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-      auto k8b = a.prepare_backward ? (a.accumulate_grads ? sh_bwd_kernel<true, true> : sh_bwd_kernel<false, true>)
+      auto k8b = (a.prepare_backward && a.shs) ? (a.accumulate_grads ? sh_bwd_kernel<true, true> : sh_bwd_kernel<false, true>)
                                     : (a.accumulate_grads ? sh_bwd_kernel<true, false> : sh_bwd_kernel<false, false>);
       hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
       HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);

@@ -423,8 +423,10 @@ def test_backward_scratch_prezero_and_memset_paths_agree(gpu):
         g = C_.rasterize_gaussians_backward(call, color, invd, gc, gd)
         res.append([t.clone() for t in g if t is not None])
         assert all(torch.isfinite(t).all() for t in res[-1])
+    # an announced backward also lets K1 store d(rgb)/d(direction) for the SH backward; the unannounced one recomputes it
+    # from the coefficients in another summation order: equal up to float32 rounding there, bit-identical otherwise
     for a, b in zip(res[0], res[1]):
-        assert torch.equal(a, b)
+        assert torch.allclose(a, b, rtol=0, atol=2e-6 * float(a.abs().max()))
     for a, b in zip(res[0], res[2]):
         assert torch.equal(a, b)
 
