@@ -5,21 +5,23 @@
 // backward entered from train_single.py:123 / train_post.py:142).
 //
 // CDNA4 design (not the CUDA 256-threads-one-pixel-each shape):
-//  * a 16x16 tile is cut into four 16x4 STRIPS; a wave64 owns S strips, i.e. a lane owns S
-//    pixels (same x, y = y0 + 4*s).  Default S=4: ONE WAVE RENDERS A WHOLE TILE.  The
-//    per-Gaussian record is read from LDS once per tile instead of once per strip (LDS
-//    broadcast bandwidth, shared by the CU's four SIMDs, is the binding resource at one pixel
-//    per lane: measured 0.53 / 0.37 / 0.35 ms forward for S = 1 / 2 / 4 at 1080p, 1 M
-//    Gaussians), no workgroup barrier is needed, and the backward's cross-lane reduction runs
-//    once per (tile, Gaussian).
-//  * dead-pair skipping: alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity).  A strip
-//    whose 64 pixels are all below that threshold (minus a 1e-3 guard band) is skipped after
-//    5 VALU instructions, before the exp; the exact alpha test still takes every borderline
-//    decision, so results do not depend on the pre-test.
-//  * pixel coordinates are TILE-RELATIVE: the record carries the pixel centre as hi + lo
-//    floats from K1's double-precision projection; (hi - tile_origin) + lo is exact to ~1e-6 px
-//    at any resolution (absolute float32 coordinates carry 6e-5 px of error at x ~ 1900).
-//  * "done" lives in the sign of T (T < 0 <=> saturated, |T| = final transmittance).
+//  * a 16x16 tile is cut into four 16x4 STRIPS; a lane owns four pixels (same x, y = y0 + 4*s) and ONE WAVE RENDERS
+//    A WHOLE TILE: the per-Gaussian record is read from LDS once per tile, no workgroup barrier is needed, and the
+//    backward's cross-lane reduction runs once per (tile, Gaussian).  Measured 0.53 / 0.37 / 0.35 ms forward for
+//    4 / 2 / 1 waves per tile before anything else was tuned (round 1).
+//  * the two strips of a PAIR (rows 0-7 resp. 8-15 of the tile) go through one instruction stream as float2 values;
+//    compares, selects, min / max, exp and rcp have no packed form and are halved by that (packed FMAs themselves cost
+//    as much as two plain ones on this chip: scripts/microbench/valu_issue.hip).
+//  * who is visited: K1 stores, per Gaussian, the half extents of the box around its alpha >= 1/255 region; the lane
+//    that stages a Gaussian into LDS tests that box against the tile's two halves, two ballots turn the answers
+//    into 64-bit masks in scalar registers, and the loop walks their set bits.  A Gaussian whose box misses the tile
+//    costs no vector instruction, one that reaches a single half never computes the other half's exponents.
+//  * inside a visited half: alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity).  If no pixel of the half is above
+//    that threshold (minus a 1e-3 guard band) the half is left after 5 vector instructions, before the exp; the exact
+//    alpha test still takes every borderline decision, so results do not depend on either pre-test.
+//  * pixel coordinates are TILE-RELATIVE: the record carries the pixel centre as hi + lo floats from K1's
+//    double-precision projection; (hi - tile_origin) + lo is exact to ~1e-6 px at any resolution.
+//  * a finished / outside pixel is moved to y = 1e18 (never a candidate again): "done" needs no flag.
 //  * backward: BACK-TO-FRONT from the forward's last contributor with
 //        T_i = T_{i+1} / (1 - alpha_i),   A_i = alpha_{i+1} q_{i+1} + (1 - alpha_{i+1}) A_{i+1},
 //        dL/dalpha_i = (q_i - A_i) T_i - T_final (dL/dC . bg) / (1 - alpha_i),   q = dL/dC . c + dL/dD / z
@@ -77,14 +79,9 @@ __device__ __forceinline__ bool block_to_tile(int T, int gx, const uint32_t* __r
 // ================================================================================
 // The kernels: one wave per tile, the four strips processed as two PACKED pairs.
 //
-// gfx950's fp32 vector peak (157 TFLOP/s) is a packed-math figure: a wave64 VALU instruction
-// occupies its SIMD for 4 cycles and v_pk_{fma,mul,add}_f32 does two floats per lane in that
-// time.  rocprof (profiles/r01_run3_pmc_sq.json) shows both compositing kernels VALU-issue-bound
-// (SQ_ACTIVE_INST_VALU x waves/SIMD ~ kernel time), so the lever is instruction count: the two
-// strips of a pair (same lane, y and y+4) go through one instruction stream as float2 values.
-// Non-live lanes are handled by zeroing alpha (an alpha = 0 Gaussian is the identity for every
-// recurrence used here), not by select-updating the state.  A finished pixel is moved to
-// y = 1e18: its power is hugely negative, so the candidate test needs no separate "done" flag.
+// Both compositing kernels are vector-issue-bound (profiles/pmc_valu.json: K7 runs at ~91 % of the issue rate measured
+// for its instruction mix), so the lever is instruction count.  Non-live lanes are handled by zeroing alpha (an
+// alpha = 0 Gaussian is the identity for every recurrence used here), not by select-updating the state.
 // ================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
