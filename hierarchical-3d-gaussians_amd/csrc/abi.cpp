@@ -162,6 +162,12 @@ static int validate(const hgs_raster_args* a) {
     if ((a->activations & HGS_ACT_OPACITY_SIGMOID) && (a->activations & HGS_ACT_OPACITY_ABS)) { set_error("choose one opacity activation"); return HGS_ERR_INVALID; }
     if ((a->activations & (HGS_ACT_SCALE_EXP | HGS_ACT_ROT_NORMALIZE)) && a->cov3D_precomp) { set_error("scale / rotation activations need scales and rotations"); return HGS_ERR_INVALID; }
     if ((a->interpolation_weights != nullptr) != (a->num_node_kids != nullptr)) { set_error("interpolation_weights and num_node_kids must be given together"); return HGS_ERR_INVALID; }
+    if ((a->lod_render_indices != nullptr) != (a->lod_parent_indices != nullptr)) { set_error("lod_render_indices and lod_parent_indices must be given together"); return HGS_ERR_INVALID; }
+    if (a->lod_render_indices) {
+      if (!a->shs || a->shs_rest || !a->scales || !a->rotations || a->activations || !a->interpolation_weights) { set_error("in-kernel LOD interpolation needs shs, scales, rotations, interpolation_weights / num_node_kids and no activations"); return HGS_ERR_INVALID; }
+      if (a->lod_n < 0 || a->lod_n > a->P || a->lod_rows < a->P - a->lod_n) { set_error("bad lod_n / lod_rows (P=%d lod_n=%d lod_rows=%d)", a->P, a->lod_n, a->lod_rows); return HGS_ERR_INVALID; }
+      if (a->defer_sh_bwd) { set_error("defer_sh_bwd is not available with in-kernel LOD interpolation"); return HGS_ERR_INVALID; }
+    }
   }
   return HGS_OK;
 }
@@ -291,6 +297,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   int rc = validate(a);
   if (rc) return rc;
   if (!geom_ws || !bin_ws || !img_ws || !bwd_ws || !out_color || !dL_dcolor || !grads) { set_error("null workspace/input"); return HGS_ERR_INVALID; }
+  if (a->lod_render_indices && !a->prepare_backward) { set_error("the backward of an in-kernel LOD interpolation needs prepare_backward = 1 in the forward and the backward call"); return HGS_ERR_INVALID; }
   if (a->P > 0) {
     if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity) { set_error("missing gradient outputs"); return HGS_ERR_INVALID; }
     if ((a->shs && !grads->dL_dshs) || (a->shs_rest && !grads->dL_dshs_rest) || (a->colors_precomp && !grads->dL_dcolors) ||

@@ -238,8 +238,53 @@ __device__ __forceinline__ void project_gaussian_d(const float p[3], const float
 // value is what every later stage (discrete float32 chain and continuous double chain) sees, exactly
 // as if the caller had passed it.  nrm receives max(|q_raw|, 1e-12) (1 without normalisation).
 // ---------------------------------------------------------------------------------------------
+// ---- in-kernel LOD interpolation (hgs_raster_args.lod_*) -------------------------------------------------------------
+struct LodRow {
+  size_t r, p;    // node row, parent row of the attribute arrays (r == p: the row is taken as it is)
+  float w, u;     // weight of the node row, 1 - w
+};
+__device__ __forceinline__ LodRow lod_row(const hgs_raster_args& a, int idx) {
+  LodRow l;
+  if (!a.lod_render_indices) { l.r = l.p = (size_t)idx; l.w = 1.0f; l.u = 0.0f; return l; }
+  if (idx < a.lod_n) {
+    l.r = (size_t)a.lod_render_indices[idx];
+    l.p = (size_t)a.lod_parent_indices[idx];
+    l.w = a.interpolation_weights[idx];
+    l.u = 1.0f - l.w;
+  } else {                                     // skybox tail of the arrays
+    l.r = l.p = (size_t)(a.lod_rows - (a.P - a.lod_n) + (idx - a.lod_n));
+    l.w = 1.0f; l.u = 0.0f;
+  }
+  return l;
+}
+// w * x + u * y with both products and the sum rounded separately (what torch's t * x[r] + (1 - t) * x[p] does)
+__device__ __forceinline__ float lod_lerp(float x, float y, float w, float u) {
+#pragma clang fp contract(off)
+  const float a = w * x, b = u * y;
+  return a + b;
+}
+__device__ __forceinline__ void load_mean(const hgs_raster_args& a, const LodRow& l, float p[3]) {
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float x = a.means3D[l.r * 3 + k];
+    p[k] = a.lod_render_indices ? lod_lerp(x, a.means3D[l.p * 3 + k], l.w, l.u) : x;
+  }
+}
+
 __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx, float sc[3], float q[4],
                                                double* nrm) {
+  if (a.lod_render_indices) {                  // interpolated row (no activations in this mode)
+    const LodRow l = lod_row(a, idx);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) sc[k] = lod_lerp(a.scales[l.r * 3 + k], a.scales[l.p * 3 + k], l.w, l.u);
+    const float4 qa = reinterpret_cast<const float4*>(a.rotations)[l.r];
+    float4 qb = reinterpret_cast<const float4*>(a.rotations)[l.p];
+    const float sgn = (qa.x * qb.x + qa.y * qb.y + qa.z * qb.z + qa.w * qb.w) < 0.0f ? -1.0f : 1.0f;
+    q[0] = lod_lerp(qa.x, sgn * qb.x, l.w, l.u); q[1] = lod_lerp(qa.y, sgn * qb.y, l.w, l.u);
+    q[2] = lod_lerp(qa.z, sgn * qb.z, l.w, l.u); q[3] = lod_lerp(qa.w, sgn * qb.w, l.w, l.u);
+    if (nrm) *nrm = 1.0;
+    return;
+  }
   sc[0] = a.scales[idx * 3 + 0]; sc[1] = a.scales[idx * 3 + 1]; sc[2] = a.scales[idx * 3 + 2];
   if (a.activations & HGS_ACT_SCALE_EXP) {
 #pragma unroll
@@ -258,6 +303,11 @@ __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx
 
 // activated opacity; dact (optional) = d(activated)/d(raw)
 __device__ __forceinline__ float load_opacity(const hgs_raster_args& a, int idx, double* dact) {
+  if (a.lod_render_indices) {
+    const LodRow l = lod_row(a, idx);
+    if (dact) *dact = 1.0;
+    return lod_lerp(a.opacities[l.r], a.opacities[l.p], l.w, l.u);
+  }
   const float raw = a.opacities[idx];
   if (a.activations & HGS_ACT_OPACITY_SIGMOID) {
     const double o = 1.0 / (1.0 + exp(-(double)raw));

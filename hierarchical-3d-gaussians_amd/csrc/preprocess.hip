@@ -210,6 +210,34 @@ __device__ __forceinline__ void load_sh_split(const float* __restrict__ dc, cons
     if (i < nr) sh[3 + i] = src[i];
 }
 
+// In-kernel LOD interpolation: the workgroup's rows are gathered (node row, parent row) and lerped on their way into
+// LDS, one lane per 16-byte chunk so that every 192-byte row is read as contiguous segments.  (node, parent, weight) of
+// row i sit in the pad floats of its LDS slot (written by lane i before the barrier that precedes this call).
+__device__ __forceinline__ void coop_gather_sh(const float* __restrict__ shs, int block_first, int P, int n, float* lds) {
+  const int count = min(kPreBlock, P - block_first);
+  const int cpr = n / 4;                                        // 16-byte chunks per row
+  const int stride = sh_row_stride(n);
+  const float4* src = reinterpret_cast<const float4*>(shs);
+  for (int v = threadIdx.x; v < count * cpr; v += kPreBlock) {
+    const int row = v / cpr, c = v - row * cpr;
+    const float* pad = lds + row * stride + n;
+    const size_t r = (size_t)__float_as_uint(pad[0]), p = (size_t)__float_as_uint(pad[1]);
+    const float w = pad[2], u = 1.0f - w;
+    const float4 x = src[r * cpr + c], y = src[p * cpr + c];
+    *reinterpret_cast<float4*>(lds + row * stride + c * 4) =
+        make_float4(lod_lerp(x.x, y.x, w, u), lod_lerp(x.y, y.y, w, u), lod_lerp(x.z, y.z, w, u), lod_lerp(x.w, y.w, w, u));
+  }
+}
+__device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, float sh[48]) {
+  const LodRow l = lod_row(a, idx);
+  const int n = a.M * 3;
+  const float* x = a.shs + l.r * n;
+  const float* y = a.shs + l.p * n;
+#pragma unroll
+  for (int i = 0; i < 48; ++i)
+    if (i < n) sh[i] = lod_lerp(x[i], y[i], l.w, l.u);
+}
+
 template <bool JAC>   // JAC: also store d(rgb)/d(direction) for the backward (its own instantiation: the nine extra
                       // accumulators and the basis-gradient arrays would cost every other caller of K1 its occupancy)
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
@@ -228,8 +256,17 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   pr.visible = false;
   float p[3] = {0.f, 0.f, 0.f};
   float sc_act[3] = {0.f, 0.f, 0.f}, q_act[4] = {1.f, 0.f, 0.f, 0.f};   // activated scale / rotation
+  const bool lod = a.lod_render_indices != nullptr;
+  const int shn = a.M * 3;
   if (idx < a.P) {
-    p[0] = a.means3D[idx * 3 + 0]; p[1] = a.means3D[idx * 3 + 1]; p[2] = a.means3D[idx * 3 + 2];
+    const LodRow lr = lod_row(a, idx);
+    load_mean(a, lr, p);
+    if (lod && a.shs && (shn & 3) == 0) {
+      // the cooperative SH gather below needs every row's (node row, parent row, weight): they ride in the four pad
+      // floats at the end of the row's LDS slot
+      float* pad = lds_sh + threadIdx.x * sh_row_stride(shn) + shn;
+      pad[0] = __uint_as_float((uint32_t)lr.r); pad[1] = __uint_as_float((uint32_t)lr.p); pad[2] = lr.w;
+    }
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
@@ -242,12 +279,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   }
   // SH coefficients: stream the workgroup's block through LDS when most of it is visible (coalesced),
   // fall back to per-lane loads (visible lanes only) when most of the block is culled.
-  const int shn = a.M * 3;
   bool coop = false;
   if (a.shs && (shn & 3) == 0) {
     coop = __syncthreads_count(pr.visible) * 2 >= kPreBlock;
     if (coop) {
-      if (a.shs_rest) {
+      if (lod) {
+        coop_gather_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
+      } else if (a.shs_rest) {
         coop_load_seg(a.shs, blockIdx.x * kPreBlock, a.P, 3, 0, sh_row_stride(shn), lds_sh);
         coop_load_seg(a.shs_rest, blockIdx.x * kPreBlock, a.P, shn - 3, 3, sh_row_stride(shn), lds_sh);
       } else {
@@ -271,6 +309,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       } else {
         float sh[48];
         if (coop) lds_row_read(lds_sh, shn, sh);
+        else if (lod) load_sh_lod(a, idx, sh);
         else if (a.shs_rest) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
         else load_sh(a.shs, idx, a.M, sh);
         float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
@@ -459,7 +498,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     sums5 = (float)s[5]; sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
     const uint32_t flags = g.flags[idx];
-    const float p[3] = {a.means3D[idx * 3 + 0], a.means3D[idx * 3 + 1], a.means3D[idx * 3 + 2]};
+    float p[3];
+    load_mean(a, lod_row(a, idx), p);
     float q[4] = {1.f, 0.f, 0.f, 0.f};
     float sc[3] = {1.f, 1.f, 1.f};
     double qnorm = 1.0;
@@ -678,8 +718,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (!JAC && coop) __syncthreads();              // every row has been read: the buffer becomes the output stage
   if (active) {
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
-    const float px = a.means3D[idx * 3 + 0], py = a.means3D[idx * 3 + 1], pz = a.means3D[idx * 3 + 2];
-    const float dx = px - a.campos[0], dy = py - a.campos[1], dz = pz - a.campos[2];
+    float pm[3];
+    load_mean(a, lod_row(a, idx), pm);
+    const float dx = pm[0] - a.campos[0], dy = pm[1] - a.campos[1], dz = pm[2] - a.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
     float b[16];

@@ -71,25 +71,39 @@ SPECULATIVE = True
 
 def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                 viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
-                debug, interpolation_weights, num_node_kids, do_depth, sh_rest=None, activations=0):
+                debug, interpolation_weights, num_node_kids, do_depth, sh_rest=None, activations=0, lod=None):
+    """``lod`` = (render_indices, parent_indices, skybox_points): in-kernel LOD interpolation -- the attribute tensors
+    hold all hierarchy Gaussians (G rows), the op renders P = len(render_indices) + skybox_points rows."""
     means3D = _require_gpu(means3D, "means3D")
     if means3D.dim() != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
-    P = means3D.shape[0]
+    rows = means3D.shape[0]                      # rows of the attribute arrays
+    P = rows
+    ri = pi = None
+    if lod is not None:
+        ri, pi, K = lod
+        for t, name in ((ri, "render_indices"), (pi, "parent_indices")):
+            if not t.is_cuda or t.dtype != torch.int32:
+                raise RuntimeError(f"{name} must be an int32 GPU tensor")
+        ri, pi = ri.contiguous(), pi.contiguous()
+        n = int(ri.numel())
+        if pi.numel() < n or K < 0 or K > rows:
+            raise RuntimeError("parent_indices shorter than render_indices, or more skybox rows than rows")
+        P = n + int(K)
     if sh is not None and sh.numel() == 0:
         sh = None
     if sh is not None:
         sh = _require_gpu(sh, "shs")
-        if sh.dim() != 3 or sh.shape[0] != P or sh.shape[2] != 3:
+        if sh.dim() != 3 or sh.shape[0] != rows or sh.shape[2] != 3:
             raise RuntimeError("shs must have dimensions (num_points, num_coeffs, 3)")
-    colors = _opt(colors, "colors_precomp", P, 3)
-    scales = _opt(scales, "scales", P, 3)
-    rotations = _opt(rotations, "rotations", P, 4)
-    cov3D_precomp = _opt(cov3D_precomp, "cov3D_precomp", P, 6)
-    if P > 0:
+    colors = _opt(colors, "colors_precomp", rows, 3)
+    scales = _opt(scales, "scales", rows, 3)
+    rotations = _opt(rotations, "rotations", rows, 4)
+    cov3D_precomp = _opt(cov3D_precomp, "cov3D_precomp", rows, 6)
+    if rows > 0:
         opacity = _require_gpu(opacity, "opacities")
-        if opacity.numel() != P:
-            raise RuntimeError(f"opacities must hold {P} values")
+        if opacity.numel() != rows:
+            raise RuntimeError(f"opacities must hold {rows} values")
         if (sh is None) == (colors is None):
             raise RuntimeError("Please provide excatly one of either SHs or precomputed colors!")
         if ((scales is None or rotations is None) and cov3D_precomp is None) or \
@@ -101,7 +115,7 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     if sh_rest is not None:
         # raw-parameter path: sh = features_dc [P,1,3], sh_rest = features_rest [P,M-1,3]
         sh_rest = _require_gpu(sh_rest, "shs_rest")
-        if sh is None or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != P or sh_rest.shape[2] != 3:
+        if sh is None or sh.shape[1] != 1 or sh_rest.dim() != 3 or sh_rest.shape[0] != rows or sh_rest.shape[2] != 3:
             raise RuntimeError("split SH storage needs features_dc (num_points, 1, 3) and features_rest (num_points, M-1, 3)")
         M = 1 + sh_rest.shape[1]
     bg = _small(background, "bg", 3)
@@ -109,6 +123,9 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     pm = _small(projmatrix, "projmatrix", 16)
     cp = _small(campos, "campos", 3)
     w, k = _lod(interpolation_weights, num_node_kids, P)
+    if lod is not None and (w is None or sh is None or scales is None or sh_rest is not None or activations):
+        raise RuntimeError("in-op LOD interpolation needs shs, scales / rotations, interpolation_weights and "
+                           "num_node_kids (no precomputed colours / covariances, no raw-parameter path)")
     a = _lib.RasterArgs()
     a.P, a.M, a.sh_degree = P, M, int(degree)
     a.width, a.height = int(image_width), int(image_height)
@@ -120,7 +137,10 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     a.scales, a.rotations, a.cov3D_precomp = p(scales), p(rotations), p(cov3D_precomp)
     a.interpolation_weights, a.num_node_kids = p(w), p(k)
     a.shs_rest, a.activations = p(sh_rest), int(activations)
-    keep = (bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, w, k, sh_rest)
+    if lod is not None:
+        a.lod_render_indices, a.lod_parent_indices = p(ri), p(pi)
+        a.lod_n, a.lod_rows = int(ri.numel()), rows
+    keep = (bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D_precomp, w, k, sh_rest, ri, pi)
     return a, keep, P, M
 
 
@@ -131,20 +151,20 @@ def _stream(device):
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tanfovx, tanfovy, image_height, image_width, sh, degree, campos,
                         prefiltered, debug, render_indices, parent_indices, interpolation_weights,
-                        num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False):
+                        num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False, lod=None):
     """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
     invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward.  ``prepare_backward``: allocate
     the backward's scratch now and let the forward's compositing kernel zero-fill it on the side
     (hgs_raster_args.bwd_ws_prezero) instead of a memset in the backward."""
-    if (render_indices is not None and render_indices.numel() > 0) or \
-            (parent_indices is not None and parent_indices.numel() > 0):
+    if lod is None and ((render_indices is not None and render_indices.numel() > 0) or
+                        (parent_indices is not None and parent_indices.numel() > 0)):
         raise RuntimeError("rasterize_gaussians expects already gathered rows; non-empty render_indices / "
-                           "parent_indices are resolved by GaussianRasterizer.forward (lod_gather) before this call")
+                           "parent_indices are resolved by GaussianRasterizer.forward (lod=...) before this call")
     lib = _lib.lib()
     a, keep, P, M = _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier,
                                 cov3D_precomp, viewmatrix, projmatrix, tanfovx, tanfovy, image_height,
                                 image_width, sh, degree, campos, debug, interpolation_weights, num_node_kids,
-                                do_depth, sh_rest, activations)
+                                do_depth, sh_rest, activations, lod)
     a.prepare_backward = int(bool(prepare_backward))
     dev = means3D.device
     H, W = int(image_height), int(image_width)
@@ -163,7 +183,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     binb = None
     scratch = None
     L_ws = 0
-    shape_key = (devi, W, H, P)
+    # with lod= the number of rendered rows changes with every cut: the hierarchy (its row count) is the workload
+    shape_key = (devi, W, H, P) if lod is None else (devi, W, H, "lod", means3D.shape[0])
     prev = _last_L.get(shape_key) if SPECULATIVE else None
     if prev is not None and P > 0:
         # no-bubble path: everything is enqueued before the host learns L
@@ -196,7 +217,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
     if len(_last_L) > 64:
         _last_L.clear()
-    _last_L[shape_key] = L.value
+    # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
+    _last_L[shape_key] = L.value if lod is None else max(L.value, int(0.9 * (prev or 0)))
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
@@ -218,7 +240,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     lib = _lib.lib()
     a, P, dev = call.args, call.P, call.device
     f32 = dict(dtype=torch.float32, device=dev)
-    bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D, w, k, sh_rest = call.keep
+    bg, vm, pm, cp, means3D, sh, colors, opacity, scales, rotations, cov3D, w, k, sh_rest = call.keep[:14]
     dL_dcolor = dL_dcolor.to(torch.float32).contiguous()
     use_depth = bool(a.do_depth) and dL_dinvdepth is not None
     if use_depth:
@@ -236,7 +258,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     d_m3 = buf("means3D", (P, 3))
     d_m2 = buf("means2D", (P, 3))
     d_op = buf("opacities", (P, 1))
-    d_sh = buf("shs", tuple(sh.shape)) if sh is not None else None
+    d_sh = buf("shs", (P,) + tuple(sh.shape[1:])) if sh is not None else None      # P rows (!= sh.shape[0] with lod=)
     d_shr = buf("shs_rest", tuple(sh_rest.shape)) if sh_rest is not None else None
     d_col = buf("colors_precomp", (P, 3)) if colors is not None else None
     d_sc = buf("scales", (P, 3)) if scales is not None else None

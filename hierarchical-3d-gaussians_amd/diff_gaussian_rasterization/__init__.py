@@ -283,22 +283,53 @@ def rasterize_gaussians_raw(xyz, means2D, features_dc, features_rest, opacity_ra
                                         rotation_raw, raster_settings, act, context)
 
 
-class _LodGather(torch.autograd.Function):
-    """In-op LOD interpolation: gather + lerp of node and parent attributes, and the matching
-    scatter in the backward -- what gaussian_renderer/__init__.py:199-218 does with ~25 torch kernels."""
+class _RasterizeGaussiansLod(torch.autograd.Function):
+    """In-op LOD interpolation: the op takes the FULL hierarchy attribute tensors plus the cut
+    (render / parent indices, weights) and interpolates node and parent rows in registers inside its per-Gaussian
+    kernels, forward and backward (hgs_raster_args.lod_*) -- what gaussian_renderer/__init__.py:199-234 does with ~25
+    torch kernels and three materialised copies of the rows.  The backward's row gradients are scattered to node and
+    parent rows by hgs_lod_gather_bwd."""
 
     @staticmethod
-    def forward(ctx, render_indices, parent_indices, weights, means3D, scales, rotations, shs, opacities):
-        n = render_indices.numel()
-        ctx.save_for_backward(render_indices, parent_indices[:n], weights[:n], rotations)
-        ctx.shapes = tuple(None if t is None else tuple(t.shape) for t in (means3D, scales, rotations, shs, opacities))
-        return _C.lod_gather(render_indices, parent_indices[:n], weights[:n], means3D, scales, rotations, shs, opacities)
+    def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, raster_settings, render_indices,
+                parent_indices, weights, kids, skybox_points):
+        rs = raster_settings
+        empty = render_indices.new_empty(0)
+        num_rendered, color, radii, geom, binb, img, invdepth, call = _C.rasterize_gaussians(
+            rs.bg, means3D, None, opacities, scales, rotations, rs.scale_modifier, None,
+            rs.viewmatrix, rs.projmatrix, rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, sh,
+            rs.sh_degree, rs.campos, rs.prefiltered, rs.debug, empty, empty, weights, kids, rs.do_depth,
+            prepare_backward=any(ctx.needs_input_grad), lod=(render_indices, parent_indices, skybox_points))
+        ctx.call = call
+        ctx.num_rendered = num_rendered
+        ctx.skybox_points = skybox_points
+        ctx.shapes = tuple(tuple(t.shape) for t in (means3D, scales, rotations, sh, opacities))
+        ctx.save_for_backward(color, invdepth, render_indices, parent_indices, weights, means3D, sh, opacities, scales,
+                              rotations)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii, invdepth
 
     @staticmethod
-    def backward(ctx, g_means, g_scales, g_rot, g_shs, g_op):
-        ri, pi, w, rotations = ctx.saved_tensors
-        ds = _C.lod_gather_backward(ri, pi, w, rotations, (g_means, g_scales, g_rot, g_shs, g_op), ctx.shapes)
-        return (None, None, None) + ds
+    def backward(ctx, grad_color, grad_radii, grad_invdepth):
+        color, invdepth, ri, pi, w, means3D, sh, opacities, scales, rotations = ctx.saved_tensors
+        call = ctx.call
+        if call is None:
+            raise RuntimeError("the rasterizer's backward ran twice (its workspaces are released after the first pass)")
+        if grad_color is None:
+            grad_color = torch.zeros_like(color)
+        d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(call, color, invdepth, grad_color,
+                                                                                   grad_invdepth)
+        ctx.call = None
+        n, K = int(ri.numel()), ctx.skybox_points
+        pi, w = pi[:n], w[:n]
+        if K > 0:      # the skybox rows are their own parents with weight 1
+            sky = torch.arange(means3D.shape[0] - K, means3D.shape[0], dtype=ri.dtype, device=ri.device)
+            ri, pi = torch.cat((ri, sky)), torch.cat((pi, sky))
+            w = torch.cat((w, torch.ones(K, dtype=w.dtype, device=w.device)))
+        g_means, g_scales, g_rot, g_shs, g_op = _C.lod_gather_backward(ri, pi, w, rotations,
+                                                                       (d_m3, d_sc, d_rot, d_sh, d_op), ctx.shapes)
+        return g_means, d_m2, g_shs, g_op, g_scales, g_rot, None, None, None, None, None, None
 
 
 def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -309,24 +340,19 @@ def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales,
         # render_indices / parent_indices / interpolation_weights select and blend the rows to draw
         if colors_precomp is not None or cov3Ds_precomp is not None:
             raise RuntimeError("in-op LOD interpolation needs shs and scales/rotations (no precomputed colours/covariances)")
-        if context is not None and context.grad_buffers is not None:
-            raise RuntimeError("grad_buffers hold gradients of the op's direct inputs; with in-op LOD interpolation "
-                               "those are the gathered rows, not the hierarchy's parameters")
+        if context is not None and (context.grad_buffers is not None or context.backward_stream is not None):
+            raise RuntimeError("grad_buffers / backward_stream are not available with in-op LOD interpolation: its "
+                               "gradients are scattered to the hierarchy's rows after the op's own backward")
         n = rs.render_indices.numel()
-        ri, pi, w, kids = rs.render_indices, rs.parent_indices[:n], rs.interpolation_weights[:n], rs.num_node_kids[:n]
         K = context.skybox_points if context is not None else 0
+        w, kids = rs.interpolation_weights, rs.num_node_kids
         if K > 0:
-            # the skybox rows ride along as their own parents with weight 1 and one sibling
+            # the skybox rows (the last K rows of the arrays) are drawn as they are, with weight 1 and one sibling
             # (gaussian_renderer/__init__.py:220-234); the caller's tensors are left untouched
-            sky = torch.arange(means3D.shape[0] - K, means3D.shape[0], dtype=ri.dtype, device=ri.device)
-            ri, pi = torch.cat((ri, sky)), torch.cat((pi, sky))
-            w = torch.cat((w, torch.ones(K, dtype=w.dtype, device=w.device)))
-            kids = torch.cat((kids, torch.ones(K, dtype=kids.dtype, device=kids.device)))
-        means3D, scales, rotations, sh, opacities = _LodGather.apply(ri, pi, w, means3D, scales, rotations, sh, opacities)
-        means2D = means2D[:n + K]
-        empty = rs.render_indices.new_empty(0)
-        raster_settings = rs._replace(render_indices=empty, parent_indices=empty, interpolation_weights=w,
-                                      num_node_kids=kids)
+            w = torch.cat((w[:n], torch.ones(K, dtype=w.dtype, device=w.device)))
+            kids = torch.cat((kids[:n], torch.ones(K, dtype=kids.dtype, device=kids.device)))
+        return _RasterizeGaussiansLod.apply(means3D, means2D[:n + K], sh, opacities, scales, rotations, rs,
+                                            rs.render_indices, rs.parent_indices, w, kids, K)
     return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
                                      cov3Ds_precomp, raster_settings, context)
 

@@ -28,7 +28,9 @@ class RasterArgs(C.Structure):
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
         ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
-        ("prepare_backward", C.c_int32), ("reserved0", C.c_int32),
+        ("prepare_backward", C.c_int32), ("lod_n", C.c_int32),
+        ("lod_render_indices", C.c_void_p), ("lod_parent_indices", C.c_void_p),
+        ("lod_rows", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

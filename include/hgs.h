@@ -106,6 +106,20 @@ typedef struct hgs_raster_args {
    * the backward's SH kernel no longer has to read them again (192 of its 396 bytes per Gaussian at M = 16).
    * 0: nothing extra is stored (inference), the backward recomputes from the coefficients. */
   int32_t prepare_backward;
+  /* In-kernel LOD interpolation.  lod_render_indices != NULL: the attribute arrays (means3D,
+   * scales, rotations, opacities, shs) hold ALL lod_rows hierarchy Gaussians and row i of the op is
+   *     i <  lod_n :  w_i * attr[lod_render_indices[i]] + (1 - w_i) * attr[lod_parent_indices[i]],  w_i = interpolation_weights[i]
+   *                   (every product and the sum rounded separately, as the torch expression of
+   *                   gaussian_renderer/__init__.py:204-218 rounds; the parent quaternion flipped into the node's hemisphere)
+   *     i >= lod_n :  attr[lod_rows - (P - lod_n) + (i - lod_n)]   -- the skybox tail (:220-234)
+   * computed in registers by the per-Gaussian kernels of the forward AND of the backward: no interpolated row is ever
+   * written to memory.  Needs shs + scales + rotations (no precomputed colours / covariances, no activations),
+   * interpolation_weights / num_node_kids with >= P entries, prepare_backward = 1 for a differentiable call.  The
+   * backward writes the gradients w.r.t. the INTERPOLATED rows ([P, ...]); hgs_lod_gather_bwd scatters them. */
+  int32_t lod_n;
+  const int32_t* lod_render_indices;
+  const int32_t* lod_parent_indices;
+  int32_t lod_rows;
   int32_t reserved0;
 } hgs_raster_args;
 

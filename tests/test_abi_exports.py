@@ -32,8 +32,9 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_layouts_match_header():
     import ctypes as C
     # hgs_raster_args: 11 x 4-byte scalars (+ 4 bytes of padding), 14 pointers, 2 x 4-byte scalars, 1 pointer,
-    # 2 x 4-byte scalars
-    assert C.sizeof(_lib.RasterArgs) == 11 * 4 + 4 + 14 * 8 + 2 * 4 + 8 + 2 * 4
+    # 2 x 4-byte scalars, 2 pointers, 2 x 4-byte scalars
+    assert C.sizeof(_lib.RasterArgs) == 11 * 4 + 4 + 14 * 8 + 2 * 4 + 8 + 2 * 4 + 2 * 8 + 2 * 4
+    assert _lib.RasterArgs.lod_render_indices.offset == 184
     assert _lib.RasterArgs.bg.offset == 48
     assert C.sizeof(_lib.RasterGrads) == 9 * 8
     assert C.sizeof(_lib.RasterViews) == 10 * 8
