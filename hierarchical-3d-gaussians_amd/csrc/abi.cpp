@@ -166,7 +166,7 @@ static int validate(const hgs_raster_args* a) {
     if (a->lod_render_indices) {
       if (!a->shs || a->shs_rest || !a->scales || !a->rotations || a->activations || !a->interpolation_weights) { set_error("in-kernel LOD interpolation needs shs, scales, rotations, interpolation_weights / num_node_kids and no activations"); return HGS_ERR_INVALID; }
       if (a->lod_n < 0 || a->lod_n > a->P || a->lod_rows < a->P - a->lod_n) { set_error("bad lod_n / lod_rows (P=%d lod_n=%d lod_rows=%d)", a->P, a->lod_n, a->lod_rows); return HGS_ERR_INVALID; }
-      if (a->defer_sh_bwd) { set_error("defer_sh_bwd is not available with in-kernel LOD interpolation"); return HGS_ERR_INVALID; }
+      if (a->defer_sh_bwd || a->accumulate_grads) { set_error("defer_sh_bwd / accumulate_grads are not available with in-kernel LOD interpolation"); return HGS_ERR_INVALID; }
     }
   }
   return HGS_OK;

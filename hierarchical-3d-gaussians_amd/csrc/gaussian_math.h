@@ -243,9 +243,11 @@ struct LodRow {
   size_t r, p;    // node row, parent row of the attribute arrays (r == p: the row is taken as it is)
   float w, u;     // weight of the node row, 1 - w
 };
+// LOD is a template parameter of the kernels that use these helpers: the plain call must not pay registers for it
+template <bool LOD>
 __device__ __forceinline__ LodRow lod_row(const hgs_raster_args& a, int idx) {
   LodRow l;
-  if (!a.lod_render_indices) { l.r = l.p = (size_t)idx; l.w = 1.0f; l.u = 0.0f; return l; }
+  if constexpr (!LOD) { l.r = l.p = (size_t)idx; l.w = 1.0f; l.u = 0.0f; return l; }
   if (idx < a.lod_n) {
     l.r = (size_t)a.lod_render_indices[idx];
     l.p = (size_t)a.lod_parent_indices[idx];
@@ -263,18 +265,21 @@ __device__ __forceinline__ float lod_lerp(float x, float y, float w, float u) {
   const float a = w * x, b = u * y;
   return a + b;
 }
+template <bool LOD>
 __device__ __forceinline__ void load_mean(const hgs_raster_args& a, const LodRow& l, float p[3]) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float x = a.means3D[l.r * 3 + k];
-    p[k] = a.lod_render_indices ? lod_lerp(x, a.means3D[l.p * 3 + k], l.w, l.u) : x;
+    if constexpr (LOD) p[k] = lod_lerp(x, a.means3D[l.p * 3 + k], l.w, l.u);
+    else p[k] = x;
   }
 }
 
+template <bool LOD>
 __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx, float sc[3], float q[4],
                                                double* nrm) {
-  if (a.lod_render_indices) {                  // interpolated row (no activations in this mode)
-    const LodRow l = lod_row(a, idx);
+  if constexpr (LOD) {                         // interpolated row (no activations in this mode)
+    const LodRow l = lod_row<true>(a, idx);
 #pragma unroll
     for (int k = 0; k < 3; ++k) sc[k] = lod_lerp(a.scales[l.r * 3 + k], a.scales[l.p * 3 + k], l.w, l.u);
     const float4 qa = reinterpret_cast<const float4*>(a.rotations)[l.r];
@@ -302,9 +307,10 @@ __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx
 }
 
 // activated opacity; dact (optional) = d(activated)/d(raw)
+template <bool LOD>
 __device__ __forceinline__ float load_opacity(const hgs_raster_args& a, int idx, double* dact) {
-  if (a.lod_render_indices) {
-    const LodRow l = lod_row(a, idx);
+  if constexpr (LOD) {
+    const LodRow l = lod_row<true>(a, idx);
     if (dact) *dact = 1.0;
     return lod_lerp(a.opacities[l.r], a.opacities[l.p], l.w, l.u);
   }

@@ -229,7 +229,7 @@ __device__ __forceinline__ void coop_gather_sh(const float* __restrict__ shs, in
   }
 }
 __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, float sh[48]) {
-  const LodRow l = lod_row(a, idx);
+  const LodRow l = lod_row<true>(a, idx);
   const int n = a.M * 3;
   const float* x = a.shs + l.r * n;
   const float* y = a.shs + l.p * n;
@@ -238,8 +238,9 @@ __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, f
     if (i < n) sh[i] = lod_lerp(x[i], y[i], l.w, l.u);
 }
 
-template <bool JAC>   // JAC: also store d(rgb)/d(direction) for the backward (its own instantiation: the nine extra
-                      // accumulators and the basis-gradient arrays would cost every other caller of K1 its occupancy)
+template <bool JAC, bool LOD>   // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD interpolation
+                                // (their own instantiations: the extra state would cost every other caller of K1 its
+                                // occupancy)
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -256,11 +257,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   pr.visible = false;
   float p[3] = {0.f, 0.f, 0.f};
   float sc_act[3] = {0.f, 0.f, 0.f}, q_act[4] = {1.f, 0.f, 0.f, 0.f};   // activated scale / rotation
-  const bool lod = a.lod_render_indices != nullptr;
+  constexpr bool lod = LOD;
   const int shn = a.M * 3;
   if (idx < a.P) {
-    const LodRow lr = lod_row(a, idx);
-    load_mean(a, lr, p);
+    const LodRow lr = lod_row<LOD>(a, idx);
+    load_mean<LOD>(a, lr, p);
     if (lod && a.shs && (shn & 3) == 0) {
       // the cooperative SH gather below needs every row's (node row, parent row, weight): they ride in the four pad
       // floats at the end of the row's LDS slot
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
 #pragma unroll
       for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
     } else {
-      load_scale_rot(a, idx, sc_act, q_act, nullptr);
+      load_scale_rot<LOD>(a, idx, sc_act, q_act, nullptr);
       float R[9], s[3];
       cov3d_from_scale_rot(sc_act, a.scale_modifier, q_act, pr.c3, R, s);
     }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       }
       if (pr.clampx) flags |= 8u;
       if (pr.clampy) flags |= 16u;
-      float opac = load_opacity(a, idx, nullptr);
+      float opac = load_opacity<LOD>(a, idx, nullptr);
       if (a.interpolation_weights && a.num_node_kids)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
       // continuous quantities from the double-precision chain (see gaussian_math.h)
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 //   5: sum G*dL/dalpha          6..8: sum w*dL/dC_k              9: sum w*dL/dD
 // with X = dL/dpower, w = alpha*T.
 // ---------------------------------------------------------------------------
-template <bool ACC>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
+template <bool ACC, bool LOD>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
 __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
                                                                    float* __restrict__ drgb,
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
     const uint32_t flags = g.flags[idx];
     float p[3];
-    load_mean(a, lod_row(a, idx), p);
+    load_mean<LOD>(a, lod_row<LOD>(a, idx), p);
     float q[4] = {1.f, 0.f, 0.f, 0.f};
     float sc[3] = {1.f, 1.f, 1.f};
     double qnorm = 1.0;
@@ -508,7 +509,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 #pragma unroll
       for (int i = 0; i < 6; ++i) pd.c3[i] = (double)a.cov3D_precomp[(size_t)idx * 6 + i];
     } else {
-      load_scale_rot(a, idx, sc, q, &qnorm);
+      load_scale_rot<LOD>(a, idx, sc, q, &qnorm);
       cov3d_from_scale_rot_d(sc, a.scale_modifier, q, pd);
     }
     project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, (flags & 8u) != 0,
@@ -629,7 +630,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     {
       float dod = 1.0f;
       double dact = 1.0;
-      const float o_act = load_opacity(a, idx, &dact);
+      const float o_act = load_opacity<LOD>(a, idx, &dact);
       if (a.interpolation_weights && a.num_node_kids)
         (void)lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
       d_op = a.activations ? (float)((double)sums5 * (double)dod * dact) : sums5 * dod;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 // K8b: SH part of the backward.  Pure streaming kernel (192 B of coefficients in, 192 B of gradients out
 // per Gaussian at M = 16), split from the double-precision geometry chain of K8a so that it runs at high
 // occupancy.  Adds the view-direction term to dL/dmeans3D written by K8a.
-template <bool ACC, bool JAC>   // JAC: d(rgb)/d(direction) was stored by K1 (prepare_backward): the coefficients are not read
+template <bool ACC, bool JAC, bool LOD>   // JAC: d(rgb)/d(direction) was stored by K1 (prepare_backward): the coefficients are not read
 __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                            const float* __restrict__ drgb, hgs_raster_grads out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -719,7 +720,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (active) {
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
     float pm[3];
-    load_mean(a, lod_row(a, idx), pm);
+    load_mean<LOD>(a, lod_row<LOD>(a, idx), pm);
     const float dx = pm[0] - a.campos[0], dy = pm[1] - a.campos[1], dz = pm[2] - a.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
@@ -987,7 +988,9 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     const size_t lds_bytes = a.shs ? (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float) : 0;
-    auto k1 = (a.prepare_backward && a.shs) ? preprocess_fwd_kernel<true> : preprocess_fwd_kernel<false>;
+    const bool jac = a.prepare_backward && a.shs;
+    auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true> : preprocess_fwd_kernel<false, true>)
+                                   : (jac ? preprocess_fwd_kernel<true, false> : preprocess_fwd_kernel<false, false>);
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii);
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
   }
@@ -1005,13 +1008,15 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
                           const hgs_raster_grads& out, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
-    auto k8a = a.accumulate_grads ? preprocess_bwd_kernel<true> : preprocess_bwd_kernel<false>;
+    auto k8a = a.lod_render_indices ? preprocess_bwd_kernel<false, true>      // (accumulation is refused with lod, abi.cpp)
+                                    : (a.accumulate_grads ? preprocess_bwd_kernel<true, false> : preprocess_bwd_kernel<false, false>);
     hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-      auto k8b = (a.prepare_backward && a.shs) ? (a.accumulate_grads ? sh_bwd_kernel<true, true> : sh_bwd_kernel<false, true>)
-                                    : (a.accumulate_grads ? sh_bwd_kernel<true, false> : sh_bwd_kernel<false, false>);
+      auto k8b = a.lod_render_indices ? sh_bwd_kernel<false, true, true>
+                 : (a.prepare_backward && a.shs) ? (a.accumulate_grads ? sh_bwd_kernel<true, true, false> : sh_bwd_kernel<false, true, false>)
+                                                 : (a.accumulate_grads ? sh_bwd_kernel<true, false, false> : sh_bwd_kernel<false, false, false>);
       hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
       HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);
     }
