@@ -24,6 +24,10 @@ def test_permuting_the_gaussians_permutes_the_result(gpu):
     partials are summed in the same (tile) order, and nothing in the backward is an atomic."""
     P, W, H = 200_000, 1280, 720
     cam, scene, gc, gd = _case(P, W, H, 3)
+    # distinct depths (random float32 depths collide: ~0.7 % of 200 k draws from [2, 20])
+    z = torch.linspace(2.0, 20.0, P)[torch.from_numpy(np.random.default_rng(1).permutation(P))]
+    scene.means3D[:, :2] *= (z / scene.means3D[:, 2])[:, None]        # keep the screen position
+    scene.means3D[:, 2] = z
     assert np.unique(scene.means3D[:, 2].numpy()).size == P, "the case needs distinct depths"
     bg = torch.tensor([0.1, 0.0, 0.2])
     perm = torch.from_numpy(np.random.default_rng(0).permutation(P))
