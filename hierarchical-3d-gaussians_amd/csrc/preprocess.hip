@@ -375,8 +375,16 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
       const double kLog2e = 1.4426950408889634;
       const float A2 = (float)(-0.5 * kLog2e * pd.conA);
-      const float B2 = (float)(-kLog2e * pd.conB);
+      float B2 = (float)(-kLog2e * pd.conB);
       const float C2 = (float)(-0.5 * kLog2e * pd.conC);
+      // The compositing kernels clamp the exponent at 0 instead of testing its sign ("power > 0 -> skip" never fires
+      // for a positive definite conic).  Rounding the three coefficients to float32 must therefore not make an extremely
+      // elongated conic indefinite (relative determinant below ~1e-7: sigma of thousands of pixels): if it does, the
+      // mixed term is pulled back inside by one part in a million.
+      {
+        const double lim = 4.0 * (double)A2 * (double)C2;
+        if (!((double)B2 * (double)B2 < lim)) B2 = (float)copysign(sqrt(fmax(lim, 0.0)) * (1.0 - 1.0e-6), (double)B2);
+      }
       const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
                                 ((uint32_t)(pr.maxx - pr.minx) << 20);
       float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;

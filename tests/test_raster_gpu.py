@@ -398,6 +398,36 @@ def test_awkward_inputs(gpu):
     assert float(hip["grads"]["opacities"][12:18].abs().max()) == 0.0
 
 
+def test_extremely_elongated_gaussians_stay_well_behaved(gpu):
+    """Needles thousands of pixels long and half a pixel wide: their conic is positive definite only by a relative
+    1e-6 .. 1e-8 of its entries, less than float32 resolves.  The kernels clamp the exponent at 0 instead of testing its
+    sign, so K1 must keep the ROUNDED conic positive definite -- otherwise pixels far off the needle's axis would be
+    blended at full opacity.  Checked against the float64 oracle with a tolerance that allows for the conditioning."""
+    import math
+    W, H = 160, 112
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(60, cam, seed=8)
+    g = torch.Generator().manual_seed(4)
+    fx = W / (2 * cam.tanfovx)
+    z = scene.means3D[:, 2]
+    long_px = torch.exp(math.log(100.0) + (math.log(30000.0) - math.log(100.0)) * torch.rand(60, generator=g))
+    scene.scales[:, 0] = long_px * z / fx
+    scene.scales[:, 1:] = (0.3 * z / fx)[:, None]
+    ang = math.pi * torch.rand(60, generator=g)                        # rotation about the view axis
+    scene.rotations = torch.stack([torch.cos(ang / 2), torch.zeros(60), torch.zeros(60), torch.sin(ang / 2)], 1)
+    scene.opacities[:] = 0.5
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.zeros(3)
+    oo, _ = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    assert torch.isfinite(hip["color"]).all() and all(torch.isfinite(t).all() for t in hip["grads"].values())
+    diff = (hip["color"].double() - oo.color.detach()).abs().amax(0)
+    assert float((diff > 2e-3).float().mean()) < 2e-3, float((diff > 2e-3).float().mean())
+    # off-axis pixels must stay dark: nothing is blended where the oracle sees (almost) nothing
+    dark = oo.color.detach().amax(0) < 1e-3
+    assert float(hip["color"].amax(0)[dark].max()) < 1e-2
+
+
 def test_backward_scratch_prezero_and_memset_paths_agree(gpu):
     """The instance-gradient scratch is cleared either by the forward's compositing kernel
     (hgs_raster_args.bwd_ws_prezero, what the autograd op uses) or by a memset in the backward (a caller that did
