@@ -53,6 +53,28 @@ __device__ __forceinline__ float row_sum16(float v) {
   v += dpp_mov<0x140>(v);   // row_mirror
   return v;
 }
+// Three registers of 16-lane partial sums (every row of 16 lanes = one value) -> ONE register in which every quad of
+// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 and 12-15 = c's.  The row is halved with
+// bank-masked DPP adds that write their result next to each other instead of into separate registers: 7 DPP adds for
+// the three values where three full row reductions take 12.  (s_nop: a DPP operand must not be read within two
+// instructions of the vector instruction that wrote it; the compiler does not see into the asm block.)
+__device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
+  float ab, abc, c1;
+  asm("s_nop 1\n\t"
+      "v_add_f32_dpp %2, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"        // c1: lanes i, 15-i = c[i] + c[15-i]
+      "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"        // lanes 0-7 : a[i] + a[15-i]
+      "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"        // lanes 8-15: b[i] + b[15-i]
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %1, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   // lanes 4-7, 12-15: c, four partials
+      "v_add_f32_dpp %1, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // lanes 0-3: a, lanes 8-11: b
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(ab), "=&v"(abc), "=&v"(c1)
+      : "v"(a), "v"(b), "v"(c));
+  return abc;
+}
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct TileGeom {
@@ -250,7 +272,7 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
 
 // ---- packed backward ------------------------------------------------------------------
 struct BwdPair {
-  f2 fly, T, A, la, lq, bgd, g0, g1, g2, gd;
+  f2 fly, T, A, bgd, g0, g1, g2, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
   uint32_t nc0, nc1;
 };
 struct BwdSums {
@@ -273,10 +295,10 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
   const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
-  const f2 An = fma2(p.la, p.lq - p.A, p.A);                    // value blended behind it, per unit T
   f2 q = fma2(p.g2, splat(q2.x), fma2(p.g1, splat(q1.w), p.g0 * q1.z));
   if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
-  const f2 dfull = fma2(q - An, Tcur, -(p.bgd * rinv));
+  const f2 qA = q - p.A;
+  const f2 dfull = fma2(qA, Tcur, -(p.bgd * rinv));
   const f2 dLda = {live0 ? dfull.x : 0.0f, live1 ? dfull.y : 0.0f};
   const f2 w = ae * Tcur;
   const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
@@ -292,9 +314,7 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   S.s8 = fma2(w, p.g2, S.s8);
   if (DEPTH) S.s9 = fma2(w, p.gd, S.s9);
   p.T = Tcur;
-  p.A = An;
-  p.la = ae;
-  p.lq = q;
+  p.A = fma2(ae, qA, p.A);                                      // A_(i-1) = alpha_i q_i + (1 - alpha_i) A_i
   return 1;
 }
 
@@ -360,15 +380,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   P0.g1 = f2{g1[0], g1[1]};    P1.g1 = f2{g1[2], g1[3]};
   P0.g2 = f2{g2[0], g2[1]};    P1.g2 = f2{g2[2], g2[3]};
   P0.gd = f2{gd[0], gd[1]};    P1.gd = f2{gd[2], gd[3]};
-  P0.A = P0.la = P0.lq = P1.A = P1.la = P1.lq = splat(0.0f);
+  P0.A = P1.A = splat(0.0f);
   P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
   const uint32_t r0 = ranges[tg.tile * 2 + 0];
-  // value index held by this lane's row after the swap reduction (see below): row r -> {0,2,1,3}[r]; the third
-  // register holds s8 / s9 in rows 1 / 3 (rows 0 / 2 carry partial sums that go to the record's two pad floats)
-  const int row = lane >> 4;
+  // which float of the 12-float instance record this lane stores after the reduction (-1: none).  Rows carry the
+  // values {0,2,1,3}[row] of each group of four (permlane swap order); within a row, quad 0 holds s0..s3's, quad 2
+  // s4..s7's, quad 1 s8 (row 1) / s9 (row 3) -- see row_sum16_x3
+  const int row = lane >> 4, quad = (lane >> 2) & 3;
   const int slot = ((row & 1) << 1) | (row >> 1);
-  const int slot2 = (((row & 1) ^ 1) << 1) | (row >> 1);
-
+  int store_k = -1;
+  if ((lane & 3) == 0) {
+    if (quad == 0) store_k = slot;
+    else if (quad == 2) store_k = 4 + slot;
+    else if (quad == 1 && (row & 1)) store_k = 8 + (row >> 1);
+  }
   for (int bstart = (int)((maxnc - 1) / BATCH) * BATCH; bstart >= 0; bstart -= BATCH) {
     const int n = min(BATCH, (int)maxnc - bstart);
     __syncthreads();
@@ -442,19 +467,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         const float u2 = swap32_add(S.s4.x + S.s4.y, S.s5.x + S.s5.y);
         const float u3 = swap32_add(S.s6.x + S.s6.y, S.s7.x + S.s7.y);
         const float u4 = swap32_add(S.s8.x + S.s8.y, DEPTH ? (S.s9.x + S.s9.y) : 0.0f);
-        const float v0 = row_sum16(swap16_add(u0, u1));
-        const float v1 = row_sum16(swap16_add(u2, u3));
-        float v2 = row_sum16(u4);
-        v2 += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v2), 0x142, 0xA, 0xF, false));   // row_bcast:15 into rows 1, 3
-        if ((lane & 15) == 0) {
+        float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
+        // s8 / s9 occupy two rows each (0,1 / 2,3): lane 15 of rows 0 / 2 (a copy of c's row total) is added into the
+        // c quad of rows 1 / 3
+        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0x2, false));   // row_bcast:15
+        if (store_k >= 0) {
           const uint32_t off = __float_as_uint(q2.z);
           const uint32_t rb = __float_as_uint(q2.w);
           const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
           const uint32_t e = off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
-          float* dst = inst + (size_t)e * kInstStride + slot;
-          dst[0] = v0;
-          dst[4] = v1;
-          dst[8 + slot2 - slot] = v2;
+          inst[(size_t)e * kInstStride + store_k] = v;     // ONE store: ten lanes, 40 of the record's 48 bytes
         }
       }
     }
