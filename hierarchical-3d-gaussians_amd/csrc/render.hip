@@ -54,9 +54,10 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 // Three registers of 16-lane partial sums (every row of 16 lanes = one value) -> ONE register in which every quad of
-// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 and 12-15 = c's.  The row is halved with
-// bank-masked DPP adds that write their result next to each other instead of into separate registers: 7 DPP adds for
-// the three values where three full row reductions take 12.  (s_nop: a DPP operand must not be read within two
+// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 = c's summed over the row PAIR (0,1) resp.
+// (2,3) in rows 1 and 3.  The row is halved with
+// bank-masked DPP adds that write their result next to each other instead of into separate registers: 8 DPP adds for
+// the three values where three full row reductions and the row-pair add take 13.  (s_nop: a DPP operand must not be read within two
 // instructions of the vector instruction that wrote it; the compiler does not see into the asm block.)
 __device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
   float ab, abc, c1;
@@ -70,7 +71,11 @@ __device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
       "s_nop 1\n\t"
       "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
       "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      // c's values (s8 / s9) occupy two rows each (0,1 / 2,3): lane 15 of rows 0 / 2 (a copy of c's row total) is
+      // added into the c quad (lanes 4-7) of rows 1 / 3
+      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0x2"
       : "=&v"(ab), "=&v"(abc), "=&v"(c1)
       : "v"(a), "v"(b), "v"(c));
   return abc;
@@ -318,6 +323,13 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   return 1;
 }
 
+// x + y of a float2 as ONE plain v_add_f32 (the compiler picks a packed add with swizzled operands for this, which
+// costs 1.6x as much -- scripts/microbench/valu_issue.hip)
+__device__ __forceinline__ float fold(f2 v) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
+  return r;
+}
 __device__ __forceinline__ float swap32_add(float a, float b) {   // [a.lo+a.hi | b.lo+b.hi]
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -462,15 +474,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         // v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7).  s8 / s9 occupy one half-wave each after the first
         // halving: their two rows are reduced separately and joined by ONE row_bcast:15 add (a permlane16 swap with
         // zero + add costs three times as much): v2 rows = (s8 partial, s8, s9 partial, s9).
-        const float u0 = swap32_add(S.s0.x + S.s0.y, S.s1.x + S.s1.y);
-        const float u1 = swap32_add(S.s2.x + S.s2.y, S.s3.x + S.s3.y);
-        const float u2 = swap32_add(S.s4.x + S.s4.y, S.s5.x + S.s5.y);
-        const float u3 = swap32_add(S.s6.x + S.s6.y, S.s7.x + S.s7.y);
-        const float u4 = swap32_add(S.s8.x + S.s8.y, DEPTH ? (S.s9.x + S.s9.y) : 0.0f);
-        float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
-        // s8 / s9 occupy two rows each (0,1 / 2,3): lane 15 of rows 0 / 2 (a copy of c's row total) is added into the
-        // c quad of rows 1 / 3
-        v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0x2, false));   // row_bcast:15
+        const float u0 = swap32_add(fold(S.s0), fold(S.s1));
+        const float u1 = swap32_add(fold(S.s2), fold(S.s3));
+        const float u2 = swap32_add(fold(S.s4), fold(S.s5));
+        const float u3 = swap32_add(fold(S.s6), fold(S.s7));
+        const float u4 = swap32_add(fold(S.s8), DEPTH ? fold(S.s9) : 0.0f);
+        const float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
         if (store_k >= 0) {
           const uint32_t off = __float_as_uint(q2.z);
           const uint32_t rb = __float_as_uint(q2.w);
