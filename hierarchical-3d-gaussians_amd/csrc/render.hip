@@ -140,8 +140,12 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   const bool live0 = alpha.x >= kAlphaMin;
   const bool live1 = alpha.y >= kAlphaMin;
   const f2 Tn = p.T * (1.0f - alpha);
-  const bool stop0 = live0 && (Tn.x < kTEps), stop1 = live1 && (Tn.y < kTEps);
-  const bool blend0 = live0 && !stop0, blend1 = live1 && !stop1;
+  // ONE compare per strip for the saturation test: "blend" and "stop" are both derived from its wave mask in scalar
+  // registers (written with booleans the compiler emits a second, complementary compare per strip)
+  const uint64_t l0 = __ballot(live0), l1 = __ballot(live1);
+  const uint64_t g0 = __ballot(!(Tn.x < kTEps)), g1 = __ballot(!(Tn.y < kTEps));
+  const bool blend0 = __builtin_amdgcn_inverse_ballot_w64(l0 & g0), blend1 = __builtin_amdgcn_inverse_ballot_w64(l1 & g1);
+  const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(l0 & ~g0), stop1 = __builtin_amdgcn_inverse_ballot_w64(l1 & ~g1);
   const f2 ae = {blend0 ? alpha.x : 0.0f, blend1 ? alpha.y : 0.0f};
   const f2 w = ae * p.T;
   p.Cr = fma2(w, splat(q1.z), p.Cr);
