@@ -80,7 +80,6 @@ __device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
       : "v"(a), "v"(b), "v"(c));
   return abc;
 }
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
 struct TileGeom {
   int tile, tx, ty;
@@ -114,12 +113,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 
-// min(x, 0) as exactly one v_min_f32 (fminf adds a canonicalising v_max x, x in front of it)
-__device__ __forceinline__ float min_zero(float x) {
-  float r;
-  asm("v_min_f32 %0, 0, %1" : "=v"(r) : "v"(x));
-  return r;
-}
+// exp2(min(x, 0)) = min(exp2(x), 1) as ONE instruction: the [0, 1] output clamp of v_exp_f32 (the compiler folds the
+// median into the instruction's clamp bit).  Also turns +inf / NaN inputs into 1 / 0.
+__device__ __forceinline__ float exp2_le1(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
 template <bool DEPTH>
 struct FwdPair {
@@ -130,10 +126,11 @@ struct FwdPair {
 template <bool DEPTH>
 __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const float4& q1,
                                               const float4& q2, uint32_t idx1) {
-  // min(pw, 0): the conic is positive definite (0.3 px^2 was added to the covariance's diagonal), so the exponent is
-  // <= 0 up to rounding; clamping replaces the reference lineage's "power > 0 -> skip" test, which in exact arithmetic
-  // never fires, by the value the exact exponent would give (and costs no compare)
-  const f2 G = {fast_exp2(min_zero(pw.x)), fast_exp2(min_zero(pw.y))};
+  // exp2(min(pw, 0)): the conic is positive definite (0.3 px^2 was added to the covariance's diagonal, K1 keeps the
+  // rounded conic positive definite), so the exponent is <= 0 up to rounding; clamping replaces the reference lineage's
+  // "power > 0 -> skip" test, which in exact arithmetic never fires, by the value the exact exponent would give, and
+  // costs nothing (output clamp of the exp instruction)
+  const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band)
@@ -146,13 +143,15 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   const uint64_t g0 = __ballot(!(Tn.x < kTEps)), g1 = __ballot(!(Tn.y < kTEps));
   const bool blend0 = __builtin_amdgcn_inverse_ballot_w64(l0 & g0), blend1 = __builtin_amdgcn_inverse_ballot_w64(l1 & g1);
   const bool stop0 = __builtin_amdgcn_inverse_ballot_w64(l0 & ~g0), stop1 = __builtin_amdgcn_inverse_ballot_w64(l1 & ~g1);
-  const f2 ae = {blend0 ? alpha.x : 0.0f, blend1 ? alpha.y : 0.0f};
-  const f2 w = ae * p.T;
+  // non-blending lanes: weight 0 (the identity of the colour recurrences), T kept -- as selects (two plain
+  // instructions per quantity; zeroing alpha and redoing the packed products costs more)
+  const f2 aT = alpha * p.T;
+  const f2 w = {blend0 ? aT.x : 0.0f, blend1 ? aT.y : 0.0f};
   p.Cr = fma2(w, splat(q1.z), p.Cr);
   p.Cg = fma2(w, splat(q1.w), p.Cg);
   p.Cb = fma2(w, splat(q2.x), p.Cb);
   if (DEPTH) p.Dd = fma2(w, splat(q2.y), p.Dd);
-  p.T = p.T * (1.0f - ae);
+  p.T = f2{blend0 ? Tn.x : p.T.x, blend1 ? Tn.y : p.T.y};
   p.last0 = blend0 ? idx1 : p.last0;
   p.last1 = blend1 ? idx1 : p.last1;
   p.fly.x = stop0 ? kBig : p.fly.x;      // a saturated pixel leaves the tile (see above); whether the WHOLE tile
@@ -291,9 +290,9 @@ struct BwdSums {
 template <bool DEPTH>
 __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
                                                   const float4& q1, const float4& q2) {
-  // min(pw, 0): as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also keeps G
-  // finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
-  const f2 G = {fast_exp2(min_zero(pw.x)), fast_exp2(min_zero(pw.y))};
+  // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
+  // keeps G finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
+  const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const bool live0 = c0 && (alpha.x >= kAlphaMin);   // = blended by the forward
