@@ -287,9 +287,10 @@ struct BwdSums {
   f2 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
 };
 
-template <bool DEPTH>
-__device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
-                                                  const float4& q1, const float4& q2) {
+// FIRST: the sums are assigned, not accumulated (the first visited half of an instance: no zero-filled accumulators)
+template <bool DEPTH, bool FIRST>
+__device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
+                                              const float4& q1, const float4& q2) {
   // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
   // keeps G finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
@@ -311,19 +312,31 @@ __device__ __forceinline__ uint64_t bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw,
   const f2 w = ae * Tcur;
   const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
   const f2 Xdx = X * dx, Xdy = X * dy;
-  S.s0 += Xdx;
-  S.s1 += Xdy;
-  S.s2 = fma2(Xdx, splat(dx), S.s2);
-  S.s3 = fma2(Xdx, dy, S.s3);
-  S.s4 = fma2(Xdy, dy, S.s4);
-  S.s5 = fma2(G, dLda, S.s5);
-  S.s6 = fma2(w, p.g0, S.s6);
-  S.s7 = fma2(w, p.g1, S.s7);
-  S.s8 = fma2(w, p.g2, S.s8);
-  if (DEPTH) S.s9 = fma2(w, p.gd, S.s9);
+  if (FIRST) {
+    S.s0 = Xdx;
+    S.s1 = Xdy;
+    S.s2 = Xdx * dx;
+    S.s3 = Xdx * dy;
+    S.s4 = Xdy * dy;
+    S.s5 = G * dLda;
+    S.s6 = w * p.g0;
+    S.s7 = w * p.g1;
+    S.s8 = w * p.g2;
+    if (DEPTH) S.s9 = w * p.gd;
+  } else {
+    S.s0 += Xdx;
+    S.s1 += Xdy;
+    S.s2 = fma2(Xdx, splat(dx), S.s2);
+    S.s3 = fma2(Xdx, dy, S.s3);
+    S.s4 = fma2(Xdy, dy, S.s4);
+    S.s5 = fma2(G, dLda, S.s5);
+    S.s6 = fma2(w, p.g0, S.s6);
+    S.s7 = fma2(w, p.g1, S.s7);
+    S.s8 = fma2(w, p.g2, S.s8);
+    if (DEPTH) S.s9 = fma2(w, p.gd, S.s9);
+  }
   p.T = Tcur;
   p.A = fma2(ae, qA, p.A);                                      // A_(i-1) = alpha_i q_i + (1 - alpha_i) A_i
-  return 1;
 }
 
 // x + y of a float2 as ONE plain v_add_f32 (the compiler picks a packed add with swizzled operands for this, which
@@ -448,7 +461,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       // per flagged half: exponents, per-strip candidate predicates (log-domain alpha test AND "the forward blended
       // this Gaussian into the pixel", i.e. rel < n_contrib) and the wave-uniform "half has a candidate" from the
       // ballots of the plain compares combined in scalar registers
-      f2 dy0 = splat(0.0f), dy1 = splat(0.0f), pw0 = splat(0.0f), pw1 = splat(0.0f);
+      // (read only under b0 / b1, i.e. only when assigned: left uninitialised on purpose -- a zero initialiser costs
+      // four vector moves per instance on the path of a half that is not visited)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
+#pragma clang diagnostic ignored "-Wconditional-uninitialized"
+      f2 dy0, dy1, pw0, pw1;
       bool c0 = false, c1 = false, c2 = false, c3 = false, b0 = false, b1 = false;
       if ((m0 >> j) & 1) {
         dy0 = gyt - P0.fly;
@@ -467,11 +485,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       if (!(b0 || b1)) continue;
       const float4 q2 = lrec[j * kRecVec + 2];
       BwdSums S;
-      S.s0 = S.s1 = S.s2 = S.s3 = S.s4 = S.s5 = S.s6 = S.s7 = S.s8 = S.s9 = splat(0.0f);
-      uint64_t any_blend = 0;
-      if (b0) any_blend |= bwd_pair_live<DEPTH>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
-      if (b1) any_blend |= bwd_pair_live<DEPTH>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
-      if (any_blend != 0) {   // wave-uniform
+      if (!DEPTH) S.s9 = splat(0.0f);
+      if (b0) {
+        bwd_pair_live<DEPTH, true>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
+        if (b1) bwd_pair_live<DEPTH, false>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
+      } else {
+        bwd_pair_live<DEPTH, true>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
+      }
+      {
         // 10 sums x 64 lanes -> 12 slots: fold the two strips of each pair, then halve the lane count twice with
         // permlane32/16 swaps (two values share a register afterwards), then DPP row reductions.
         // v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7).  s8 / s9 occupy one half-wave each after the first
