@@ -28,9 +28,9 @@
 //    (every term relatively accurate; a front-to-back variant using V - prefix was measured 10-80x
 //    less accurate on pixels with capped alphas and was dropped).
 //  * the 10 per-(tile,Gaussian) partial sums are reduced over the 4 strips in registers, over the
-//    wave with permlane swaps + DPP row reductions, and four lanes store the 48-byte instance record to
-//    its EMISSION slot; K8 sums each Gaussian's contiguous run.  No LDS accumulator, no atomics
-//    of any kind, bit-reproducible.
+//    wave with permlane swaps + bank-masked DPP adds (three registers of row partials share one reduction), and ten
+//    lanes store the instance record to its EMISSION slot with one instruction; K8 sums each Gaussian's
+//    contiguous run.  No LDS accumulator, no atomics of any kind, bit-reproducible.
 #include "common.h"
 
 namespace hgs {
@@ -54,11 +54,11 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 // Three registers of 16-lane partial sums (every row of 16 lanes = one value) -> ONE register in which every quad of
-// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 = c's summed over the row PAIR (0,1) resp.
-// (2,3) in rows 1 and 3.  The row is halved with
-// bank-masked DPP adds that write their result next to each other instead of into separate registers: 8 DPP adds for
-// the three values where three full row reductions and the row-pair add take 13.  (s_nop: a DPP operand must not be read within two
-// instructions of the vector instruction that wrote it; the compiler does not see into the asm block.)
+// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 of rows 1 / 3 = c's summed over the row
+// PAIR (0,1) / (2,3).  The row is halved with bank-masked DPP adds that write their results next to each other
+// instead of into separate registers: 8 DPP adds where three full row reductions and the row-pair add take 13.
+// (s_nop: a DPP operand must not be read within two instructions of the vector instruction that wrote it, and the
+// compiler does not see into the asm block.)
 __device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
   float ab, abc, c1;
   asm("s_nop 1\n\t"
@@ -493,11 +493,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         bwd_pair_live<DEPTH, true>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
       }
       {
-        // 10 sums x 64 lanes -> 12 slots: fold the two strips of each pair, then halve the lane count twice with
-        // permlane32/16 swaps (two values share a register afterwards), then DPP row reductions.
-        // v0 rows = (s0,s2,s1,s3), v1 rows = (s4,s6,s5,s7).  s8 / s9 occupy one half-wave each after the first
-        // halving: their two rows are reduced separately and joined by ONE row_bcast:15 add (a permlane16 swap with
-        // zero + add costs three times as much): v2 rows = (s8 partial, s8, s9 partial, s9).
+        // 10 sums x 64 lanes -> 10 floats of the instance record: fold the two strips of each pair, halve the lane
+        // count twice with permlane32 / permlane16 swaps (two values share a register afterwards: rows of the two
+        // registers = (s0,s2,s1,s3) and (s4,s6,s5,s7); s8 / s9 keep two rows each), then ONE packed row reduction of the
+        // three registers (row_sum16_x3) that also joins the row pairs of s8 / s9.
         const float u0 = swap32_add(fold(S.s0), fold(S.s1));
         const float u1 = swap32_add(fold(S.s2), fold(S.s3));
         const float u2 = swap32_add(fold(S.s4), fold(S.s5));
