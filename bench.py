@@ -443,6 +443,10 @@ def main():
                 result["roofline"]["valu"] = {
                     "insts_per_launch": pv["valu_insts_per_launch"], "achieved_ginst_s": rate / 1e9,
                     "peak_ginst_s": peak / 1e9, "frac": rate / peak,
+                    # SQ_ACTIVE_INST_VALU (quad-cycles the vector ALU was executing, per wave) x waves over the
+                    # SIMD-cycles the launch lasted at the nominal 2.4 GHz: how busy the vector ALUs were
+                    "alu_busy_frac": (pv["valu_active_quadcycles_per_wave"] * 4.0 * pv["waves"] / 1024.0) / (sec * 2.4e9)
+                    if "valu_active_quadcycles_per_wave" in pv else None,
                     "source": f"{valu_path} (run id {valu_db.get('_run', 'unknown')}): SQ_INSTS_VALU per launch from a "
                               "committed rocprofv3 --pmc pass of this command (NOT measured in this run); time from this "
                               "run; peak_ginst_s = " + str(valu_db.get("_peak_source", "256 CUs x 4 SIMDs x 2.4 GHz / 4 "
