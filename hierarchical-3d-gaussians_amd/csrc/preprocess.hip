@@ -92,6 +92,32 @@ __device__ __forceinline__ void coop_load_sh(const float* __restrict__ shs, int 
   }
 }
 
+// The same block load split in two: ISSUE the workgroup's coalesced 16-byte loads into registers (up to 12 per lane),
+// COMMIT them to the padded LDS rows later -- whatever the kernel computes in between runs under the loads' latency.
+__device__ __forceinline__ void coop_issue_sh(const float* __restrict__ shs, int block_first, int P, int n,
+                                              float4 (&reg)[12]) {
+  const int vecs = min(kPreBlock, P - block_first) * n / 4;
+  const float4* src = reinterpret_cast<const float4*>(shs + (size_t)block_first * n);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int v = (int)threadIdx.x + k * kPreBlock;
+    reg[k] = v < vecs ? src[v] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void coop_commit_sh(const float4 (&reg)[12], int block_first, int P, int n, float* lds) {
+  const int vecs = min(kPreBlock, P - block_first) * n / 4;
+  const int stride = sh_row_stride(n);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int v = (int)threadIdx.x + k * kPreBlock;
+    if (v < vecs) {
+      const int e = v * 4;
+      const int gsn = n == 48 ? e / 48 : e / n, off = e - gsn * n;
+      *reinterpret_cast<float4*>(lds + gsn * stride + off) = reg[k];
+    }
+  }
+}
+
 template <bool ACC>
 __device__ __forceinline__ void coop_store_sh(float* __restrict__ dst_all, int block_first, int P, int n,
                                               const float* lds) {
@@ -238,9 +264,10 @@ __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, f
     if (i < n) sh[i] = lod_lerp(x[i], y[i], l.w, l.u);
 }
 
-template <bool JAC, bool LOD>   // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD interpolation
-                                // (their own instantiations: the extra state would cost every other caller of K1 its
-                                // occupancy)
+template <bool JAC, bool LOD, bool DEFER>   // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
+                                // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
+                                // ahead of the double-precision chain (their own instantiations: the extra state
+                                // would cost every other caller of K1 its occupancy)
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    int32_t* __restrict__ radii) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -280,7 +307,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   }
   // SH coefficients: stream the workgroup's block through LDS when most of it is visible (coalesced),
   // fall back to per-lane loads (visible lanes only) when most of the block is culled.
-  bool coop = false;
+  // Plain layout: the block's loads are ISSUED here, into registers, and committed to LDS only after the
+  // double-precision chain below -- K1 holds 3 waves per SIMD (LDS), too few to hide the latency of a load that is
+  // waited for on the spot (0.114 -> see DESIGN.md).
+  bool coop = false, deferred = false;
+  float4 shreg[DEFER ? 12 : 1];
   if (a.shs && (shn & 3) == 0) {
     coop = __syncthreads_count(pr.visible) * 2 >= kPreBlock;
     if (coop) {
@@ -289,19 +320,80 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       } else if (a.shs_rest) {
         coop_load_seg(a.shs, blockIdx.x * kPreBlock, a.P, 3, 0, sh_row_stride(shn), lds_sh);
         coop_load_seg(a.shs_rest, blockIdx.x * kPreBlock, a.P, shn - 3, 3, sh_row_stride(shn), lds_sh);
+      } else if constexpr (DEFER) {
+        coop_issue_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, shreg);
+        deferred = true;
       } else {
         coop_load_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
       }
-      __syncthreads();
     }
   }
+  // ---- everything that does not need the coefficients: the double-precision chain, the record's geometry ----------
+  int32_t rad = 0;
+  uint32_t flags = 0;
+  float opac = 0.f, thr = 0.f, ext_x = -1.0f, ext_y = -1.0f, invz = 0.f;
+  float gx_hi = 0.f, gy_hi = 0.f, gx_lo = 0.f, gy_lo = 0.f, A2 = 0.f, B2 = 0.f, C2 = 0.f;
+  if (idx < a.P && pr.visible) {
+    touched = (uint32_t)((pr.maxx - pr.minx) * (pr.maxy - pr.miny));
+    rad = (int32_t)pr.rad_f;
+    if (pr.clampx) flags |= 8u;
+    if (pr.clampy) flags |= 16u;
+    opac = load_opacity<LOD>(a, idx, nullptr);
+    if (a.interpolation_weights && a.num_node_kids)
+      opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
+    // continuous quantities from the double-precision chain (see gaussian_math.h)
+    ProjD pd;
+    if (a.cov3D_precomp) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
+    } else {
+      cov3d_from_scale_rot_d(sc_act, a.scale_modifier, q_act, pd);
+    }
+    project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
+    // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
+    gx_hi = (float)pd.px; gy_hi = (float)pd.py;
+    gx_lo = (float)(pd.px - (double)gx_hi); gy_lo = (float)(pd.py - (double)gy_hi);
+    // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
+    const double kLog2e = 1.4426950408889634;
+    A2 = (float)(-0.5 * kLog2e * pd.conA);
+    B2 = (float)(-kLog2e * pd.conB);
+    C2 = (float)(-0.5 * kLog2e * pd.conC);
+    // The compositing kernels clamp the exponent at 0 instead of testing its sign ("power > 0 -> skip" never fires
+    // for a positive definite conic).  Rounding the three coefficients to float32 must therefore not make an extremely
+    // elongated conic indefinite (relative determinant below ~1e-7: sigma of thousands of pixels): if it does, the
+    // mixed term is pulled back inside by one part in a million.
+    {
+      const double lim = 4.0 * (double)A2 * (double)C2;
+      if (!((double)B2 * (double)B2 < lim)) B2 = (float)copysign(sqrt(fmax(lim, 0.0)) * (1.0 - 1.0e-6), (double)B2);
+    }
+    // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
+    // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
+    // never a candidate, exactly like the exact test)
+    thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
+    // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
+    //   A dx^2 + 2 B dx dy + C dy^2 <= 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T C / det), |dy| <= sqrt(T A / det).
+    // The compositing kernels use them to decide, once per (tile, Gaussian) and in scalar registers, which half of
+    // the tile can be touched at all; they are inflated (same 1e-3 guard in the exponent, 1e-4 relative, 5e-3 px)
+    // so that the box contains every pixel the exact alpha test could accept.  -1: no pixel ever (o <= ~1/255).
+    {
+      const double T2 = 2.0 * (log(255.0 * (double)opac) + 1.0e-3 * 0.6931471805599453);
+      const double det = pd.conA * pd.conC - pd.conB * pd.conB;
+      if (T2 > 0.0 && det > 0.0) {
+        ext_x = (float)(sqrt(T2 * pd.conC / det) * 1.0001 + 5.0e-3);
+        ext_y = (float)(sqrt(T2 * pd.conA / det) * 1.0001 + 5.0e-3);
+      } else if (T2 > 0.0) {
+        ext_x = ext_y = 1.0e9f;       // degenerate conic: never skip on the box
+      }
+    }
+    invz = (float)(1.0 / pd.tz);
+  }
+  if constexpr (DEFER) {
+    if (deferred) coop_commit_sh(shreg, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
+  }
+  if (coop) __syncthreads();
+  // ---- colour, then the record -------------------------------------------------------------------------------------
   if (idx < a.P) {
-    int32_t rad = 0;
-    uint32_t flags = 0;
     if (pr.visible) {
-      touched = (uint32_t)((pr.maxx - pr.minx) * (pr.maxy - pr.miny));
-      rad = (int32_t)pr.rad_f;
-      // colour
       float rgb[3];
       if (a.colors_precomp) {
         rgb[0] = a.colors_precomp[idx * 3 + 0];
@@ -355,62 +447,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
         if (r2 < 0.f) { r2 = 0.f; flags |= 4u; }
         rgb[0] = r0; rgb[1] = r1; rgb[2] = r2;
       }
-      if (pr.clampx) flags |= 8u;
-      if (pr.clampy) flags |= 16u;
-      float opac = load_opacity<LOD>(a, idx, nullptr);
-      if (a.interpolation_weights && a.num_node_kids)
-        opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
-      // continuous quantities from the double-precision chain (see gaussian_math.h)
-      ProjD pd;
-      if (a.cov3D_precomp) {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
-      } else {
-        cov3d_from_scale_rot_d(sc_act, a.scale_modifier, q_act, pd);
-      }
-      project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
-      // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
-      const float gx_hi = (float)pd.px, gy_hi = (float)pd.py;
-      const float gx_lo = (float)(pd.px - (double)gx_hi), gy_lo = (float)(pd.py - (double)gy_hi);
-      // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
-      const double kLog2e = 1.4426950408889634;
-      const float A2 = (float)(-0.5 * kLog2e * pd.conA);
-      float B2 = (float)(-kLog2e * pd.conB);
-      const float C2 = (float)(-0.5 * kLog2e * pd.conC);
-      // The compositing kernels clamp the exponent at 0 instead of testing its sign ("power > 0 -> skip" never fires
-      // for a positive definite conic).  Rounding the three coefficients to float32 must therefore not make an extremely
-      // elongated conic indefinite (relative determinant below ~1e-7: sigma of thousands of pixels): if it does, the
-      // mixed term is pulled back inside by one part in a million.
-      {
-        const double lim = 4.0 * (double)A2 * (double)C2;
-        if (!((double)B2 * (double)B2 < lim)) B2 = (float)copysign(sqrt(fmax(lim, 0.0)) * (1.0 - 1.0e-6), (double)B2);
-      }
       const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
                                 ((uint32_t)(pr.maxx - pr.minx) << 20);
       float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
       rec[0] = make_float4(gx_hi, gy_hi, A2, B2);
       rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
-      // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
-      // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
-      // never a candidate, exactly like the exact test)
-      const float thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
-      // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
-      //   A dx^2 + 2 B dx dy + C dy^2 <= 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T C / det), |dy| <= sqrt(T A / det).
-      // The compositing kernels use them to decide, once per (tile, Gaussian) and in scalar registers, which half of
-      // the tile can be touched at all; they are inflated (same 1e-3 guard in the exponent, 1e-4 relative, 5e-3 px)
-      // so that the box contains every pixel the exact alpha test could accept.  -1: no pixel ever (o <= ~1/255).
-      float ext_x = -1.0f, ext_y = -1.0f;
-      {
-        const double T2 = 2.0 * (log(255.0 * (double)opac) + 1.0e-3 * 0.6931471805599453);
-        const double det = pd.conA * pd.conC - pd.conB * pd.conB;
-        if (T2 > 0.0 && det > 0.0) {
-          ext_x = (float)(sqrt(T2 * pd.conC / det) * 1.0001 + 5.0e-3);
-          ext_y = (float)(sqrt(T2 * pd.conA / det) * 1.0001 + 5.0e-3);
-        } else if (T2 > 0.0) {
-          ext_x = ext_y = 1.0e9f;       // degenerate conic: never skip on the box
-        }
-      }
-      rec[2] = make_float4(rgb[2], (float)(1.0 / pd.tz), ext_x, __uint_as_float(rectbits));
+      rec[2] = make_float4(rgb[2], invz, ext_x, __uint_as_float(rectbits));
       rec[3] = make_float4(gx_lo, gy_lo, thr, ext_y);
     }
     // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
@@ -997,8 +1039,10 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   if (nblk > 0) {
     const size_t lds_bytes = a.shs ? (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float) : 0;
     const bool jac = a.prepare_backward && a.shs;
-    auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true> : preprocess_fwd_kernel<false, true>)
-                                   : (jac ? preprocess_fwd_kernel<true, false> : preprocess_fwd_kernel<false, false>);
+    const bool defer = a.shs && !a.shs_rest && !a.lod_render_indices && ((a.M * 3) & 3) == 0;
+    auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
+              : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
+                      : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
     hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii);
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
   }
