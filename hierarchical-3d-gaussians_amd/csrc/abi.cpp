@@ -193,7 +193,7 @@ int hgs_raster_ws_sizes(int32_t P, int32_t width, int32_t height, uint32_t L, si
   if (geom_bytes) *geom_bytes = GeomWs::bytes(P);
   if (bin_bytes) *bin_bytes = BinWs::bytes(L, T);
   if (img_bytes) *img_bytes = ImgWs::bytes(width, height);
-  if (bwd_bytes) *bwd_bytes = align_up((size_t)(L ? L : 1) * kInstStride * 4) + align_up((size_t)(P > 0 ? P : 1) * 3 * 4) + kAlign;
+  if (bwd_bytes) *bwd_bytes = bwd_ws_bytes(L, P);
   return HGS_OK;
 }
 
@@ -298,6 +298,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   if (rc) return rc;
   if (!geom_ws || !bin_ws || !img_ws || !bwd_ws || !out_color || !dL_dcolor || !grads) { set_error("null workspace/input"); return HGS_ERR_INVALID; }
   if (a->lod_render_indices && !a->prepare_backward) { set_error("the backward of an in-kernel LOD interpolation needs prepare_backward = 1 in the forward and the backward call"); return HGS_ERR_INVALID; }
+  if (a->lod_scatter && (!a->lod_render_indices || ((a->M * 3) & 3) != 0 || a->accumulate_grads || a->defer_sh_bwd)) { set_error("lod_scatter needs in-kernel LOD interpolation, 3M %% 4 == 0, no accumulation and no deferred SH backward"); return HGS_ERR_INVALID; }
   if (a->P > 0) {
     if (!grads->dL_dmeans3D || !grads->dL_dmeans2D || !grads->dL_dopacity) { set_error("missing gradient outputs"); return HGS_ERR_INVALID; }
     if ((a->shs && !grads->dL_dshs) || (a->shs_rest && !grads->dL_dshs_rest) || (a->colors_precomp && !grads->dL_dcolors) ||
@@ -328,7 +329,13 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   if (!a->colors_precomp) gr.dL_dcolors = nullptr;
   if (!a->scales) { gr.dL_dscales = nullptr; gr.dL_drotations = nullptr; }
   if (!a->cov3D_precomp) gr.dL_dcov3D = nullptr;
-  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, gr, s));
+  uint32_t* lod_flag = nullptr;
+  if (a->lod_render_indices && a->lod_scatter) {
+    lod_flag = bwd_ws_lod_flag(bwd_ws, L, a->P);
+    HGS_HIP(hipMemsetAsync(lod_flag, 0, sizeof(uint32_t), s));
+    if ((rc = launch_lod_monotone(a->lod_parent_indices, a->lod_n, lod_flag, s))) return rc;
+  }
+  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, bwd_ws_dmean(bwd_ws, L, a->P), lod_flag, gr, s));
 }
 
 int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,

@@ -107,8 +107,11 @@ int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
 int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
+// dmean_rows / lod_flag: scratch of the in-kernel LOD scatter (hgs_raster_args.lod_scatter): the per-row mean gradient
+// K8a hands to K8b, and the "parent indices are not non-decreasing" word (set by launch_lod_monotone)
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
-                          const hgs_raster_grads& out, hipStream_t s);
+                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, hipStream_t s);
+int launch_lod_monotone(const int32_t* parent_indices, int32_t n, uint32_t* flag, hipStream_t s);
 // Per-view device pointers of the batched SH kernels.  Kept small (24 pointers): they are kernel arguments and must
 // stay in scalar registers across the view loop.
 struct ShBwdViews {
@@ -132,6 +135,16 @@ int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_
 // the per-Gaussian colour gradients sit behind the instance gradients in the backward scratch
 inline float* bwd_ws_drgb(void* bwd_ws, uint32_t L) {
   return reinterpret_cast<float*>(static_cast<char*>(bwd_ws) + align_up((size_t)(L ? L : 1) * kInstStride * 4));
+}
+// behind them: [P,3] mean gradients of the rows and one flag word (in-kernel LOD scatter only)
+inline float* bwd_ws_dmean(void* bwd_ws, uint32_t L, int32_t P) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(bwd_ws_drgb(bwd_ws, L)) + align_up((size_t)(P > 0 ? P : 1) * 3 * 4));
+}
+inline uint32_t* bwd_ws_lod_flag(void* bwd_ws, uint32_t L, int32_t P) {
+  return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(bwd_ws_dmean(bwd_ws, L, P)) + align_up((size_t)(P > 0 ? P : 1) * 3 * 4));
+}
+inline size_t bwd_ws_bytes(uint32_t L, int32_t P) {
+  return align_up((size_t)(L ? L : 1) * kInstStride * 4) + 2 * align_up((size_t)(P > 0 ? P : 1) * 3 * 4) + 2 * kAlign;
 }
 // tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
 bool tile_bin_supported(int32_t T);

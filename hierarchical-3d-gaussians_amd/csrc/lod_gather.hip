@@ -189,6 +189,15 @@ __global__ __launch_bounds__(256) void lod_scatter_sh_kernel(const int32_t* __re
 }
 
 }  // namespace
+
+int launch_lod_monotone(const int32_t* parent_indices, int32_t n, uint32_t* flag, hipStream_t s) {
+  if (n > 1) {
+    hipLaunchKernelGGL(lod_monotone_kernel, dim3((n + 255) / 256), dim3(256), 0, s, parent_indices, n, flag);
+    HGS_LAUNCH_CHECK("lod_monotone", s, false);
+  }
+  return HGS_OK;
+}
+
 }  // namespace hgs
 
 using namespace hgs;

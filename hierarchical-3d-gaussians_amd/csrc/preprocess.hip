@@ -512,14 +512,52 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
 //   5: sum G*dL/dalpha          6..8: sum w*dL/dC_k              9: sum w*dL/dD
 // with X = dL/dpower, w = alpha*T.
 // ---------------------------------------------------------------------------
+// ---- in-kernel LOD scatter (hgs_raster_args.lod_scatter) ----------------------------------------------------------
+// Row i of the op is w_i * attr[r_i] + (1 - w_i) * attr[p_i]; its gradient g_i goes to the node row (w_i g_i: the node
+// rows of a cut are unique -> plain stores) and to the parent row ((1 - w_i) g_i, summed over the siblings).  Siblings
+// are CONSECUTIVE rows when the parent indices are non-decreasing (expand_to_size emits them so): the first lane of a
+// run sums it from LDS in row order and stores once.  Runs cut by a workgroup boundary (at most two per workgroup) and
+// every run of an order that is not non-decreasing (flag word, launch_lod_monotone) use atomic adds instead; two
+// partial sums added to a zero-filled row give the same bits in either order.
+__device__ __forceinline__ int lod_parent_at(const hgs_raster_args& a, int i) {   // parent row of op row i, any i < P
+  return i < a.lod_n ? a.lod_parent_indices[i] : a.lod_rows - (a.P - a.lod_n) + (i - a.lod_n);
+}
+struct LodRun {
+  bool leader;    // first row of its run within this workgroup
+  bool atomic;    // the run continues in a neighbouring workgroup, or the order is not monotone
+  int end;        // one past the run's last row (workgroup-relative)
+};
+__device__ __forceinline__ LodRun lod_run(const hgs_raster_args& a, const int* lds_par, int t, int count, int block_first,
+                                          bool nonmono) {
+  LodRun r;
+  const int p = lds_par[t];
+  r.leader = (t == 0) || lds_par[t - 1] != p;
+  r.end = t + 1;
+  r.atomic = nonmono;
+  if (r.leader) {
+    while (r.end < count && lds_par[r.end] == p) ++r.end;
+    if (t == 0 && block_first > 0 && lod_parent_at(a, block_first - 1) == p) r.atomic = true;
+    if (r.end == count && block_first + count < a.P && lod_parent_at(a, block_first + count) == p) r.atomic = true;
+  }
+  return r;
+}
+__device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
+  if (atomic) atomicAdd(dst, v); else *dst = v;
+}
+
 template <bool ACC, bool LOD>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
 __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
                                                                    float* __restrict__ drgb,
+                                                                   float* __restrict__ dmean_rows,
+                                                                   const uint32_t* __restrict__ lod_flag,
                                                                    hgs_raster_grads out) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
-  if (idx >= a.P) return;
-  const uint32_t n = g.tiles_touched[idx];
+  const bool in_range = idx < a.P;
+  if constexpr (!LOD) {
+    if (!in_range) return;
+  }
+  const uint32_t n = in_range ? g.tiles_touched[idx] : 0u;   // (LOD: out-of-range lanes stay for the scatter's barriers)
 
   float d_mean[3] = {0.f, 0.f, 0.f};
   float d_m2[3] = {0.f, 0.f, 0.f};
@@ -700,6 +738,74 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     }
   }
 
+  if constexpr (LOD) {
+    if (a.lod_scatter) {
+      // scales, rotations, opacity: scattered here; the mean's gradient goes on to K8b (which adds the view-direction
+      // term and scatters it together with the SH gradients)
+      __shared__ float lds_v[8 * kPreBlock];
+      __shared__ int lds_par[kPreBlock];
+      __shared__ unsigned char lds_vis[kPreBlock];
+      const int t = threadIdx.x;
+      const int block_first = blockIdx.x * kPreBlock;
+      const int count = min(kPreBlock, a.P - block_first);
+      LodRow l;
+      l.r = l.p = 0; l.w = 1.0f; l.u = 0.0f;
+      if (in_range) l = lod_row<true>(a, idx);
+      const bool self = l.p == l.r;
+      const bool vis = in_range && n != 0;
+      const float wn = self ? 1.0f : l.w, u = (self || !vis) ? 0.0f : l.u;
+      float sgn = 1.0f;
+      if (vis && !self) {
+        const float4 qa = reinterpret_cast<const float4*>(a.rotations)[l.r];
+        const float4 qb = reinterpret_cast<const float4*>(a.rotations)[l.p];
+        sgn = (qa.x * qb.x + qa.y * qb.y + qa.z * qb.z + qa.w * qb.w) < 0.0f ? -1.0f : 1.0f;
+      }
+      if (in_range) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          dmean_rows[idx * 3 + j] = d_mean[j];
+          out.dL_dmeans2D[idx * 3 + j] = d_m2[j];
+        }
+      }
+      if (vis) {      // node row (culled rows have zero gradients: the caller's zero fill stands)
+        out.dL_dopacity[l.r] = wn * d_op;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) out.dL_dscales[l.r * 3 + j] = wn * d_scale[j];
+        reinterpret_cast<float4*>(out.dL_drotations)[l.r] = make_float4(wn * d_rot[0], wn * d_rot[1], wn * d_rot[2], wn * d_rot[3]);
+      }
+      lds_par[t] = in_range ? (int)l.p : -1;
+      lds_vis[t] = (vis && !self) ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) lds_v[j * kPreBlock + t] = u * d_scale[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds_v[(3 + j) * kPreBlock + t] = (u * sgn) * d_rot[j];
+      lds_v[7 * kPreBlock + t] = u * d_op;
+      __syncthreads();
+      if (t < count) {
+        const LodRun run = lod_run(a, lds_par, t, count, block_first, *lod_flag != 0u);
+        if (run.leader) {
+          float acc8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          bool any = false;
+          for (int j = t; j < run.end; ++j) {
+            if (!lds_vis[j]) continue;
+            any = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc8[k] += lds_v[k * kPreBlock + j];
+          }
+          if (any) {
+            const size_t pp = (size_t)lds_par[t];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lod_add(out.dL_dscales + pp * 3 + k, acc8[k], run.atomic);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) lod_add(out.dL_drotations + pp * 4 + k, acc8[3 + k], run.atomic);
+            lod_add(out.dL_dopacity + pp, acc8[7], run.atomic);
+          }
+        }
+      }
+      return;
+    }
+    if (!in_range) return;
+  }
   // accumulate_grads: add to what the buffers hold (gradient accumulation over several views of one optimizer
   // step); dL/dmeans2D (a per-view statistic) and dL/dcolors_precomp (the gradient of a view's colours) are always
   // overwritten
@@ -736,7 +842,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 // occupancy.  Adds the view-direction term to dL/dmeans3D written by K8a.
 template <bool ACC, bool JAC, bool LOD>   // JAC: d(rgb)/d(direction) was stored by K1 (prepare_backward): the coefficients are not read
 __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, GeomWs g,
-                                                           const float* __restrict__ drgb, hgs_raster_grads out) {
+                                                           const float* __restrict__ drgb,
+                                                           const float* __restrict__ dmean_rows,
+                                                           const uint32_t* __restrict__ lod_flag, hgs_raster_grads out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds = reinterpret_cast<float*>(smem_raw);
   const int n = a.M * 3;
@@ -767,6 +875,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
     }
   }
   if (!JAC && coop) __syncthreads();              // every row has been read: the buffer becomes the output stage
+  float vdir[3] = {0.f, 0.f, 0.f};                // view-direction term of dL/dmean
   if (active) {
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
     float pm[3];
@@ -801,9 +910,98 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
     }
     // through the normalisation dir = d/|d|
     const float dot = ux * gdx + uy * gdy + uz * gdz;
-    out.dL_dmeans3D[idx * 3 + 0] += (gdx - ux * dot) * inv;
-    out.dL_dmeans3D[idx * 3 + 1] += (gdy - uy * dot) * inv;
-    out.dL_dmeans3D[idx * 3 + 2] += (gdz - uz * dot) * inv;
+    vdir[0] = (gdx - ux * dot) * inv; vdir[1] = (gdy - uy * dot) * inv; vdir[2] = (gdz - uz * dot) * inv;
+    if (!(LOD && a.lod_scatter)) {
+      out.dL_dmeans3D[idx * 3 + 0] += vdir[0];
+      out.dL_dmeans3D[idx * 3 + 1] += vdir[1];
+      out.dL_dmeans3D[idx * 3 + 2] += vdir[2];
+    }
+  }
+  if constexpr (LOD) {
+    if (a.lod_scatter) {
+      // scatter of the SH and mean gradients (see lod_run): rows staged in LDS (the four pad floats of a row carry its
+      // node row, parent row, weight and "on screen"), every 16 bytes of a row handled by one lane
+      __shared__ float lds_m[3 * kPreBlock];
+      __shared__ int lds_par[kPreBlock];
+      const int t = threadIdx.x;
+      const int count = min(kPreBlock, a.P - block_first);
+      const int stride = sh_row_stride(n), cpr = n >> 2;
+      LodRow l;
+      l.r = l.p = 0; l.w = 1.0f; l.u = 0.0f;
+      if (valid) l = lod_row<true>(a, idx);
+      if (valid) {
+        lds_row_write(lds, n, dsh);
+        float* pad = lds + t * stride + n;
+        pad[0] = __uint_as_float((uint32_t)l.r); pad[1] = __uint_as_float((uint32_t)l.p); pad[2] = l.w;
+        pad[3] = __uint_as_float(active ? 1u : 0u);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) lds_m[j * kPreBlock + t] = active ? dmean_rows[idx * 3 + j] + vdir[j] : 0.0f;
+      }
+      lds_par[t] = valid ? (int)l.p : -1;
+      __syncthreads();
+      const bool nonmono = *lod_flag != 0u;
+      float4* dsh_full = reinterpret_cast<float4*>(out.dL_dshs);
+      for (int v = t; v < count * cpr; v += kPreBlock) {
+        const int row = v / cpr, c = v - row * cpr;
+        const float* rp = lds + row * stride;
+        const uint32_t r = __float_as_uint(rp[n]), pr = __float_as_uint(rp[n + 1]);
+        const bool self = r == pr;
+        if (__float_as_uint(rp[n + 3])) {                         // node row: plain store
+          const float wn = self ? 1.0f : rp[n + 2];
+          const float4 g4 = *reinterpret_cast<const float4*>(rp + c * 4);
+          dsh_full[(size_t)r * cpr + c] = make_float4(wn * g4.x, wn * g4.y, wn * g4.z, wn * g4.w);
+        }
+        const LodRun run = lod_run(a, lds_par, row, count, block_first, nonmono);
+        if (run.leader) {
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          bool any = false;
+          for (int j = row; j < run.end; ++j) {
+            const float* rj = lds + j * stride;
+            if (!__float_as_uint(rj[n + 3]) || __float_as_uint(rj[n]) == __float_as_uint(rj[n + 1])) continue;
+            any = true;
+            const float uj = 1.0f - rj[n + 2];
+            const float4 g4 = *reinterpret_cast<const float4*>(rj + c * 4);
+            acc.x += uj * g4.x; acc.y += uj * g4.y; acc.z += uj * g4.z; acc.w += uj * g4.w;
+          }
+          if (any) {
+            float* dst = reinterpret_cast<float*>(dsh_full + (size_t)pr * cpr + c);
+            if (run.atomic) {
+              atomicAdd(dst + 0, acc.x); atomicAdd(dst + 1, acc.y); atomicAdd(dst + 2, acc.z); atomicAdd(dst + 3, acc.w);
+            } else {
+              *reinterpret_cast<float4*>(dst) = acc;
+            }
+          }
+        }
+      }
+      if (t < count) {                                            // the mean: one lane per row
+        const float* rp = lds + t * stride;
+        const uint32_t r = __float_as_uint(rp[n]), pr = __float_as_uint(rp[n + 1]);
+        const bool self = r == pr;
+        if (__float_as_uint(rp[n + 3])) {
+          const float wn = self ? 1.0f : rp[n + 2];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) out.dL_dmeans3D[(size_t)r * 3 + j] = wn * lds_m[j * kPreBlock + t];
+        }
+        const LodRun run = lod_run(a, lds_par, t, count, block_first, nonmono);
+        if (run.leader) {
+          float acc3[3] = {0.f, 0.f, 0.f};
+          bool any = false;
+          for (int j = t; j < run.end; ++j) {
+            const float* rj = lds + j * stride;
+            if (!__float_as_uint(rj[n + 3]) || __float_as_uint(rj[n]) == __float_as_uint(rj[n + 1])) continue;
+            any = true;
+            const float uj = 1.0f - rj[n + 2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc3[k] += uj * lds_m[k * kPreBlock + j];
+          }
+          if (any) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lod_add(out.dL_dmeans3D + (size_t)pr * 3 + k, acc3[k], run.atomic);
+          }
+        }
+      }
+      return;
+    }
   }
   if (coop) {
     if (valid) lds_row_write(lds, n, dsh);
@@ -1057,19 +1255,19 @@ int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug)
 }
 
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
-                          const hgs_raster_grads& out, hipStream_t s) {
+                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     auto k8a = a.lod_render_indices ? preprocess_bwd_kernel<false, true>      // (accumulation is refused with lod, abi.cpp)
                                     : (a.accumulate_grads ? preprocess_bwd_kernel<true, false> : preprocess_bwd_kernel<false, false>);
-    hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, out);
+    hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, dmean_rows, lod_flag, out);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
       auto k8b = a.lod_render_indices ? sh_bwd_kernel<false, true, true>
                  : (a.prepare_backward && a.shs) ? (a.accumulate_grads ? sh_bwd_kernel<true, true, false> : sh_bwd_kernel<false, true, false>)
                                                  : (a.accumulate_grads ? sh_bwd_kernel<true, false, false> : sh_bwd_kernel<false, false, false>);
-      hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, out);
+      hipLaunchKernelGGL(k8b, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, drgb, dmean_rows, lod_flag, out);
       HGS_LAUNCH_CHECK("sh_bwd", s, a.debug);
     }
   }

@@ -227,6 +227,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     return L.value, color, radii, geom, binb, img, invdepth, call
 
 
+lod_scatter_in_kernel = True     # False: row gradients through memory + lod_gather_backward (kept for 3M % 4 != 0; tests)
+
+
 def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth, out=None, accumulate=False,
                                  defer_sh=False):
     """Backward.  Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh,
@@ -255,14 +258,29 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
             return t.view(*shape)
         return torch.empty(*shape, **f32)
 
-    d_m3 = buf("means3D", (P, 3))
+    # In-op LOD interpolation: the backward's per-Gaussian kernels scatter node / parent gradients themselves into
+    # FULL-size, zero-filled arrays (hgs_raster_args.lod_scatter); only with 3M % 4 != 0 do the row gradients go
+    # through memory and lod_gather_backward.
+    lod_scatter = (lod_scatter_in_kernel and bool(a.lod_render_indices) and (int(a.M) * 3) % 4 == 0 and out is None
+                   and not defer_sh)
+    a.lod_scatter = int(lod_scatter)
     d_m2 = buf("means2D", (P, 3))
-    d_op = buf("opacities", (P, 1))
-    d_sh = buf("shs", (P,) + tuple(sh.shape[1:])) if sh is not None else None      # P rows (!= sh.shape[0] with lod=)
+    if lod_scatter:
+        G = int(a.lod_rows)
+        d_m3 = torch.zeros(G, 3, **f32)
+        d_op = torch.zeros(G, 1, **f32)
+        d_sh = torch.zeros((G,) + tuple(sh.shape[1:]), **f32)
+    else:
+        d_m3 = buf("means3D", (P, 3))
+        d_op = buf("opacities", (P, 1))
+        d_sh = buf("shs", (P,) + tuple(sh.shape[1:])) if sh is not None else None  # P rows (!= sh.shape[0] with lod=)
     d_shr = buf("shs_rest", tuple(sh_rest.shape)) if sh_rest is not None else None
     d_col = buf("colors_precomp", (P, 3)) if colors is not None else None
-    d_sc = buf("scales", (P, 3)) if scales is not None else None
-    d_rot = buf("rotations", (P, 4)) if rotations is not None else None
+    if lod_scatter:
+        d_sc, d_rot = torch.zeros(G, 3, **f32), torch.zeros(G, 4, **f32)
+    else:
+        d_sc = buf("scales", (P, 3)) if scales is not None else None
+        d_rot = buf("rotations", (P, 4)) if rotations is not None else None
     d_cov = buf("cov3D_precomp", (P, 6)) if cov3D is not None else None
     p = _lib.ptr
     g.dL_dmeans3D, g.dL_dmeans2D, g.dL_dshs, g.dL_dcolors = p(d_m3), p(d_m2), p(d_sh), p(d_col)

@@ -287,8 +287,9 @@ class _RasterizeGaussiansLod(torch.autograd.Function):
     """In-op LOD interpolation: the op takes the FULL hierarchy attribute tensors plus the cut
     (render / parent indices, weights) and interpolates node and parent rows in registers inside its per-Gaussian
     kernels, forward and backward (hgs_raster_args.lod_*) -- what gaussian_renderer/__init__.py:199-234 does with ~25
-    torch kernels and three materialised copies of the rows.  The backward's row gradients are scattered to node and
-    parent rows by hgs_lod_gather_bwd."""
+    torch kernels and three materialised copies of the rows.  The backward's per-Gaussian kernels scatter the
+    gradients to node and parent rows themselves (hgs_raster_args.lod_scatter; with 3M % 4 != 0 the row gradients go
+    through memory and hgs_lod_gather_bwd)."""
 
     @staticmethod
     def forward(ctx, means3D, means2D, sh, opacities, scales, rotations, raster_settings, render_indices,
@@ -321,6 +322,8 @@ class _RasterizeGaussiansLod(torch.autograd.Function):
         d_m2, _, d_op, d_m3, _, d_sh, d_sc, d_rot = _C.rasterize_gaussians_backward(call, color, invdepth, grad_color,
                                                                                    grad_invdepth)
         ctx.call = None
+        if call.args.lod_scatter:        # scattered to node / parent rows inside the op's backward kernels
+            return d_m3, d_m2, d_sh, d_op, d_sc, d_rot, None, None, None, None, None, None
         n, K = int(ri.numel()), ctx.skybox_points
         pi, w = pi[:n], w[:n]
         if K > 0:      # the skybox rows are their own parents with weight 1

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 3
+#define HGS_ABI_VERSION 4
 #define HGS_TILE 16
 #define HGS_INST_GRAD_STRIDE 12 /* floats per (tile, Gaussian) instance in the backward scratch */
 
@@ -114,13 +114,20 @@ typedef struct hgs_raster_args {
    *     i >= lod_n :  attr[lod_rows - (P - lod_n) + (i - lod_n)]   -- the skybox tail (:220-234)
    * computed in registers by the per-Gaussian kernels of the forward AND of the backward: no interpolated row is ever
    * written to memory.  Needs shs + scales + rotations (no precomputed colours / covariances, no activations),
-   * interpolation_weights / num_node_kids with >= P entries, prepare_backward = 1 for a differentiable call.  The
-   * backward writes the gradients w.r.t. the INTERPOLATED rows ([P, ...]); hgs_lod_gather_bwd scatters them. */
+   * interpolation_weights / num_node_kids with >= P entries, prepare_backward = 1 for a differentiable call.
+   * Backward, lod_scatter = 0: the gradients w.r.t. the INTERPOLATED rows ([P, ...]) are written; hgs_lod_gather_bwd
+   * scatters them.  lod_scatter = 1 (needs 3M % 4 == 0): the backward's per-Gaussian kernels scatter themselves --
+   * grads.dL_dmeans3D / dL_dscales / dL_drotations / dL_dopacity / dL_dshs then point at FULL arrays ([lod_rows, ...],
+   * ZERO-FILLED by the caller) and receive w_i * g_i at the node row and the sum of (1 - w_i) * g_i over each run of
+   * siblings at the parent row (the parent quaternion's hemisphere flip applied); no row gradient is ever written to
+   * memory.  Runs are found among CONSECUTIVE rows (expand_to_size emits non-decreasing parents: every parent is then
+   * written once, without atomics, bit-reproducibly); other orders are detected and fall back to atomic adds.
+   * dL_dmeans2D stays per row ([P, 3]). */
   int32_t lod_n;
   const int32_t* lod_render_indices;
   const int32_t* lod_parent_indices;
   int32_t lod_rows;
-  int32_t reserved0;
+  int32_t lod_scatter;
 } hgs_raster_args;
 
 enum {

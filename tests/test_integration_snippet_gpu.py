@@ -24,7 +24,7 @@ def test_documented_ctypes_binding_renders_the_same_image(gpu):
                     "interpolation_weights", "num_node_kids", "shs_rest")] + \
                    [("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("bwd_ws_prezero", C.c_void_p),
                     ("prepare_backward", C.c_int32), ("lod_n", C.c_int32), ("lod_render_indices", C.c_void_p),
-                    ("lod_parent_indices", C.c_void_p), ("lod_rows", C.c_int32), ("reserved0", C.c_int32)]
+                    ("lod_parent_indices", C.c_void_p), ("lod_rows", C.c_int32), ("lod_scatter", C.c_int32)]
 
     assert C.sizeof(RasterArgs) == C.sizeof(_lib.RasterArgs)
     W, H, P = 320, 180, 5000

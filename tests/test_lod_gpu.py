@@ -254,6 +254,63 @@ def test_in_op_lod_interpolation_matches_python_glue(gpu, skybox):
             assert float(gb[sk].abs().sum()) > 0.0
 
 
+@pytest.mark.parametrize("order", ["as_emitted", "shuffled"])
+def test_in_kernel_lod_scatter_equals_separate_scatter(gpu, order):
+    """The backward of the in-op LOD interpolation scatters node / parent gradients inside its per-Gaussian kernels
+    (hgs_raster_args.lod_scatter: run-leader sums when the parents are non-decreasing, atomic adds otherwise) -- same
+    gradients as the row gradients + hgs_lod_gather_bwd route, for the order expand_to_size emits and for a shuffled
+    cut (parents no longer sorted: the atomic fallback)."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    h, cam, nodes, boxes = _setup(6000, gpu, seed=4)
+    G = h.xyz.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=gpu); ns = torch.zeros(G, dtype=torch.int32, device=gpu)
+    tau = (2 * (3 + 0.5)) * cam.tanfovx / (0.5 * cam.image_width)
+    n = expand_to_size(nodes, boxes, tau, cam.camera_center.to(gpu), torch.zeros(3), ri, pi, ni)
+    assert 300 < n < G           # several workgroups: runs of siblings cross their boundaries
+    get_interpolation_weights(ni[:n], tau, nodes, boxes, cam.camera_center.cpu(), torch.zeros(3), w, ns)
+    if order == "shuffled":
+        perm = torch.randperm(n, generator=torch.Generator().manual_seed(0)).to(gpu)
+        for t in (ri, pi, w, ns):
+            t[:n] = t[:n][perm]
+        assert bool((pi[1:n] < pi[:n - 1]).any())
+    else:
+        assert not bool((pi[1:n] < pi[:n - 1]).any())
+    gc, _ = synth.upstream_grads(cam.image_height, cam.image_width)
+    gc = gc.to(gpu)
+    kw = pa.settings_kwargs(cam, torch.zeros(3), 3, do_depth=False, device=gpu, interpolation_weights=w, num_node_kids=ns)
+    kw["render_indices"], kw["parent_indices"] = ri[:n].contiguous(), pi
+    rs = dgr.GaussianRasterizationSettings(**kw)
+
+    def run(in_kernel):
+        mk = lambda t: t.to(gpu).clone().requires_grad_(True)
+        L = dict(xyz=mk(h.xyz), sc=mk(torch.exp(h.log_scales)), rot=mk(torch.nn.functional.normalize(h.rots)),
+                 shs=mk(h.shs), op=mk(h.alpha.abs()))
+        m2 = torch.zeros(G, 3, device=gpu, requires_grad=True)
+        dgr._C.lod_scatter_in_kernel = in_kernel
+        try:
+            c, _, _ = dgr.GaussianRasterizer(rs)(means3D=L["xyz"], means2D=m2, shs=L["shs"], opacities=L["op"],
+                                                scales=L["sc"], rotations=L["rot"])
+            (c * gc).sum().backward()
+        finally:
+            dgr._C.lod_scatter_in_kernel = True
+        return c.detach(), {k: v.grad for k, v in L.items()}, m2.grad
+
+    ca, ga, m2a = run(True)
+    cb, gb, m2b = run(False)
+    assert torch.equal(ca, cb) and torch.equal(m2a, m2b)
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert scale > 0
+        err = float((ga[k] - gb[k]).abs().max())
+        assert err <= 2e-6 * scale, (k, err, scale)
+    if order == "as_emitted":      # no atomics on this route: bit-reproducible
+        _, ga2, _ = run(True)
+        assert all(torch.equal(ga[k], ga2[k]) for k in ga)
+
+
 def test_config5_scale_50m_node_hierarchy_4k(gpu):
     """BASELINE config 5 at its stated size: a 50 M-node hierarchy (25 M leaves, 15 GB) fully resident in HBM -- on a
     288 GB part the reference's "VRAM-budgeted streaming" is not needed -- cut per view and rendered at 3840x2160
