@@ -122,7 +122,8 @@ typedef struct hgs_raster_args {
    * siblings at the parent row (the parent quaternion's hemisphere flip applied); no row gradient is ever written to
    * memory.  Runs are found among CONSECUTIVE rows (expand_to_size emits non-decreasing parents: every parent is then
    * written once, without atomics, bit-reproducibly); other orders are detected and fall back to atomic adds.
-   * dL_dmeans2D stays per row ([P, 3]). */
+   * dL_dmeans2D stays per row ([P, 3]).  Precondition (as for hgs_lod_gather_bwd): render indices unique, no drawn row is
+   * another entry's parent row -- true for any LOD cut. */
   int32_t lod_n;
   const int32_t* lod_render_indices;
   const int32_t* lod_parent_indices;
