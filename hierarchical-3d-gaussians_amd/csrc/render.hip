@@ -283,8 +283,11 @@ struct BwdPair {
   f2 fly, T, A, bgd, g0, g1, g2, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
   uint32_t nc0, nc1;
 };
+// Per-lane partial sums of one (tile, Gaussian) over the lane's four pixels, as plain floats.  All four pixels of a lane
+// share x, so the three sums that carry dx (sum X dx, sum X dx^2, sum X dx dy) are formed from a0 / a1 just before the
+// cross-lane reduction instead of being accumulated per pixel pair.
 struct BwdSums {
-  f2 s0, s1, s2, s3, s4, s5, s6, s7, s8, s9;
+  float a0, a1, a4, s5, s6, s7, s8, s9;   // sum X, sum X dy, sum X dy^2, sum G dL/dalpha, sum w dL/dC_rgb, sum w dL/dD
 };
 
 // FIRST: the sums are assigned, not accumulated (the first visited half of an instance: no zero-filled accumulators)
@@ -311,41 +314,31 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   const f2 dLda = {live0 ? dfull.x : 0.0f, live1 ? dfull.y : 0.0f};
   const f2 w = ae * Tcur;
   const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
-  const f2 Xdx = X * dx, Xdy = X * dy;
+  const f2 Xdy = X * dy;
+  // dot products over the pair's two pixels with plain instructions (a packed product + a fold of its halves costs more)
   if (FIRST) {
-    S.s0 = Xdx;
-    S.s1 = Xdy;
-    S.s2 = Xdx * dx;
-    S.s3 = Xdx * dy;
-    S.s4 = Xdy * dy;
-    S.s5 = G * dLda;
-    S.s6 = w * p.g0;
-    S.s7 = w * p.g1;
-    S.s8 = w * p.g2;
-    if (DEPTH) S.s9 = w * p.gd;
+    S.a0 = X.x + X.y;
+    S.a1 = Xdy.x + Xdy.y;
+    S.a4 = fmaf(Xdy.y, dy.y, Xdy.x * dy.x);
+    S.s5 = fmaf(G.y, dLda.y, G.x * dLda.x);
+    S.s6 = fmaf(w.y, p.g0.y, w.x * p.g0.x);
+    S.s7 = fmaf(w.y, p.g1.y, w.x * p.g1.x);
+    S.s8 = fmaf(w.y, p.g2.y, w.x * p.g2.x);
+    if (DEPTH) S.s9 = fmaf(w.y, p.gd.y, w.x * p.gd.x);
   } else {
-    S.s0 += Xdx;
-    S.s1 += Xdy;
-    S.s2 = fma2(Xdx, splat(dx), S.s2);
-    S.s3 = fma2(Xdx, dy, S.s3);
-    S.s4 = fma2(Xdy, dy, S.s4);
-    S.s5 = fma2(G, dLda, S.s5);
-    S.s6 = fma2(w, p.g0, S.s6);
-    S.s7 = fma2(w, p.g1, S.s7);
-    S.s8 = fma2(w, p.g2, S.s8);
-    if (DEPTH) S.s9 = fma2(w, p.gd, S.s9);
+    S.a0 += X.x + X.y;
+    S.a1 += Xdy.x + Xdy.y;
+    S.a4 = fmaf(Xdy.y, dy.y, fmaf(Xdy.x, dy.x, S.a4));
+    S.s5 = fmaf(G.y, dLda.y, fmaf(G.x, dLda.x, S.s5));
+    S.s6 = fmaf(w.y, p.g0.y, fmaf(w.x, p.g0.x, S.s6));
+    S.s7 = fmaf(w.y, p.g1.y, fmaf(w.x, p.g1.x, S.s7));
+    S.s8 = fmaf(w.y, p.g2.y, fmaf(w.x, p.g2.x, S.s8));
+    if (DEPTH) S.s9 = fmaf(w.y, p.gd.y, fmaf(w.x, p.gd.x, S.s9));
   }
   p.T = Tcur;
   p.A = fma2(ae, qA, p.A);                                      // A_(i-1) = alpha_i q_i + (1 - alpha_i) A_i
 }
 
-// x + y of a float2 as ONE plain v_add_f32 (the compiler picks a packed add with swizzled operands for this, which
-// costs 1.6x as much -- scripts/microbench/valu_issue.hip)
-__device__ __forceinline__ float fold(f2 v) {
-  float r;
-  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(v.x), "v"(v.y));
-  return r;
-}
 __device__ __forceinline__ float swap32_add(float a, float b) {   // [a.lo+a.hi | b.lo+b.hi]
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -485,7 +478,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       if (!(b0 || b1)) continue;
       const float4 q2 = lrec[j * kRecVec + 2];
       BwdSums S;
-      if (!DEPTH) S.s9 = splat(0.0f);
+      if (!DEPTH) S.s9 = 0.0f;
       if (b0) {
         bwd_pair_live<DEPTH, true>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
         if (b1) bwd_pair_live<DEPTH, false>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
@@ -493,15 +486,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         bwd_pair_live<DEPTH, true>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
       }
       {
-        // 10 sums x 64 lanes -> 10 floats of the instance record: fold the two strips of each pair, halve the lane
+        // 10 sums x 64 lanes -> 10 floats of the instance record: halve the lane
         // count twice with permlane32 / permlane16 swaps (two values share a register afterwards: rows of the two
         // registers = (s0,s2,s1,s3) and (s4,s6,s5,s7); s8 / s9 keep two rows each), then ONE packed row reduction of the
         // three registers (row_sum16_x3) that also joins the row pairs of s8 / s9.
-        const float u0 = swap32_add(fold(S.s0), fold(S.s1));
-        const float u1 = swap32_add(fold(S.s2), fold(S.s3));
-        const float u2 = swap32_add(fold(S.s4), fold(S.s5));
-        const float u3 = swap32_add(fold(S.s6), fold(S.s7));
-        const float u4 = swap32_add(fold(S.s8), DEPTH ? fold(S.s9) : 0.0f);
+        const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
+        const float s2 = dx * s0;                        // sum X dx^2
+        const float u0 = swap32_add(s0, S.a1);
+        const float u1 = swap32_add(s2, s3);
+        const float u2 = swap32_add(S.a4, S.s5);
+        const float u3 = swap32_add(S.s6, S.s7);
+        const float u4 = swap32_add(S.s8, S.s9);
         const float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
         if (store_k >= 0) {
           const uint32_t off = __float_as_uint(q2.z);
