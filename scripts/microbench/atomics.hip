@@ -21,6 +21,14 @@ __global__ void store_kernel(uint32_t* out, uint32_t n, uint32_t span) {
   if (i < n) out[hash(i) % span] = i;
 }
 
+// the same stores, but a workgroup only writes into the eighth of the span that belongs to its XCD (workgroup b runs
+// on XCD b % 8): every 128-byte line is then assembled in ONE L2 instead of being written back in pieces by eight
+__global__ void store_xcd_kernel(uint32_t* out, uint32_t n, uint32_t span) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t part = span / 8;
+  if (i < n) out[(blockIdx.x & 7) * part + hash(i) % part] = i;
+}
+
 int main() {
   const uint32_t n = 2665429;
   uint32_t *cnt, *sink;
@@ -48,6 +56,16 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
     printf("random 4B stores n=%u span=%u : %.1f us\n", n, span, best * 1e3);
+  }
+  for (uint32_t span : {2665429u, 8u << 20}) {
+    float best = 1e9f;
+    for (int it = 0; it < 5; ++it) {
+      CK(hipEventRecord(a));
+      hipLaunchKernelGGL(store_xcd_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, cnt, n, span);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    printf("random 4B stores, XCD-local eighths n=%u span=%u : %.1f us\n", n, span, best * 1e3);
   }
   return 0;
 }
