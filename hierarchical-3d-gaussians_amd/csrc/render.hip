@@ -280,7 +280,8 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
 
 // ---- packed backward ------------------------------------------------------------------
 struct BwdPair {
-  f2 fly, T, A, bgd, g0, g1, g2, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
+  f2 fly, T, A, bgd, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
+  const f2* pix;           // LDS: this lane's dL/dC (r, g, b) of the pair's two pixels at [0], [64], [128] (see the kernel)
   uint32_t nc0, nc1;
 };
 // Per-lane partial sums of one (tile, Gaussian) over the lane's four pixels, as plain floats.  All four pixels of a lane
@@ -307,7 +308,8 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
   const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
-  f2 q = fma2(p.g2, splat(q2.x), fma2(p.g1, splat(q1.w), p.g0 * q1.z));
+  const f2 g0 = p.pix[0], g1 = p.pix[64], g2 = p.pix[128];
+  f2 q = fma2(g2, splat(q2.x), fma2(g1, splat(q1.w), g0 * q1.z));
   if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
   const f2 qA = q - p.A;
   const f2 dfull = fma2(qA, Tcur, -(p.bgd * rinv));
@@ -321,18 +323,18 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
     S.a1 = Xdy.x + Xdy.y;
     S.a4 = fmaf(Xdy.y, dy.y, Xdy.x * dy.x);
     S.s5 = fmaf(G.y, dLda.y, G.x * dLda.x);
-    S.s6 = fmaf(w.y, p.g0.y, w.x * p.g0.x);
-    S.s7 = fmaf(w.y, p.g1.y, w.x * p.g1.x);
-    S.s8 = fmaf(w.y, p.g2.y, w.x * p.g2.x);
+    S.s6 = fmaf(w.y, g0.y, w.x * g0.x);
+    S.s7 = fmaf(w.y, g1.y, w.x * g1.x);
+    S.s8 = fmaf(w.y, g2.y, w.x * g2.x);
     if (DEPTH) S.s9 = fmaf(w.y, p.gd.y, w.x * p.gd.x);
   } else {
     S.a0 += X.x + X.y;
     S.a1 += Xdy.x + Xdy.y;
     S.a4 = fmaf(Xdy.y, dy.y, fmaf(Xdy.x, dy.x, S.a4));
     S.s5 = fmaf(G.y, dLda.y, fmaf(G.x, dLda.x, S.s5));
-    S.s6 = fmaf(w.y, p.g0.y, fmaf(w.x, p.g0.x, S.s6));
-    S.s7 = fmaf(w.y, p.g1.y, fmaf(w.x, p.g1.x, S.s7));
-    S.s8 = fmaf(w.y, p.g2.y, fmaf(w.x, p.g2.x, S.s8));
+    S.s6 = fmaf(w.y, g0.y, fmaf(w.x, g0.x, S.s6));
+    S.s7 = fmaf(w.y, g1.y, fmaf(w.x, g1.x, S.s7));
+    S.s8 = fmaf(w.y, g2.y, fmaf(w.x, g2.x, S.s8));
     if (DEPTH) S.s9 = fmaf(w.y, p.gd.y, fmaf(w.x, p.gd.x, S.s9));
   }
   p.T = Tcur;
@@ -349,14 +351,20 @@ __device__ __forceinline__ float swap16_add(float a, float b) {   // rows: [a.r0
 }
 
 template <bool DEPTH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void render_bwd_packed_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_bwd_packed_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order) {
   constexpr int BATCH = 64;
-  __shared__ float4 lrec[BATCH * kRecVec];
+  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,emission offset,rect)
+  __shared__ float4 lrec[BATCH * kLds];
+  __shared__ float lthr[BATCH];          // skip threshold
+  // The colour gradients of a lane's four pixels are constants that only the live path reads: they sit in LDS ([pair][r,
+  // g, b][lane] as float2; written and read by the SAME lane, so no barrier), not in 12 registers -- the kernel then
+  // fits 80 registers = 6 waves per SIMD (7 KB of LDS per wave: 24 waves per CU)
+  __shared__ f2 lpix[2 * 3 * 64];
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
@@ -397,9 +405,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
   P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
   P0.T = f2{Tr[0], Tr[1]};     P1.T = f2{Tr[2], Tr[3]};
   P0.bgd = f2{bgd[0], bgd[1]}; P1.bgd = f2{bgd[2], bgd[3]};
-  P0.g0 = f2{g0[0], g0[1]};    P1.g0 = f2{g0[2], g0[3]};
-  P0.g1 = f2{g1[0], g1[1]};    P1.g1 = f2{g1[2], g1[3]};
-  P0.g2 = f2{g2[0], g2[1]};    P1.g2 = f2{g2[2], g2[3]};
+  P0.pix = lpix + lane; P1.pix = lpix + 3 * 64 + lane;
+  lpix[0 * 64 + lane] = f2{g0[0], g0[1]}; lpix[3 * 64 + lane] = f2{g0[2], g0[3]};
+  lpix[1 * 64 + lane] = f2{g1[0], g1[1]}; lpix[4 * 64 + lane] = f2{g1[2], g1[3]};
+  lpix[2 * 64 + lane] = f2{g2[0], g2[1]}; lpix[5 * 64 + lane] = f2{g2[2], g2[3]};
   P0.gd = f2{gd[0], gd[1]};    P1.gd = f2{gd[2], gd[3]};
   P0.A = P1.A = splat(0.0f);
   P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
@@ -431,10 +440,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       half0 = xok && (a0.y - ey <= 7.0f) && (a0.y + ey >= 0.0f);
       half1 = xok && (a0.y - ey <= 15.0f) && (a0.y + ey >= 8.0f);
       a2.z = __uint_as_float(offsets[gid]);     // emission offset of this Gaussian's instance run
-      lrec[lane * kRecVec + 0] = a0;
-      lrec[lane * kRecVec + 1] = r[1];
-      lrec[lane * kRecVec + 2] = a2;
-      lrec[lane * kRecVec + 3] = a3;
+      lrec[lane * kLds + 0] = a0;
+      lrec[lane * kLds + 1] = r[1];
+      lrec[lane * kLds + 2] = a2;
+      lthr[lane] = a3.z;
     }
     const uint64_t m0 = __ballot(half0), m1 = __ballot(half1);
     __syncthreads();
@@ -443,14 +452,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
       const int j = 63 - __builtin_clzll(todo);
       todo &= ~(1ull << j);
       const uint32_t rel = (uint32_t)(bstart + j);
-      const float4 q0 = lrec[j * kRecVec + 0];
-      const float4 q1 = lrec[j * kRecVec + 1];
-      const float4 q3 = lrec[j * kRecVec + 3];
+      const float4 q0 = lrec[j * kLds + 0];
+      const float4 q1 = lrec[j * kLds + 1];
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const float thr = q3.z;
+      const float thr = lthr[j];
       // per flagged half: exponents, per-strip candidate predicates (log-domain alpha test AND "the forward blended
       // this Gaussian into the pixel", i.e. rel < n_contrib) and the wave-uniform "half has a candidate" from the
       // ballots of the plain compares combined in scalar registers
@@ -476,7 +484,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 5))) void
         b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
       }
       if (!(b0 || b1)) continue;
-      const float4 q2 = lrec[j * kRecVec + 2];
+      const float4 q2 = lrec[j * kLds + 2];
       BwdSums S;
       if (!DEPTH) S.s9 = 0.0f;
       if (b0) {
