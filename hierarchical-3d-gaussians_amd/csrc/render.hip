@@ -294,7 +294,7 @@ struct BwdSums {
 // FIRST: the sums are assigned, not accumulated (the first visited half of an instance: no zero-filled accumulators)
 template <bool DEPTH, bool FIRST>
 __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
-                                              const float4& q1, const float4& q2) {
+                                              const float4& q1, f2 q2) {   // q2 = (blue, 1/z)
   // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
   // keeps G finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
@@ -485,7 +485,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
       }
       if (!(b0 || b1)) continue;
-      const float4 q2 = lrec[j * kLds + 2];
+      // the record's third float4 in two halves: (blue, 1/z) now, for the live path; (emission offset, rectangle) next
+      // to the reduction that hides its latency -- read as one float4 here, the two scalars it feeds into the store's
+      // address make the compiler wait for the whole read before the live path starts
+      const f2 q2 = *reinterpret_cast<const f2*>(&lrec[j * kLds + 2]);
       BwdSums S;
       if (!DEPTH) S.s9 = 0.0f;
       if (b0) {
@@ -499,6 +502,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         // count twice with permlane32 / permlane16 swaps (two values share a register afterwards: rows of the two
         // registers = (s0,s2,s1,s3) and (s4,s6,s5,s7); s8 / s9 keep two rows each), then ONE packed row reduction of the
         // three registers (row_sum16_x3) that also joins the row pairs of s8 / s9.
+        const uint2 slot = *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(&lrec[j * kLds + 2]) + 2);
         const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
         const float s2 = dx * s0;                        // sum X dx^2
         const float u0 = swap32_add(s0, S.a1);
@@ -507,9 +511,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         const float u3 = swap32_add(S.s6, S.s7);
         const float u4 = swap32_add(S.s8, S.s9);
         const float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
+        __builtin_amdgcn_sched_barrier(0);              // (keep the scalar address arithmetic behind the reduction)
         if (store_k >= 0) {
-          const uint32_t off = __float_as_uint(q2.z);
-          const uint32_t rb = __float_as_uint(q2.w);
+          const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot.x);
+          const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot.y);
           const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
           const uint32_t e = off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
           inst[(size_t)e * kInstStride + store_k] = v;     // ONE store: ten lanes, 40 of the record's 48 bytes
