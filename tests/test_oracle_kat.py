@@ -149,3 +149,41 @@ def test_lod_opacity_identity_and_stacking():
     r = ro.lod_opacity(o, torch.zeros(4, dtype=torch.float64), kids)
     assert torch.allclose(1 - (1 - r[:3]) ** 3, o[:3])            # k stacked copies composite like the parent
     assert torch.allclose(ro.lod_opacity(o, torch.ones(4, dtype=torch.float64), kids), o)
+
+
+def test_saturation_stop_rule_and_last_contributor():
+    """App. A.8: a pixel is finished when T (1 - alpha) would drop below 1e-4 -- the Gaussian that triggers the test is
+    NOT blended.  Five very wide layers of opacity 0.95 on one axis: T = 1 -> 0.05 -> 0.0025 -> 1.25e-4, the fourth layer
+    would give 6.25e-6 < 1e-4 and ends the pixel: three layers blended, final T = 1.25e-4, last contributor = 3.
+    (Numbers chosen away from the threshold: with alpha = 0.99 the second layer sits at 1e-4 +- rounding.)"""
+    cam = synth.make_camera(32, 32)
+    zs = [2.0, 3.0, 4.0, 5.0, 6.0]
+    cols = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (1.0, 1.0, 0.0), (0.0, 1.0, 1.0)]
+    sc = synth.Scene(torch.tensor([[0.0, 0.0, z] for z in zs]), torch.tensor([[20.0 * z / 2.0] * 3 for z in zs]),
+                     torch.tensor([[1.0, 0, 0, 0]] * 5), torch.full((5, 1), 0.95), torch.zeros(5, 16, 3), 0)
+    for i, c in enumerate(cols):                              # SH degree 0: rgb = 0.5 + C0 * dc
+        sc.shs[i, 0] = (torch.tensor(c) - 0.5) / 0.28209479177387814
+    out = _render(sc, cam, torch.tensor([0.5, 0.5, 0.5]))
+    y = x = 16
+    w = [0.95, 0.95 * 0.05, 0.95 * 0.0025]                    # layer weights (the footprint factor is 1 - 1e-5 here)
+    assert int(out.n_contrib[y, x]) == 3
+    assert abs(float(out.final_T[y, x]) - 1.25e-4) < 1e-7
+    expect = np.array([w[0], w[1], w[2]]) + 1.25e-4 * 0.5
+    assert np.abs(out.color[:, y, x].numpy() - expect).max() < 2e-5
+    assert abs(float(out.invdepth[0, y, x]) - (w[0] / 2.0 + w[1] / 3.0 + w[2] / 4.0)) < 2e-5
+
+
+def test_frustum_cull_keeps_gaussians_up_to_the_ewa_clamp():
+    """App. A.3-4: only z <= 0.2 culls; a centre far outside the image is kept, and its view-space x / z is clamped to
+    1.3 tan(fov / 2) inside the EWA Jacobian (the projected centre itself is not clamped): the Gaussian keeps a positive
+    radius but touches no tile once its 3-sigma square leaves the image."""
+    cam = synth.make_camera(64, 64)
+    inside = _render(_one(z=4.0, s=0.05, xy=(0.0, 0.0)), cam)
+    off = _render(_one(z=4.0, s=0.05, xy=(4.0 * 3.0 * cam.tanfovx, 0.0)), cam)      # x / z = 3 tan(fov / 2)
+    assert int(inside.radii[0]) > 0 and inside.binning.num_rendered > 0
+    assert int(off.radii[0]) == 0 and off.binning.num_rendered == 0                  # nothing to draw: radius reported 0
+    # just outside the right edge, but its 3-sigma square still reaches the last tile column
+    edge = _render(_one(z=4.0, s=0.3, xy=(4.0 * 1.05 * cam.tanfovx, 0.0)), cam)
+    assert int(edge.radii[0]) > 0 and edge.binning.num_rendered > 0
+    gx = edge.geom.grid[0]
+    assert int(edge.geom.rect_max[0, 0]) == gx and int(edge.geom.rect_min[0, 0]) < gx

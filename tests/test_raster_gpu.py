@@ -398,6 +398,34 @@ def test_awkward_inputs(gpu):
     assert float(hip["grads"]["opacities"][12:18].abs().max()) == 0.0
 
 
+def test_closed_form_known_answers_on_the_device(gpu):
+    """The HIP path against hand-derivable numbers, not against the oracle: five very wide
+    layers of opacity 0.95 on one axis -- T goes 1 -> 0.05 -> 0.0025 -> 1.25e-4, the fourth layer would give
+    6.25e-6 < 1e-4 and ends the pixel WITHOUT being blended: three layers with weights 0.95, 0.0475, 0.002375, final T
+    1.25e-4, last contributor 3, and only the three blended layers receive gradients."""
+    cam = synth.make_camera(32, 32)
+    zs = [2.0, 3.0, 4.0, 5.0, 6.0]
+    cols = [(1.0, 0.0, 0.0), (0.0, 1.0, 0.0), (0.0, 0.0, 1.0), (1.0, 1.0, 0.0), (0.0, 1.0, 1.0)]
+    sc = synth.Scene(torch.tensor([[0.0, 0.0, z] for z in zs]), torch.tensor([[20.0 * z / 2.0] * 3 for z in zs]),
+                     torch.tensor([[1.0, 0, 0, 0]] * 5), torch.full((5, 1), 0.95), torch.zeros(5, 16, 3), 0)
+    for i, c in enumerate(cols):
+        sc.shs[i, 0] = (torch.tensor(c) - 0.5) / 0.28209479177387814
+    gc = torch.zeros(3, 32, 32); gc[:, 16, 16] = 1.0           # upstream gradient on the one pixel that is checked
+    gd = torch.zeros(1, 32, 32)
+    hip = pa.run_hip(sc, cam, torch.tensor([0.5, 0.5, 0.5]), gc, gd, gpu)
+    y = x = 16
+    w = [0.95, 0.95 * 0.05, 0.95 * 0.0025]
+    expect = torch.tensor(w) + 1.25e-4 * 0.5
+    assert float((hip["color"][:, y, x] - expect).abs().max()) < 2e-5
+    assert abs(float(hip["invdepth"][0, y, x]) - (w[0] / 2.0 + w[1] / 3.0 + w[2] / 4.0)) < 2e-5
+    assert int(hip["views"]["n_contrib"][y, x]) == 3
+    assert abs(float(hip["views"]["final_T"][y, x]) - 1.25e-4) < 1e-7
+    g = hip["grads"]["shs"][:, 0, :]                           # dL/d(dc) = C0 * weight of the layer, its own channel
+    assert float(g[3:].abs().max()) == 0.0                     # layers 4, 5 were never blended into that pixel
+    for i in range(3):
+        assert abs(float(g[i, i]) - 0.28209479177387814 * w[i]) < 2e-6
+
+
 def test_extremely_elongated_gaussians_stay_well_behaved(gpu):
     """Needles thousands of pixels long and half a pixel wide: their conic is positive definite only by a relative
     1e-6 .. 1e-8 of its entries, less than float32 resolves.  The kernels clamp the exponent at 0 instead of testing its
