@@ -105,9 +105,12 @@ __device__ __forceinline__ bool block_to_tile(int T, int gx, const uint32_t* __r
 // ================================================================================
 // The kernels: one wave per tile, the four strips processed as two PACKED pairs.
 //
-// Both compositing kernels are vector-issue-bound (profiles/pmc_valu.json: K7 runs at ~91 % of the issue rate measured
-// for its instruction mix), so the lever is instruction count.  Non-live lanes are handled by zeroing alpha (an
-// alpha = 0 Gaussian is the identity for every recurrence used here), not by select-updating the state.
+// Both compositing kernels are vector-issue-bound (profiles/pmc_valu.json: the vector ALUs are busy ~88 % of a launch)
+// and, at 6 - 8 waves per SIMD, sensitive to the dependent chain of an instance as well: the levers are instruction
+// count, cheap instruction forms (plain instead of packed where nothing is gained by packing, output modifiers,
+// mask algebra in scalar registers) and as few LDS round trips per instance as possible.  Non-live lanes are handled
+// by zeroing alpha (an alpha = 0 Gaussian is the identity for every recurrence used here), not by select-updating the
+// state.  The ISA of the two inner loops was read after every change (DESIGN.md, K6/K7 ladder).
 // ================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
