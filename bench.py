@@ -405,6 +405,10 @@ def main():
                        "gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H,
                        "schedule": primary, "views_per_step_per_gpu": kk_,
                        "parallelism": f"per-view dp{world}: " + (batched_desc if batched_primary else dropin_desc),
+                       "exchange": (None if world == 1 else
+                                    "direct two-shot all-reduce over peer pointers (hgs_p2p_*, HGS_DP_ALLREDUCE=direct)"
+                                    if os.environ.get("HGS_DP_ALLREDUCE", "") == "direct" else
+                                    f"torch.distributed all-reduce ({dist.get_backend()})"),
                        "scaling_note": "value is the drop-in call shape at N = 1 and the batched data-parallel schedule "
                                        "at N > 1; compare batched.value across N for scaling efficiency",
                        "measurement_order": "the secondary schedule runs before the primary one (chip at its clocks "

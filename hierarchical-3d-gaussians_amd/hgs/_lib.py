@@ -124,7 +124,15 @@ SIGNATURES = {
     "hgs_hier_load": (C.c_int, [C.c_char_p, C.POINTER(HierHost)]),
     "hgs_hier_write": (C.c_int, [C.c_char_p, C.POINTER(HierHost)]),
     "hgs_hier_free": (None, [C.POINTER(HierHost)]),
+    "hgs_p2p_alloc": (C.c_int, [C.c_size_t, C.c_int32, C.POINTER(_P), C.c_int]),
+    "hgs_p2p_free": (C.c_int, [_P, C.c_int]),
+    "hgs_p2p_export": (C.c_int, [_P, C.c_char_p, C.c_int]),
+    "hgs_p2p_open": (C.c_int, [C.c_char_p, C.POINTER(_P), C.c_int]),
+    "hgs_p2p_close": (C.c_int, [_P, C.c_int]),
+    "hgs_p2p_allreduce_sum": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_size_t, C.c_size_t,
+                                        C.c_uint32, _P, C.c_int]),
 }
+P2P_MAX_WORLD, P2P_HANDLE_BYTES, P2P_FLAG_BYTES = 8, 64, 256
 
 _lib = None
 

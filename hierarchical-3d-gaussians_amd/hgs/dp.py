@@ -12,7 +12,7 @@ dominates small messages, so nothing is split into per-tensor all-reduces.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Sequence
+from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -42,15 +42,25 @@ class GradBucket:
     """Flat float32 bucket holding the gradients of every Gaussian parameter tensor, laid out
     tensor after tensor; ``views`` alias it, so filling the views fills the bucket."""
 
-    def __init__(self, shapes: Dict[str, Sequence[int]], device):
+    def __init__(self, shapes: Dict[str, Sequence[int]], device, direct: Optional[bool] = None):
+        """``direct``: exchange through DirectAllReduce (peer pointers) instead of torch.distributed's all-reduce;
+        default from the environment (HGS_DP_ALLREDUCE=direct).  The bucket then lives in exportable memory and every
+        tensor starts on a multiple of 4 floats (the direct kernels move 16 bytes per lane)."""
         self.names: List[str] = [n for n in GRAD_ORDER if n in shapes]
         sizes = [int(torch.Size(shapes[n]).numel()) for n in self.names]
-        self.flat = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        if direct is None:
+            direct = os.environ.get("HGS_DP_ALLREDUCE", "") == "direct"
+        direct = bool(direct) and dist.is_initialized() and dist.get_world_size() > 1
+        pad = (lambda x: (x + 3) // 4 * 4) if direct else (lambda x: x)
+        total = sum(pad(sz) for sz in sizes)
+        self.direct = DirectAllReduce(total, device) if direct else None
+        self.flat = self.direct.flat if direct else torch.zeros(total, dtype=torch.float32, device=device)
+        self._comm = None
         self.views: Dict[str, torch.Tensor] = {}
         off = 0
         for n, sz in zip(self.names, sizes):
             self.views[n] = self.flat[off:off + sz].view(*shapes[n])
-            off += sz
+            off += pad(sz)
 
     def fill(self, grads: Dict[str, torch.Tensor]):
         for n in self.names:
@@ -59,7 +69,10 @@ class GradBucket:
     def all_reduce(self, average: bool = False):
         """SUM over ranks (the gradient of the sum of the per-view losses)."""
         if dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.direct is not None:
+                self.direct.all_reduce()
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             if average:
                 self.flat.div_(dist.get_world_size())
         return self.views
@@ -78,8 +91,122 @@ class GradBucket:
         The collective is ordered after everything enqueued so far on the CURRENT stream and runs next to whatever
         the caller enqueues afterwards; ``handle.wait()`` orders the current stream after it."""
         if dist.is_initialized() and dist.get_world_size() > 1:
+            if self.direct is not None:
+                # the same contract on a communication stream of our own: ordered after the current stream's work,
+                # wait() orders the current stream after the exchange
+                sp = self.span(names)
+                dev = self.flat.device
+                if self._comm is None:
+                    self._comm = torch.cuda.Stream(device=dev)
+                self._comm.wait_stream(torch.cuda.current_stream(dev))
+                self.direct.all_reduce(sp.storage_offset() - self.flat.storage_offset(), sp.numel(), stream=self._comm)
+                ev = torch.cuda.Event()
+                ev.record(self._comm)
+                return _EventHandle(ev, dev)
             return dist.all_reduce(self.span(names), op=dist.ReduceOp.SUM, async_op=True)
         return None
+
+
+class _EventHandle:
+    """What GradBucket.all_reduce_async returns on the direct route: wait() like a torch.distributed work handle."""
+
+    def __init__(self, event, device):
+        self.event, self.device = event, device
+
+    def wait(self):
+        torch.cuda.current_stream(self.device).wait_event(self.event)
+        return True
+
+
+class _DeviceArray:
+    """Raw device memory handed to torch through __cuda_array_interface__ (torch.as_tensor shares it, does not copy)."""
+
+    def __init__(self, ptr: int, numel: int):
+        self.__cuda_array_interface__ = {"shape": (numel,), "typestr": "<f4", "data": (ptr, False), "version": 2,
+                                         "strides": None}
+
+
+class DirectAllReduce:
+    """SUM all-reduce of a flat float32 bucket over PEER POINTERS (include/hgs.h, hgs_p2p_*): every rank reduces one
+    shard of all buckets by reading its peers' memory directly (xGMI is point to point: all seven links of a GPU carry
+    data at once, where a ring all-reduce is bound by one link -- SURVEY.md section 5) and then copies the other
+    shards.  Every rank ends with bit-identical sums (each shard is summed by one rank, in rank order).
+
+    The bucket lives in memory this class allocates (``flat``: a torch tensor over it), because it has to be exported
+    to the other processes; hand it to ``GradBucket(..., flat=...)``.  Control plane: torch.distributed (any backend)
+    for the one-off exchange of the IPC handles.  Opt-in (``HGS_DP_ALLREDUCE=direct``); unmeasured on multi-GPU
+    hardware -- the protocol is exercised by two ranks sharing one GPU (tests/test_dp_direct_gpu.py)."""
+
+    def __init__(self, numel: int, device: torch.device):
+        import ctypes as C
+        from . import _lib
+        if not (dist.is_initialized() and dist.get_world_size() > 1):
+            raise RuntimeError("DirectAllReduce needs an initialised process group with more than one rank")
+        self._lib, self._C = _lib, C
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if self.world > _lib.P2P_MAX_WORLD:
+            raise RuntimeError(f"DirectAllReduce supports up to {_lib.P2P_MAX_WORLD} ranks")
+        self.device = torch.device(device)
+        self.dev_index = self.device.index or 0
+        self.numel = int(numel)
+        padded = (self.numel + 3) // 4 * 4
+        lib = _lib.lib()
+        own_buf, own_flag = C.c_void_p(), C.c_void_p()
+        _lib.check(lib.hgs_p2p_alloc(padded * 4, 0, C.byref(own_buf), self.dev_index), "hgs_p2p_alloc")
+        _lib.check(lib.hgs_p2p_alloc(_lib.P2P_FLAG_BYTES, 1, C.byref(own_flag), self.dev_index), "hgs_p2p_alloc")
+        self._own = (own_buf.value, own_flag.value)
+        hb, hf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES), C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+        _lib.check(lib.hgs_p2p_export(own_buf, hb, self.dev_index), "hgs_p2p_export")
+        _lib.check(lib.hgs_p2p_export(own_flag, hf, self.dev_index), "hgs_p2p_export")
+        handles = [None] * self.world
+        dist.all_gather_object(handles, (hb.raw, hf.raw))
+        self._opened = []
+        bufs, flags = (C.c_void_p * self.world)(), (C.c_void_p * self.world)()
+        for k, (kb, kf) in enumerate(handles):
+            if k == self.rank:
+                bufs[k], flags[k] = own_buf.value, own_flag.value
+                continue
+            pb, pf = C.c_void_p(), C.c_void_p()
+            _lib.check(lib.hgs_p2p_open(kb, C.byref(pb), self.dev_index), "hgs_p2p_open")
+            _lib.check(lib.hgs_p2p_open(kf, C.byref(pf), self.dev_index), "hgs_p2p_open")
+            self._opened += [pb.value, pf.value]
+            bufs[k], flags[k] = pb.value, pf.value
+        self._bufs, self._flags = bufs, flags
+        self.flat = torch.as_tensor(_DeviceArray(own_buf.value, padded), device=self.device)[:self.numel]
+        self._flag_t = torch.as_tensor(_DeviceArray(own_flag.value, _lib.P2P_FLAG_BYTES // 4), device=self.device)
+        self.epoch = 0
+        dist.barrier()          # every rank has opened every handle before anybody starts
+
+    def all_reduce(self, offset: int = 0, numel: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+        """Enqueue the all-reduce of flat[offset : offset + numel] (multiples of 4 floats; the tail of the bucket is
+        padded) on ``stream`` (default: the current one).  Every rank must make the same calls in the same order."""
+        n = self.numel - offset if numel is None else int(numel)
+        if offset % 4:
+            raise ValueError("offset must be a multiple of 4 floats")
+        n = (n + 3) // 4 * 4
+        self.epoch += 1
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        self._lib.check(self._lib.lib().hgs_p2p_allreduce_sum(self.rank, self.world, self._bufs, self._flags, int(offset),
+                                                              n, self.epoch, self._C.c_void_p(st.cuda_stream),
+                                                              self.dev_index), "hgs_p2p_allreduce_sum")
+
+    def check(self):
+        """Raise if a barrier timed out (host sync)."""
+        if int(self._flag_t.view(torch.int32)[3].item()) != 0:
+            raise RuntimeError("direct all-reduce: a peer did not reach a barrier in time")
+
+    def close(self):
+        lib = self._lib.lib()
+        torch.cuda.synchronize(self.device)
+        dist.barrier()          # nobody still reads this rank's memory
+        for ptr in self._opened:
+            lib.hgs_p2p_close(self._C.c_void_p(ptr), self.dev_index)
+        self._opened = []
+        if self._own is not None:
+            self.flat = self._flag_t = None
+            for ptr in self._own:
+                lib.hgs_p2p_free(self._C.c_void_p(ptr), self.dev_index)
+            self._own = None
 
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:

@@ -379,6 +379,34 @@ int hgs_hier_load(const char* path, hgs_hier_host* out); /* allocates; release w
 int hgs_hier_write(const char* path, const hgs_hier_host* in);
 void hgs_hier_free(hgs_hier_host* h);
 
+/* ---------------------------------------------------------------------------
+ * Direct (two-shot) SUM all-reduce over peer pointers: the exchange step of per-view data parallelism (SURVEY.md
+ * section 8(e); the reference itself is single-GPU: train_single.py:57-59 renders one camera per step, nothing to
+ * replace).  One process per GPU; every rank allocates its gradient bucket and a small flag block with hgs_p2p_alloc,
+ * exports both (hipIpc), opens its peers' and then calls hgs_p2p_allreduce_sum: rank r sums shard r of ALL buckets in
+ * rank order (reading the peers' memory over xGMI: all links at once, where a ring is bound by one) and writes it back
+ * into its own bucket, then copies the other ranks' reduced shards from their buckets -- every rank ends with
+ * bit-identical sums.  Three flag barriers per call (release / acquire at system scope, bounded spin: a peer that
+ * never arrives sets the error word instead of hanging the device).  world <= HGS_P2P_MAX_WORLD.
+ * Opt-in (hgs/dp.py: HGS_DP_ALLREDUCE=direct); the default exchange is RCCL's all-reduce through torch.distributed.
+ * ------------------------------------------------------------------------- */
+#define HGS_P2P_MAX_WORLD 8
+#define HGS_P2P_HANDLE_BYTES 64
+#define HGS_P2P_FLAG_BYTES 256   /* size of a rank's flag block: barrier words 0..2, error word 3 */
+/* flags != 0: uncached fine-grained memory for the flag block; else ordinary device memory for the bucket */
+int hgs_p2p_alloc(size_t bytes, int32_t flags, void** ptr, int device);
+int hgs_p2p_free(void* ptr, int device);
+int hgs_p2p_export(void* ptr, uint8_t handle[HGS_P2P_HANDLE_BYTES], int device);
+int hgs_p2p_open(const uint8_t handle[HGS_P2P_HANDLE_BYTES], void** ptr, int device);
+int hgs_p2p_close(void* ptr, int device);
+/* bufs[world] / flag_blocks[world]: device pointers valid in THIS process (own allocation at [rank], opened peers
+ * elsewhere).  Reduces the floats [offset, offset + n) of every bucket; offset and n multiples of 4.  epoch: a counter
+ * that every rank increments by one per call (all ranks must make the same sequence of calls).  Stream-ordered: the
+ * buckets must have been written by work enqueued earlier on `stream`; the result is complete, and the bucket may be
+ * overwritten, after the calls' kernels.  The error word (flag block word 3) is non-zero after a timed-out barrier. */
+int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* const* flag_blocks, size_t offset,
+                          size_t n, uint32_t epoch, hgs_stream_t stream, int device);
+
 #ifdef __cplusplus
 }
 #endif

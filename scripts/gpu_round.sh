@@ -54,4 +54,8 @@ if has dp2; then
   echo "== 2 ranks sharing the one GPU (gloo): bench + DP tests"
   HGS_DP_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 3 --warmup 1 --no-stage-timing --no-secondary > gpurun_out/bench_dp2_gloo.json 2> gpurun_out/bench_dp2.err; echo "dp2 exit $?"; cat gpurun_out/bench_dp2_gloo.json | head -c 600; tail -3 gpurun_out/bench_dp2.err
 fi
+if has dp2; then
+  echo "== same, gradient exchange by the direct peer-pointer all-reduce (hgs_p2p_*)"
+  HGS_DP_BACKEND=gloo HGS_DP_ALLREDUCE=direct timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29612 bench.py --gpus 2 --steps 3 --warmup 1 --no-stage-timing --no-secondary > gpurun_out/bench_dp2_direct.json 2> gpurun_out/bench_dp2_direct.err; echo "dp2 direct exit $?"; cat gpurun_out/bench_dp2_direct.json | head -c 400; tail -2 gpurun_out/bench_dp2_direct.err
+fi
 nproc; free -g | head -2
