@@ -57,9 +57,9 @@ def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
     return {k: v.detach().cpu() for k, v in params.items()}, {k: v.cpu() for k, v in accum.items()}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, route):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), HGS_DP_ALLREDUCE=route)
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "hierarchical-3d-gaussians_amd"))
     sys.path.insert(0, os.path.dirname(HERE))
@@ -73,12 +73,15 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(900)
-def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu):
+@pytest.mark.parametrize("route", ["dist", "direct"])
+def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu, route):
+    """route: the bucket's exchange -- torch.distributed's all-reduce (gloo here, RCCL in production) or the direct
+    peer-pointer all-reduce (hgs_p2p_*, HGS_DP_ALLREDUCE=direct)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, route)) for r in range(world)]
     for p in procs:
         p.start()
     got = {}
