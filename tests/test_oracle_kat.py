@@ -187,3 +187,54 @@ def test_frustum_cull_keeps_gaussians_up_to_the_ewa_clamp():
     assert int(edge.radii[0]) > 0 and edge.binning.num_rendered > 0
     gx = edge.geom.grid[0]
     assert int(edge.geom.rect_max[0, 0]) == gx and int(edge.geom.rect_min[0, 0]) < gx
+
+
+def test_ewa_projection_matches_the_textbook_formulas():
+    """EWA splatting (Zwicker et al.) written out independently of the oracle's code: Sigma = R S S R^T
+    with R from the unit quaternion, view-space mean t = W p + T, J = [[fx/tz, 0, -fx tx/tz^2], [0, fy/tz, -fy ty/tz^2]]
+    with tx/tz, ty/tz clamped to +-1.3 tan(fov/2), Sigma' = J W Sigma W^T J^T + 0.3 I, conic = Sigma'^-1,
+    radius = ceil(3 sqrt(lambda_max)), pixel centre = ((ndc + 1) size - 1) / 2."""
+    rng = np.random.default_rng(5)
+    n = 64
+    ang = 0.3
+    Rc = np.array([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])   # camera-to-world
+    Tc = np.array([0.1, -0.2, 0.3])
+    cam = synth.make_camera(200, 120, R=Rc, T=Tc)
+    p = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(-1.2, 1.2, n), rng.uniform(2.0, 6.0, n)], 1)
+    s = np.exp(rng.uniform(math.log(0.01), math.log(0.3), (n, 3)))
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    geom = ro.geometry_spec(p.astype(np.float32), s.astype(np.float32), q.astype(np.float32), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), 200, 120,
+                            float(np.float32(cam.tanfovx)), float(np.float32(cam.tanfovy)), 1.0)
+    Wm = Rc.T                                                      # world-to-camera rotation
+    fx, fy = 200 / (2 * cam.tanfovx), 120 / (2 * cam.tanfovy)
+    checked = 0
+    for i in range(n):
+        r, x, y, z = q[i]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y)],
+                      [2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x)],
+                      [2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)]])
+        Sigma = R @ np.diag(s[i] ** 2) @ R.T
+        t = Wm @ p[i] + Tc
+        if t[2] <= 0.2:
+            assert not geom.visible[i]
+            continue
+        lx, ly = 1.3 * cam.tanfovx, 1.3 * cam.tanfovy
+        tx = min(lx, max(-lx, t[0] / t[2])) * t[2]
+        ty = min(ly, max(-ly, t[1] / t[2])) * t[2]
+        J = np.array([[fx / t[2], 0, -fx * tx / t[2] ** 2], [0, fy / t[2], -fy * ty / t[2] ** 2]])
+        cov = J @ Wm @ Sigma @ Wm.T @ J.T + 0.3 * np.eye(2)
+        conic = np.linalg.inv(cov)
+        lam = 0.5 * (cov[0, 0] + cov[1, 1]) + math.sqrt(max(0.1, (0.5 * (cov[0, 0] + cov[1, 1])) ** 2 - np.linalg.det(cov)))
+        rad = math.ceil(3 * math.sqrt(lam))
+        px = ((t[0] / t[2] / cam.tanfovx + 1) * 200 - 1) / 2
+        py = ((t[1] / t[2] / cam.tanfovy + 1) * 120 - 1) / 2
+        assert abs(geom.px[i] - px) < 2e-3 and abs(geom.py[i] - py) < 2e-3
+        got = np.array([[geom.conic[i, 0], geom.conic[i, 1]], [geom.conic[i, 1], geom.conic[i, 2]]], dtype=np.float64)
+        assert np.abs(got - conic).max() <= 2e-4 * np.abs(conic).max(), (i, got, conic)
+        assert abs(float(geom.depth[i]) - t[2]) < 1e-5
+        if geom.tiles_touched[i] > 0:
+            assert int(geom.radii[i]) in (rad - 1, rad, rad + 1)   # float32 ceil at an integer boundary may differ by one
+            assert int(geom.radii[i]) == rad or abs(3 * math.sqrt(lam) - round(3 * math.sqrt(lam))) < 1e-3
+            checked += 1
+    assert checked >= 20
