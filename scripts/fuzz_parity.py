@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Soak test (GPU): many random small frames through the HIP op and the float64 oracle -- random Gaussian counts, image
+sizes (not multiples of the tile), fields of view, SH degrees, footprint ranges (sub-pixel to image-filling), opacity
+ranges (up to fully opaque stacks), backgrounds, scale modifiers, with / without the depth channel, SH or precomputed
+colours.  Prints the worst error per quantity and every case above tolerance.
+
+    python scripts/fuzz_parity.py [n_cases] [first_seed]            (test infrastructure: imports oracle/)"""
+import json
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "hierarchical-3d-gaussians_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import parity as pa                      # noqa: E402
+from hgs import synth                    # noqa: E402
+
+TOL = 1e-5
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    dev = torch.device("cuda:0")
+    worst, bad, idx_bad = {}, [], []
+    for c in range(n_cases):
+        rng = np.random.default_rng(seed0 + c)
+        W, H = int(rng.integers(17, 300)), int(rng.integers(17, 200))
+        P = int(rng.choice([1, 7, 64, 300, 1500, 4000]))
+        deg = int(rng.integers(0, 4))
+        fov = float(rng.uniform(25.0, 100.0))
+        s_hi = float(rng.choice([2.0, 6.0, 30.0, 150.0]))
+        s_lo = float(rng.choice([0.05, 0.3, 1.0]))
+        cam = synth.make_camera(W, H, fov)
+        scene = synth.make_scene(P, cam, seed=seed0 + c, sh_degree=deg, s_px=(s_lo, s_hi),
+                                 z_range=(float(rng.uniform(0.15, 2.0)), float(rng.uniform(3.0, 40.0))))
+        if rng.random() < 0.3:
+            scene.opacities[:] = torch.clamp(scene.opacities * 1.6, max=1.0)      # opaque stacks: saturation paths
+        depth = bool(rng.random() < 0.6)
+        sm = float(rng.choice([1.0, 1.0, 0.5, 1.7]))
+        bg = torch.tensor(rng.uniform(0, 1, 3), dtype=torch.float32)
+        gc, gd = synth.upstream_grads(H, W, seed=seed0 + c)
+        kw = dict(scale_modifier=sm, do_depth=depth)
+        if rng.random() < 0.25:
+            kw["colors_precomp"] = torch.tensor(rng.uniform(0, 1, (P, 3)), dtype=torch.float32)
+        oo, og = pa.run_oracle(scene, cam, bg, gc, gd, **kw)
+        hip = pa.run_hip(scene, cam, bg, gc, gd, dev, **kw)
+        mism = pa.check_indices(hip, oo)
+        if any(mism.values()):
+            idx_bad.append((seed0 + c, {k: v for k, v in mism.items() if v}))
+        st = pa.compare(hip, oo, og, do_depth=depth)
+        for k, v in st.items():
+            if isinstance(v, dict):
+                e = max(v["maxrel"], v["l2"]) if v["scale"] > 0 else v["maxrel"]
+                if e > worst.get(k, (0, None))[0]:
+                    worst[k] = (e, seed0 + c)
+                if e > TOL:
+                    bad.append((seed0 + c, k, e, dict(W=W, H=H, P=P, deg=deg, fov=fov, s=(s_lo, s_hi), depth=depth, sm=sm,
+                                                      fragile=st["fragile_frac"])))
+    print(json.dumps({"cases": n_cases, "first_seed": seed0, "tolerance": TOL,
+                      "worst": {k: {"err": v[0], "seed": v[1]} for k, v in worst.items()},
+                      "above_tolerance": bad, "index_mismatches": idx_bad}, default=str))
+    return 1 if bad or idx_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
