@@ -4,7 +4,7 @@ sizes (not multiples of the tile), fields of view, SH degrees, footprint ranges 
 ranges (up to fully opaque stacks), backgrounds, scale modifiers, with / without the depth channel, SH or precomputed
 colours.  Prints the worst error per quantity and every case above tolerance.
 
-    python scripts/fuzz_parity.py [n_cases] [first_seed]            (test infrastructure: imports oracle/)"""
+    python tests/tools/fuzz_parity.py [n_cases] [first_seed]            (test infrastructure: imports oracle/)"""
 import json
 import math
 import os
@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "hierarchical-3d-gaussians_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import parity as pa                      # noqa: E402

@@ -4,7 +4,7 @@
 ANY pixel with alpha >= 1/255, how many 16x8 tile halves (the skip unit of K6 / K7: one packed strip pair), 16x4 strips
 and 8x8 quadrants that is, and how many pixels.  Early termination is ignored (slightly overestimates the live work).
 
-    python scripts/live_stats.py > profiles/r02_live_lane_stats.json
+    python tests/tools/live_stats.py > profiles/r02_live_lane_stats.json
 
 Reading: a live half costs one pass of the packed live path over 128 pixel slots; live pixels / (live halves x 128) is
 the fraction of those slots doing useful work."""
@@ -14,7 +14,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "hierarchical-3d-gaussians_amd")):
     sys.path.insert(0, p)
 from hgs import synth                       # noqa: E402
