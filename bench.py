@@ -25,6 +25,17 @@ backward, preprocess backward) through the C ABI with inputs resident in HBM:
 
 At N = 1 ``value`` is the DROP-IN number and ``batched.value`` the other one; at N > 1 ``value`` == ``batched.value``
 (the data-parallel schedule).  To compute scaling efficiency compare ``batched.value`` across N.
+
+Both schedules cycle through 8 orbit cameras per rank (the instance count L changes from step to step, as in training:
+the speculative single-call forward sizes its workspace from the previous view of the shape; ``capacity_misses``
+counts the calls that overflowed it and were finished on the two-stage path).
+
+At N = 1 the same JSON line carries ``extra``: the other BASELINE.json configurations timed by the same process with
+the same schema (value, ms_per_step, stages_ms, roofline from THAT run's P / V / L):
+  config2_300k            300 k Gaussians at 1080p, the train_single.py call shape (configs[1])
+  heavy_1m                1 M Gaussians with s_px in [1, 8] (SURVEY App. C "heavy": L ~ 4.9 M, ~600 instances per tile)
+  config3_train_post      train_post.py-shaped step on a merged 2-chunk hierarchy (configs[2])
+  config5_50m_4k_render   50 M-node hierarchy, cut + weights + 3840x2160 render per frame as render_hierarchy.py (configs[4])
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -44,6 +55,7 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 DOMINANT = "render_bwd"  # the kernel the roofline object describes (largest share of the frame, profiles/)
+VALU_GUIDE_GINST_S = 256 * 4 * 2.4 / 2.0   # MI355X_MICROARCH.md: a wave64 VALU instruction issues over 2 cycles on a SIMD
 
 
 def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_forward=False):
@@ -129,10 +141,29 @@ def cpu_baseline(scene, cam, bg, gc, gd, L_total, seed=3, n_tiles=1024):
     t_frame = a + b * L_total
     return {"value": 1.0 / t_frame, "unit": "frames/s", "cores": torch.get_num_threads(),
             "host_cores": os.cpu_count(), "kind": "port",
+            "cores_note": "threads capped at 32: the oracle issues thousands of small per-tile tensor operations and "
+                          "torch's intra-op pool turns each into a fork-join over every thread -- on the 256-thread host "
+                          "more threads make it SLOWER (tests/conftest.py measured 8x between 16 and 256 threads)",
             "sample": f"oracle (naive PyTorch-CPU dense per-pixel blend, float32, {torch.get_num_threads()} threads): "
                       f"fwd+bwd of the per-Gaussian stage for the whole scene plus {len(small)} and {len(tiles)} "
                       f"of {T} tiles ({L1} / {L2} of {L_total} tile instances) in {t1:.2f} s / {t2:.2f} s; "
                       f"linear fit {a:.2f} s + {b * 1e6:.3f} us/instance extrapolated to the full frame"}
+
+
+def kernel_source_sha():
+    """Hash of the sources libhgs.so is built from: committed PMC summaries carry the hash of the build they were
+    collected on, and a summary from another build is not mixed into this run's line."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) +
+                   glob.glob(os.path.join(PKG, "csrc", "*.cpp")) + [os.path.join(PKG, "csrc", "Makefile"),
+                                                                    os.path.join(ROOT, "include", "hgs.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _profile_json(name):
@@ -143,6 +174,271 @@ def _profile_json(name):
             return json.load(f), os.path.join("profiles", name)
     except Exception:
         return None, None
+
+
+class DropIn:
+    """The reference's call shape, one view per step: ``GaussianRasterizer(raster_settings)(means3D, means2D, shs,
+    colors_precomp=None, opacities, scales, rotations, cov3D_precomp=None)`` + ``backward`` with fresh ``.grad`` tensors
+    (train_single.py:97,123; gaussian_renderer/__init__.py:105-113), cycling through the given views."""
+
+    def __init__(self, dgr, params, sh_degree, settings_list, gc, gd, dev, dp_bucket=None, do_depth=True):
+        self.params, self.gc, self.gd, self.dev, self.bucket, self.do_depth = params, gc, gd, dev, dp_bucket, do_depth
+        self.rasts = [dgr.GaussianRasterizer(raster_settings=rs) for rs in settings_list]
+        self.P = params["means3D"].shape[0]
+        self.i = 0
+        self.reset_stats()
+
+    def reset_stats(self):
+        self.L_sum, self.n, self.radii = 0, 0, {}
+
+    def step(self):
+        params = self.params
+        for t in params.values():
+            t.grad = None                                       # optimizer.zero_grad(set_to_none=True)
+        j = self.i % len(self.rasts)
+        self.i += 1
+        screenspace_points = torch.zeros(self.P, 3, device=self.dev, requires_grad=True)   # gaussian_renderer/__init__.py:29
+        color, radii, invd = self.rasts[j](means3D=params["means3D"], means2D=screenspace_points, shs=params["shs"],
+                                           colors_precomp=None, opacities=params["opacities"], scales=params["scales"],
+                                           rotations=params["rotations"], cov3D_precomp=None)
+        self.L_sum += color.grad_fn.num_rendered
+        self.n += 1
+        self.radii[j] = radii
+        if self.do_depth:
+            torch.autograd.backward([color, invd], [self.gc, self.gd])   # loss.backward() with dL/dcolor, dL/dinvdepth given
+        else:
+            torch.autograd.backward([color], [self.gc])
+        if self.bucket is not None:
+            self.bucket.fill({kk: v.grad for kk, v in params.items()})
+            self.bucket.all_reduce()
+
+    def mean_L(self):
+        return self.L_sum / max(self.n, 1)
+
+    def mean_V(self):
+        vs = [int((r > 0).sum().item()) for r in self.radii.values()]
+        return sum(vs) / max(len(vs), 1)
+
+
+def _settings(dgr, cam, dev, sh_degree=3, **over):
+    e_i = torch.empty(0, dtype=torch.int32, device=dev)
+    e_f = torch.empty(0, dtype=torch.float32, device=dev)
+    kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
+              bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
+              projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
+              prefiltered=False, debug=False, do_depth=True, render_indices=e_i, parent_indices=e_i,
+              interpolation_weights=e_f, num_node_kids=e_i)
+    kw.update(over)
+    return dgr.GaussianRasterizationSettings(**kw)
+
+
+def extra_dropin(name, scene_cpu, W, H, dev, measure, steps, warmup, what):
+    """One more scene through the drop-in schedule (same call, same 8 cycled cameras, same timing)."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C as dgrC
+    from hgs import synth
+    scene = scene_cpu.to(dev)
+    params = dict(means3D=scene.means3D, shs=scene.shs, opacities=scene.opacities, scales=scene.scales,
+                  rotations=scene.rotations)
+    for t in params.values():
+        t.requires_grad_(True)
+    gc, gd = (t.to(dev) for t in synth.upstream_grads(H, W, seed=1))
+    cams = [synth.orbit_camera(W, H, j, 8, radius=0.05, tilt=0.004) for j in range(8)]
+    d = DropIn(dgr, params, scene.sh_degree, [_settings(dgr, c, dev, scene.sh_degree) for c in cams], gc, gd, dev)
+    miss0 = dgrC.stats["capacity_misses"]
+    elapsed, stages = measure(d.step, steps, warmup, True, reset=d.reset_stats)
+    P, M = scene.P, scene.shs.shape[1]
+    L, V = int(round(d.mean_L())), int(round(d.mean_V()))
+    N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+    sb = survey_bytes(P, V, L, N, T, M)
+    out = {"what": what, "metric": "fwd+bwd frames/s", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "config": {"gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H, "schedule": "dropin",
+                      "capacity_misses": dgrC.stats["capacity_misses"] - miss0},
+           "algorithmic_bytes_per_frame": sum(sb.values()), "stages_ms": stages}
+    if stages.get(DOMINANT):
+        out["roofline"] = roofline_object(sb, stages, DOMINANT, "SURVEY.md §8(d): render_bwd = 24 N + 44 L + 40 V of this run")
+    out["frame_hbm_frac"] = sum(sb.values()) * out["value"] / 1e9 / HBM_PEAK_GBS
+    return out
+
+
+def extra_train_post(dev, measure, steps, warmup, leaves=500_000):
+    """BASELINE configs[2]: a train_post.py-shaped step (train_post.py:66-191) on a merged 2-chunk hierarchy at 1080p:
+    threshold log-uniform in [0.005, 0.1] (:66-74), expand_to_size + get_interpolation_weights (:91-113), render_post
+    with the interpolation done in the op (non-empty render_indices / parent_indices), L1 loss, backward, dense Adam over
+    all hierarchy Gaussians (:37,191)."""
+    import math
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C as dgrC
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    from hgs import hierarchy, synth
+    from hgs.optim import Adam
+    W, H = 1920, 1080
+    cam = synth.make_camera(W, H)
+    full = synth.make_scene(leaves, cam, seed=0)
+    left = full.means3D[:, 0] < 0
+    h = hierarchy.merge_hierarchies([hierarchy.build_hierarchy(
+        synth.Scene(full.means3D[m], full.scales[m], full.rotations[m], full.opacities[m], full.shs[m], 3))
+        for m in (left, ~left)])
+    nodes, boxes = h.nodes.to(dev), h.boxes.to(dev)
+    G = h.xyz.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+    attrs = dict(xyz=h.xyz, shs=h.shs, op=h.alpha.abs().reshape(-1, 1), sc=torch.exp(h.log_scales),
+                 rot=torch.nn.functional.normalize(h.rots))
+    params = {kk: torch.nn.Parameter(v.to(dev).contiguous()) for kk, v in attrs.items()}
+    lrs = dict(xyz=1.6e-5, shs=2.5e-3, op=1e-3, sc=1e-6, rot=1e-5)
+    opt = Adam([dict(params=[params[kk]], lr=lrs[kk], name=kk) for kk in params], lr=0.0, eps=1e-15)
+    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    mfull = torch.zeros(G, 3, device=dev, requires_grad=True)
+    g = torch.Generator().manual_seed(3)
+    vp_gpu, vp_cpu, zero3 = cam.camera_center.to(dev), cam.camera_center.cpu(), torch.zeros(3)
+    st = {"cuts": [], "L": []}
+
+    def step():
+        limit = math.pow(2, torch.rand(1, generator=g).item() * (math.log2(0.1) - math.log2(0.005)) + math.log2(0.005))
+        n = expand_to_size(nodes, boxes, limit, vp_gpu, zero3, ri, pi, ni)
+        get_interpolation_weights(ni[:n], limit, nodes, boxes, vp_cpu, zero3, w, ns)
+        rs = _settings(dgr, cam, dev, do_depth=False, interpolation_weights=w, num_node_kids=ns,
+                       render_indices=ri[:n], parent_indices=pi)
+        color, _, _ = dgr.GaussianRasterizer(rs)(means3D=params["xyz"], means2D=mfull, shs=params["shs"],
+                                                 opacities=params["op"], scales=params["sc"], rotations=params["rot"])
+        st["cuts"].append(n)
+        st["L"].append(color.grad_fn.num_rendered)
+        loss = (color - target).abs().mean()
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step(None)                       # dense, as torch.optim.Adam in train_post.py:191
+
+    miss0 = dgrC.stats["capacity_misses"]
+    elapsed, stages = measure(step, steps, warmup, True, reset=lambda: (st["cuts"].clear(), st["L"].clear()))
+    cuts, Ls = st["cuts"], st["L"]
+    out = {"what": "BASELINE configs[2]: train_post.py-shaped step (log-uniform tau, cut + weights, in-op LOD render at "
+                   "1080p, L1, backward, dense fused Adam) on a merged 2-chunk hierarchy",
+           "metric": "optimiser steps/s", "value": steps / elapsed, "unit": "steps/s", "steps": steps, "warmup": warmup,
+           "ms_per_step": elapsed / steps * 1e3,
+           "config": {"hierarchy_nodes": G, "chunks": 2, "width": W, "height": H, "mean_cut": sum(cuts) / len(cuts),
+                      "min_cut": min(cuts), "max_cut": max(cuts), "mean_tile_instances": sum(Ls) / len(Ls),
+                      "capacity_misses": dgrC.stats["capacity_misses"] - miss0},
+           "stages_ms": stages}
+    if stages.get(DOMINANT):
+        N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        Pm, Lm = int(sum(cuts) / len(cuts)), int(sum(Ls) / len(Ls))
+        out["roofline"] = roofline_object(survey_bytes(Pm, Pm, Lm, N, T, 16), stages, DOMINANT,
+                                          "SURVEY.md §8(d) render_bwd bytes at the mean cut / mean L of the timed steps "
+                                          "(no depth channel: 4 N bytes fewer per image plane are not subtracted)")
+    return out
+
+
+def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
+    """BASELINE configs[4]: a 50 M-node hierarchy (25 M leaves) resident in HBM, per frame what render_hierarchy.py:55-92
+    does: expand_to_size at tau, get_interpolation_weights, render (in-op LOD path) at 3840x2160, forward only."""
+    import diff_gaussian_rasterization as dgr
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    from hgs import _lib, hierarchy, synth
+    W, H = 3840, 2160
+    cam = synth.make_camera(W, H)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    h = hierarchy.build_hierarchy_on_device(leaves, cam, dev, seed=0)
+    torch.cuda.synchronize(); t_build = time.perf_counter() - t0
+    G = h.nodes.shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+    cams = [synth.orbit_camera(W, H, j, 8, radius=0.05, tilt=0.004) for j in range(8)]
+    vps = [(c.camera_center.to(dev), c.camera_center.cpu()) for c in cams]
+    tau = (2 * tau_px + 1) * cam.tanfovx / (0.5 * W)                   # render_hierarchy.py:55-56
+    m2 = torch.zeros(G, 3, device=dev)
+    sc, zero3 = torch.exp(h.log_scales), torch.zeros(3)
+    st = {"i": 0, "n": [], "L": []}
+
+    def frame():
+        j = st["i"] % len(cams); st["i"] += 1
+        n = expand_to_size(h.nodes, h.boxes, tau, vps[j][0], zero3, ri, pi, ni)
+        get_interpolation_weights(ni[:n], tau, h.nodes, h.boxes, vps[j][1], zero3, w, ns)
+        rs = _settings(dgr, cams[j], dev, do_depth=False, interpolation_weights=w, num_node_kids=ns,
+                       render_indices=ri[:n], parent_indices=pi)
+        with torch.no_grad():
+            color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=h.xyz, means2D=m2, shs=h.shs, opacities=h.alpha,
+                                                         scales=sc, rotations=h.rots)
+        st["n"].append(n)
+        st["L"].append(dgr._C.stats["last_L"])
+        return color
+
+    for _ in range(warmup):
+        frame()
+    torch.cuda.synchronize()
+    st["n"].clear(); st["L"].clear()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    _lib.timing_read(reset=True)
+    _lib.timing_enable(True)
+    for _ in range(3):
+        frame()
+    torch.cuda.synchronize()
+    _lib.timing_enable(False)
+    stages = {kk: (ms / max(c, 1)) for kk, (ms, c) in _lib.timing_read(reset=True).items() if c}
+    nm = sum(st["n"][:steps]) / steps
+    out = {"what": "BASELINE configs[4]: 50 M-node hierarchy resident in HBM (no streaming needed at 15 GB of 288 GB), per "
+                   "frame expand_to_size + get_interpolation_weights + 3840x2160 render through the in-op LOD path "
+                   "(forward only), as render_hierarchy.py:55-92",
+           "metric": "rendered frames/s @ 3840x2160", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
+           "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "config": {"hierarchy_nodes": G, "leaves": leaves, "tau_px": tau_px, "mean_cut": nm, "width": W, "height": H,
+                      "hierarchy_build_s": t_build, "resident_bytes": int(G * (59 * 4 + 28 + 32))},
+           "stages_ms": stages}
+    if stages.get("render_fwd") and stages.get("preprocess_fwd"):
+        N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        Pm, Lm = int(nm), int(sum(st["L"][:steps]) / steps)
+        out["config"]["mean_tile_instances"] = Lm
+        # forward-only bytes in the manner of SURVEY §8(d): the in-op LOD preprocess gathers node AND parent rows
+        # (2 x 236 B) plus indices / weight / sibling count (16 B) per cut row; compositing without the depth plane
+        sbk = {"preprocess_fwd": Pm * (2 * 236 + 16) + 4 * Pm + 40 * Pm, "render_fwd": 44 * Lm + 12 * N + 8 * N + 8 * T}
+        dom = max(sbk, key=lambda kk: stages[kk])
+        out["roofline"] = roofline_object(sbk, stages, dom, "forward only: preprocess_fwd = (2 x 236 + 16 + 44) B per cut "
+                                          "row (node + parent rows gathered), render_fwd = 44 L + 20 N + 8 T")
+    return out
+
+
+def run_extras(args, dev, measure):
+    from hgs import synth
+    out = {}
+    wanted = [x for x in args.extras.split(",") if x]
+    W, H = 1920, 1080
+    cam = synth.make_camera(W, H)
+    jobs = {
+        "config2_300k": lambda: extra_dropin("config2_300k", synth.make_scene(300_000, cam, seed=0), W, H, dev, measure, 20, 5,
+                                             "BASELINE configs[1]: ~300 k Gaussians, 1080p, train_single.py fwd+bwd call shape"),
+        "heavy_1m": lambda: extra_dropin("heavy_1m", synth.make_scene(1_000_000, cam, seed=0, s_px=(1.0, 8.0)), W, H, dev,
+                                         measure, 20, 5, "the metric configuration with heavier footprints: 1 M Gaussians, "
+                                         "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
+        "config3_train_post": lambda: extra_train_post(dev, measure, 20, 5),
+        "config5_50m_4k_render": lambda: extra_config5(dev, 10, 3),
+    }
+    for name in wanted:
+        if name not in jobs:
+            continue
+        t0 = time.perf_counter()
+        try:
+            out[name] = jobs[name]()
+        except Exception as e:          # an extra must never take the headline line down with it
+            out[name] = {"error": repr(e)}
+        out[name]["wall_s"] = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+    return out
+
+
+def roofline_object(sb, stages, dom, model_text, extra=None):
+    sec = stages[dom] * 1e-3
+    achieved = sb[dom] / sec / 1e9
+    r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBS, "avg_ms": stages[dom], "algorithmic_bytes": sb[dom], "bytes_model": model_text,
+         "traffic": None}
+    if extra:
+        r.update(extra)
+    return r
 
 
 def main():
@@ -167,6 +463,9 @@ def main():
                     help="batched schedule: per-view SH backward (accumulating) instead of one batched pass per step")
     ap.add_argument("--no-secondary", action="store_true", help="measure only the schedule `value` reports")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the `extra` objects (BASELINE configs 2 / 3 / 5 and the heavy 1 M variant)")
+    ap.add_argument("--extras", default="config2_300k,heavy_1m,config3_train_post,config5_50m_4k_render")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="L",
                     help="internal: time the CPU oracle for a frame with L tile instances, print JSON, exit")
@@ -220,23 +519,12 @@ def main():
         torch.cuda.synchronize()
 
     # ---- DROP-IN schedule: the reference's call, one view per step, one stream ------------------------------------
-    # (N > 1: every rank has its own camera and the step ends with the all-reduce of the .grad tensors' bucket copy)
-    cam_dropin = base_cam if world == 1 else synth.orbit_camera(W, H, rank, world, radius=0.05, tilt=0.004)
-    rast_dropin = dgr.GaussianRasterizer(raster_settings=settings(cam_dropin))
+    # (N > 1: every rank has its own cameras and the step ends with the all-reduce of the .grad tensors' bucket copy)
+    NCAM = 8
+    cams_dropin = [synth.orbit_camera(W, H, rank * NCAM + j, world * NCAM, radius=0.05, tilt=0.004) for j in range(NCAM)]
     dp_bucket = dp.GradBucket({kk: tuple(v.shape) for kk, v in params.items()}, dev) if world > 1 else None
-
-    def step_dropin():
-        for t in params.values():
-            t.grad = None                                       # optimizer.zero_grad(set_to_none=True)
-        screenspace_points = torch.zeros(P, 3, device=dev, requires_grad=True)      # gaussian_renderer/__init__.py:29
-        color, radii, invd = rast_dropin(means3D=params["means3D"], means2D=screenspace_points, shs=params["shs"],
-                                         colors_precomp=None, opacities=params["opacities"], scales=params["scales"],
-                                         rotations=params["rotations"], cov3D_precomp=None)
-        info["L"], info["radii"] = color.grad_fn.num_rendered, radii
-        torch.autograd.backward([color, invd], [gc, gd])       # loss.backward() with dL/dcolor, dL/dinvdepth given
-        if dp_bucket is not None:
-            dp_bucket.fill({kk: v.grad for kk, v in params.items()})
-            dp_bucket.all_reduce()
+    dropin = DropIn(dgr, params, scene.sh_degree, [settings(c) for c in cams_dropin], gc, gd, dev, dp_bucket)
+    step_dropin = dropin.step
 
     # ---- BATCHED schedule: k views per step through a RasterContext ------------------------------------------------
     k = max(1, args.views_per_step)
@@ -318,10 +606,12 @@ def main():
                     work.wait()
         return _OnStream()
 
-    def measure(step, steps, warmup, dominant_timing):
+    def measure(step, steps, warmup, dominant_timing, reset=None):
         for _ in range(warmup):
             step()
         barrier()
+        if reset is not None:
+            reset()                      # per-step statistics (L, visible counts) of the TIMED steps only
         if dominant_timing:
             # inside the timed region only the dominant kernel is bracketed by hipEvents (the roofline figure must
             # come from the timed steps themselves); the other stages are timed in a short extra pass afterwards
@@ -360,7 +650,12 @@ def main():
         is_primary = sched == primary
         if sched == "dropin":
             steps = args.steps if is_primary else max(20, min(args.steps, 40))
-            elapsed, stages = measure(step_dropin, steps, args.warmup if is_primary else 20, timing and is_primary)
+            from diff_gaussian_rasterization import _C as dgrC
+            miss0 = dgrC.stats["capacity_misses"]
+            elapsed, stages = measure(step_dropin, steps, args.warmup if is_primary else 20, timing and is_primary,
+                                      reset=dropin.reset_stats)
+            info["dropin_L"], info["dropin_V"] = dropin.mean_L(), dropin.mean_V()
+            info["dropin_misses"] = dgrC.stats["capacity_misses"] - miss0      # warm-up + timed + stage-timing steps
             views = 1
             for t in params.values():
                 t.grad = None
@@ -375,8 +670,11 @@ def main():
 
     if rank == 0:
         r = res[primary]
-        L = int(info["L"])
-        V = int((info["radii"] > 0).sum().item())
+        if primary == "dropin":
+            L, V = int(round(info["dropin_L"])), int(round(info["dropin_V"]))     # means over the timed steps' views
+        else:
+            L = int(info["L"])
+            V = int((info["radii"] > 0).sum().item())
         N, T, M = W * H, ((W + 15) // 16) * ((H + 15) // 16), scene.shs.shape[1]
         kk_ = r["views_per_step_per_gpu"]
         batched_primary = primary == "batched"
@@ -404,6 +702,9 @@ def main():
                                    f"{W}x{H}, SH degree 3, depth channel on, fwd+bwd through GaussianRasterizer",
                        "gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H,
                        "schedule": primary, "views_per_step_per_gpu": kk_,
+                       "cameras": f"{NCAM if primary == 'dropin' else k} orbit cameras per rank, cycled "
+                                  "(visible / tile_instances = mean over the timed steps)",
+                       "capacity_misses": info.get("dropin_misses") if primary == "dropin" else None,
                        "parallelism": f"per-view dp{world}: " + (batched_desc if batched_primary else dropin_desc),
                        "exchange": (None if world == 1 else
                                     "direct two-shot all-reduce over peer pointers (hgs_p2p_*, HGS_DP_ALLREDUCE=direct)"
@@ -423,45 +724,61 @@ def main():
                             "steps": rr["steps"], "ms_per_step": rr["ms_per_step"],
                             "schedule": batched_desc if name == "batched" else dropin_desc}
         stages = r["stages"]
+        src_sha = kernel_source_sha()
+        result["kernel_source_sha"] = src_sha
         if stages:
             dom = DOMINANT if DOMINANT in stages else max(stages, key=stages.get)
             sec = stages[dom] * 1e-3
-            achieved = sb[dom] / sec / 1e9
             traffic_db, traffic_path = _profile_json("pmc_traffic.json")
-            traffic = (traffic_db or {}).get(dom)
-            result["roofline"] = {
-                "bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "avg_ms": stages[dom], "algorithmic_bytes": sb[dom],
-                "bytes_model": "SURVEY.md §8(d): render_bwd = 24 N + 44 L + 40 V (N pixels, L tile instances, V visible "
-                               "Gaussians of THIS run); avg_ms = hipEvents around every launch inside the timed steps",
-                "traffic": traffic,
-                "traffic_source": (f"{traffic_path}['{dom}'] (run id {(traffic_db or {}).get('_run', 'unknown')}): "
-                                   "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, "
-                                   "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction) -- a committed "
-                                   "profile, NOT measured in this run") if traffic else None,
-                "impl_bytes": ab[dom], "impl_achieved": ab[dom] / sec / 1e9, "impl_frac": ab[dom] / sec / 1e9 / HBM_PEAK_GBS,
-                "impl_bytes_model": "this implementation's own traffic model (64-byte record, 48-byte per-instance scratch)",
-                "note": "compositing kernels are VALU-issue-bound (gather/blend, no MFMA); the HBM fraction is reported "
-                        "because the metric mandates it"}
-            # The compositing kernels are VALU-issue-bound: add the vector-ALU view next to the mandated HBM one.
             valu_db, valu_path = _profile_json("pmc_valu.json")
+            # committed PMC summaries are used only if they were collected on THIS build of the kernels
+            if traffic_db is not None and traffic_db.get("_src_sha") != src_sha:
+                stale_t, traffic_db = traffic_db.get("_run", "unknown"), None
+            else:
+                stale_t = None
+            if valu_db is not None and valu_db.get("_src_sha") != src_sha:
+                valu_db = None
+            traffic = (traffic_db or {}).get(dom)
+            result["roofline"] = roofline_object(
+                sb, stages, dom,
+                "SURVEY.md §8(d): render_bwd = 24 N + 44 L + 40 V (N pixels, L tile instances, V visible Gaussians: means "
+                "over the views of THIS run); avg_ms = hipEvents around every launch inside the timed steps",
+                {"traffic": traffic,
+                 "traffic_source": (f"{traffic_path}['{dom}'] (run id {traffic_db.get('_run', 'unknown')}, kernel sources "
+                                    f"{src_sha} = this build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                    "command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction) -- a "
+                                    "committed profile, NOT measured in this run") if traffic else
+                                   (f"dropped: profiles/pmc_traffic.json (run {stale_t}) was collected on another "
+                                    "build of the kernels" if stale_t else None),
+                 "impl_bytes": ab[dom], "impl_achieved": ab[dom] / sec / 1e9,
+                 "impl_frac": ab[dom] / sec / 1e9 / HBM_PEAK_GBS,
+                 "impl_bytes_model": "this implementation's own traffic model (record and per-instance scratch as laid out in HBM)",
+                 "note": "compositing kernels are VALU-issue-bound (gather/blend, no MFMA); the HBM fraction is "
+                         "reported because the metric mandates it"})
+            # The compositing kernels are VALU-issue-bound: add the vector-ALU view next to the mandated HBM one.
             pv = (valu_db or {}).get(dom)
             if pv:
-                peak = (valu_db.get("_peak_ginst_s") or 614.4) * 1e9
+                mix = (valu_db.get("_peak_ginst_s") or 614.4) * 1e9
                 rate = pv["valu_insts_per_launch"] / sec
                 result["roofline"]["valu"] = {
                     "insts_per_launch": pv["valu_insts_per_launch"], "achieved_ginst_s": rate / 1e9,
-                    "peak_ginst_s": peak / 1e9, "frac": rate / peak,
+                    # two roofs, so that neither can be misread: the guide's issue rate for plain wave64 VALU
+                    # instructions (one per 2 cycles per SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 2) and the measured rate
+                    # of THIS kernel's instruction mix (packed / compare / transcendental instructions issue slower)
+                    "peak_guide_ginst_s": VALU_GUIDE_GINST_S, "frac_of_guide_peak": rate / 1e9 / VALU_GUIDE_GINST_S,
+                    "peak_mix_ginst_s": mix / 1e9, "frac_of_mix_peak": rate / mix,
                     # SQ_ACTIVE_INST_VALU (quad-cycles the vector ALU was executing, per wave) x waves over the
                     # SIMD-cycles the launch lasted at the nominal 2.4 GHz: how busy the vector ALUs were
                     "alu_busy_frac": (pv["valu_active_quadcycles_per_wave"] * 4.0 * pv["waves"] / 1024.0) / (sec * 2.4e9)
                     if "valu_active_quadcycles_per_wave" in pv else None,
-                    "source": f"{valu_path} (run id {valu_db.get('_run', 'unknown')}): SQ_INSTS_VALU per launch from a "
-                              "committed rocprofv3 --pmc pass of this command (NOT measured in this run); time from this "
-                              "run; peak_ginst_s = " + str(valu_db.get("_peak_source", "256 CUs x 4 SIMDs x 2.4 GHz / 4 "
-                              "cycles per wave64 VALU instruction (assumed)"))}
+                    "source": f"{valu_path} (run id {valu_db.get('_run', 'unknown')}, kernel sources {src_sha} = this "
+                              "build): SQ_INSTS_VALU per launch from a committed rocprofv3 --pmc pass of this command "
+                              "(NOT measured in this run); time from this run; peak_mix_ginst_s = " +
+                              str(valu_db.get("_peak_source", "assumed"))}
             result["stages_ms"] = stages
             result["stages_gbs"] = {s_: sb[s_] / (v * 1e-3) / 1e9 for s_, v in stages.items() if s_ in sb}
+        if world == 1 and not args.no_extras:
+            result["extra"] = run_extras(args, dev, measure)
         if world == 1 and not args.no_cpu_baseline:
             # separate process + hard time limit: the baseline must never take the GPU number down with it
             import subprocess

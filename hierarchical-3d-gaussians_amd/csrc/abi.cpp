@@ -50,31 +50,38 @@ static thread_local char g_err[512] = "";
 // copy has run, which would defeat enqueue-ahead in hgs_raster_fwd) and ONE reusable event.  Both are released by a
 // pthread key destructor when the thread ends (autograd worker threads come and go); a thread that is still alive
 // at process exit leaves them to the driver's teardown, which is the only safe order.
+constexpr int kMaxDevices = 16;
 struct ThreadHost {
   uint32_t* pinned_L = nullptr;
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev[kMaxDevices] = {};     // one per device: an event is recorded on streams of the device it was created on
 };
 static pthread_key_t g_host_key;
 static pthread_once_t g_host_once = PTHREAD_ONCE_INIT;
 static void thread_host_free(void* p) {
   ThreadHost* h = static_cast<ThreadHost*>(p);
   if (!h) return;
-  if (h->ev) (void)hipEventDestroy(h->ev);
+  for (hipEvent_t e : h->ev)
+    if (e) (void)hipEventDestroy(e);
   if (h->pinned_L) (void)hipHostFree(h->pinned_L);
   delete h;
 }
 static void thread_host_key_init() { (void)pthread_key_create(&g_host_key, thread_host_free); }
-static ThreadHost* thread_host() {
+// call after hipSetDevice(device): the event of that device is created on first use
+static ThreadHost* thread_host(int device) {
+  if (device < 0 || device >= kMaxDevices) return nullptr;
   (void)pthread_once(&g_host_once, thread_host_key_init);
   ThreadHost* h = static_cast<ThreadHost*>(pthread_getspecific(g_host_key));
   if (!h) {
     h = new ThreadHost();
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->pinned_L), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->pinned_L), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
       thread_host_free(h);
       return nullptr;
     }
     (void)pthread_setspecific(g_host_key, h);
+  }
+  if (!h->ev[device] && hipEventCreateWithFlags(&h->ev[device], hipEventDisableTiming) != hipSuccess) {
+    h->ev[device] = nullptr;
+    return nullptr;
   }
   return h;
 }
@@ -272,14 +279,15 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   const uint32_t* L_dev = g.block_sums + nblk;
-  ThreadHost* th = thread_host();
-  if (!th) { set_error("cannot allocate pinned host memory / event"); return HGS_ERR_NOMEM; }
+  ThreadHost* th = thread_host(device);
+  if (!th) { set_error("cannot allocate pinned host memory / event (device %d)", device); return HGS_ERR_NOMEM; }
+  hipEvent_t ev = th->ev[device];
   uint32_t* stage = th->pinned_L;
   HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  hipError_t e = hipEventRecord(th->ev, s);
+  hipError_t e = hipEventRecord(ev, s);
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
   if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);
-  if (e == hipSuccess) e = hipEventSynchronize(th->ev);
+  if (e == hipSuccess) e = hipEventSynchronize(ev);
   if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
   *L_out_host = *stage;
   if (rc) return rc;

@@ -67,6 +67,9 @@ class _Call:
 # (hgs_raster_fwd).  A render at another resolution (the viewer's, train_single.py:76-78) has its own entry.
 _last_L = {}
 SPECULATIVE = True
+SPEC_GROWTH = 1.25       # speculative instance capacity = SPEC_GROWTH * (previous L of this shape) + SPEC_SLACK
+SPEC_SLACK = 65536
+stats = {"speculative_calls": 0, "capacity_misses": 0, "last_L": 0}     # counters (bench.py reports them)
 
 
 def _build_args(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
@@ -188,7 +191,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     prev = _last_L.get(shape_key) if SPECULATIVE else None
     if prev is not None and P > 0:
         # no-bubble path: everything is enqueued before the host learns L
-        L_ws = int(prev * 1.25) + 65536
+        L_ws = int(prev * SPEC_GROWTH) + SPEC_SLACK
+        stats["speculative_calls"] += 1
         _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
         binb = torch.empty(sz[1].value, **u8)
         if prepare_backward:
@@ -199,6 +203,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                                 _stream(dev), devi)
         if rc == _lib.ERR_CAPACITY:
             binb = scratch = None   # the scene grew by more than 25 %: finish on the exact two-stage path
+            stats["capacity_misses"] += 1
             a.bwd_ws_prezero = None
         else:
             _lib.check(rc, "hgs_raster_fwd")
@@ -219,6 +224,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _last_L.clear()
     # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
     _last_L[shape_key] = L.value if lod is None else max(L.value, int(0.9 * (prev or 0)))
+    stats["last_L"] = L.value
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev

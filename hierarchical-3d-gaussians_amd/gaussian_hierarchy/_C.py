@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -31,7 +32,9 @@ def _stream(dev):
 
 
 # (nodes ptr, boxes ptr, N, nodes version, boxes version) -> do the boxes nest?  (view independent: checked once per
-# hierarchy; an in-place edit of either tensor bumps its version and triggers a re-check)
+# hierarchy; an in-place edit of either tensor bumps its version and triggers a re-check).  An entry lives only as
+# long as BOTH tensor objects it was computed for: the caching allocator hands freed addresses to new tensors, whose
+# version counters start at 0 again, so a key must never outlive its tensors (a finalizer on each evicts it).
 _nested_cache = {}
 
 
@@ -48,6 +51,8 @@ def _boxes_nested(nodes, boxes) -> bool:
         if len(_nested_cache) > 16:
             _nested_cache.clear()
         hit = _nested_cache[key] = bool(out.value)
+        for t in (nodes, boxes):
+            weakref.finalize(t, _nested_cache.pop, key, None)
     return hit
 
 

@@ -12,6 +12,7 @@ dominates small messages, so nothing is split into per-tensor all-reduces.
 from __future__ import annotations
 
 import os
+import sys
 from typing import Dict, List, Optional, Sequence
 
 import torch
@@ -53,9 +54,21 @@ class GradBucket:
         direct = bool(direct) and dist.is_initialized() and dist.get_world_size() > 1
         pad = (lambda x: (x + 3) // 4 * 4) if direct else (lambda x: x)
         total = sum(pad(sz) for sz in sizes)
-        self.direct = DirectAllReduce(total, device) if direct else None
-        self.flat = self.direct.flat if direct else torch.zeros(total, dtype=torch.float32, device=device)
+        self.direct = None
+        if direct:
+            try:
+                self.direct = DirectAllReduce(total, device)
+            except DirectRouteUnavailable as e:
+                # every rank takes this branch together (DirectAllReduce agrees on the outcome collectively): the
+                # exchange falls back to torch.distributed's all-reduce (RCCL) instead of taking the job down
+                if dist.get_rank() == 0:
+                    print(f"[hgs.dp] direct peer-pointer all-reduce unavailable, using torch.distributed "
+                          f"({dist.get_backend()}) instead: {e}", file=sys.stderr, flush=True)
+        self.flat = self.direct.flat if self.direct is not None else torch.zeros(total, dtype=torch.float32, device=device)
         self._comm = None
+        self._calls = 0
+        self._verify_left = int(os.environ.get("HGS_P2P_VERIFY", "0") or 0) if self.direct is not None else 0
+        self._check_every = max(1, int(os.environ.get("HGS_P2P_CHECK_EVERY", "16") or 16))
         self.views: Dict[str, torch.Tensor] = {}
         off = 0
         for n, sz in zip(self.names, sizes):
@@ -70,12 +83,47 @@ class GradBucket:
         """SUM over ranks (the gradient of the sum of the per-view losses)."""
         if dist.is_initialized() and dist.get_world_size() > 1:
             if self.direct is not None:
+                ref = self._verify_begin(self.flat)
                 self.direct.all_reduce()
+                self._verify_end(ref, self.flat)
+                self.check_direct()
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             if average:
                 self.flat.div_(dist.get_world_size())
         return self.views
+
+    # ---- safety net of the direct route ---------------------------------------------------------------------------
+    def check_direct(self, force: bool = False):
+        """A barrier timeout of the direct route is fatal (csrc/p2p.hip poisons the bucket with NaN on the device);
+        this turns it into an exception on the host.  It costs a host sync, so it runs every HGS_P2P_CHECK_EVERY-th
+        exchange (default 16) unless ``force``."""
+        if self.direct is None:
+            return
+        self._calls += 1
+        if force or self._calls % self._check_every == 0:
+            self.direct.check()
+
+    def _verify_begin(self, span):
+        """HGS_P2P_VERIFY=N: the first N exchanges of the direct route are recomputed by torch.distributed's
+        all-reduce from a copy of the inputs and compared -- the self-check for the first run on real xGMI."""
+        if self._verify_left <= 0:
+            return None
+        ref = span.clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.SUM)
+        return ref
+
+    def _verify_end(self, ref, span):
+        if ref is None:
+            return
+        self._verify_left -= 1
+        torch.cuda.synchronize(span.device)
+        self.direct.check()
+        scale = float(ref.abs().max())
+        err = float((span - ref).abs().max()) if bool(torch.isfinite(span).all()) else float("inf")
+        if not err <= 1e-5 * max(scale, 1e-30):      # summation orders differ (rank order here, ring order in RCCL)
+            raise RuntimeError(f"direct all-reduce disagrees with torch.distributed: max |diff| {err:.3e} at scale "
+                               f"{scale:.3e} (HGS_P2P_VERIFY); do not use HGS_DP_ALLREDUCE=direct on this system")
 
     def span(self, names: Sequence[str]) -> torch.Tensor:
         """The contiguous slice of ``flat`` that holds the given tensors (they must be adjacent in the bucket)."""
@@ -98,8 +146,10 @@ class GradBucket:
                 dev = self.flat.device
                 if self._comm is None:
                     self._comm = torch.cuda.Stream(device=dev)
+                ref = self._verify_begin(sp)
                 self._comm.wait_stream(torch.cuda.current_stream(dev))
                 self.direct.all_reduce(sp.storage_offset() - self.flat.storage_offset(), sp.numel(), stream=self._comm)
+                self._verify_end(ref, sp)
                 ev = torch.cuda.Event()
                 ev.record(self._comm)
                 return _EventHandle(ev, dev)
@@ -116,6 +166,11 @@ class _EventHandle:
     def wait(self):
         torch.cuda.current_stream(self.device).wait_event(self.event)
         return True
+
+
+class DirectRouteUnavailable(RuntimeError):
+    """The peer-pointer route cannot be set up on this system (hipIpc refused, a peer could not be opened, ...).
+    Raised by EVERY rank of the job together, so that all of them can fall back to torch.distributed."""
 
 
 class _DeviceArray:
@@ -152,25 +207,48 @@ class DirectAllReduce:
         padded = (self.numel + 3) // 4 * 4
         lib = _lib.lib()
         own_buf, own_flag = C.c_void_p(), C.c_void_p()
-        _lib.check(lib.hgs_p2p_alloc(padded * 4, 0, C.byref(own_buf), self.dev_index), "hgs_p2p_alloc")
-        _lib.check(lib.hgs_p2p_alloc(_lib.P2P_FLAG_BYTES, 1, C.byref(own_flag), self.dev_index), "hgs_p2p_alloc")
-        self._own = (own_buf.value, own_flag.value)
-        hb, hf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES), C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
-        _lib.check(lib.hgs_p2p_export(own_buf, hb, self.dev_index), "hgs_p2p_export")
-        _lib.check(lib.hgs_p2p_export(own_flag, hf, self.dev_index), "hgs_p2p_export")
+        fine = 2 if os.environ.get("HGS_P2P_FINEGRAINED", "") == "1" else 0
+        self._own, self._opened = None, []
+        # Every step that can fail for ONE rank only (allocation, hipIpc export, opening a peer) is followed by an
+        # exchange of the outcome, so that all ranks raise DirectRouteUnavailable together instead of one raising
+        # while the others wait in a collective.
+        mine, err = None, None
+        try:
+            if os.environ.get("HGS_P2P_INJECT_FAILURE", "") == str(self.rank):     # tests: one rank cannot export
+                raise RuntimeError("injected failure (HGS_P2P_INJECT_FAILURE)")
+            _lib.check(lib.hgs_p2p_alloc(padded * 4, fine, C.byref(own_buf), self.dev_index), "hgs_p2p_alloc")
+            _lib.check(lib.hgs_p2p_alloc(_lib.P2P_FLAG_BYTES, 1, C.byref(own_flag), self.dev_index), "hgs_p2p_alloc")
+            self._own = (own_buf.value, own_flag.value)
+            hb, hf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES), C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
+            _lib.check(lib.hgs_p2p_export(own_buf, hb, self.dev_index), "hgs_p2p_export")
+            _lib.check(lib.hgs_p2p_export(own_flag, hf, self.dev_index), "hgs_p2p_export")
+            mine = (hb.raw, hf.raw)
+        except RuntimeError as e:
+            err = f"rank {self.rank}: {e}"
         handles = [None] * self.world
-        dist.all_gather_object(handles, (hb.raw, hf.raw))
-        self._opened = []
+        dist.all_gather_object(handles, (mine, err))
+        failed = [e for _, e in handles if e]
         bufs, flags = (C.c_void_p * self.world)(), (C.c_void_p * self.world)()
-        for k, (kb, kf) in enumerate(handles):
-            if k == self.rank:
-                bufs[k], flags[k] = own_buf.value, own_flag.value
-                continue
-            pb, pf = C.c_void_p(), C.c_void_p()
-            _lib.check(lib.hgs_p2p_open(kb, C.byref(pb), self.dev_index), "hgs_p2p_open")
-            _lib.check(lib.hgs_p2p_open(kf, C.byref(pf), self.dev_index), "hgs_p2p_open")
-            self._opened += [pb.value, pf.value]
-            bufs[k], flags[k] = pb.value, pf.value
+        if not failed:
+            try:
+                for k, ((kb, kf), _) in enumerate(handles):
+                    if k == self.rank:
+                        bufs[k], flags[k] = own_buf.value, own_flag.value
+                        continue
+                    pb, pf = C.c_void_p(), C.c_void_p()
+                    _lib.check(lib.hgs_p2p_open(kb, C.byref(pb), self.dev_index), "hgs_p2p_open")
+                    self._opened.append(pb.value)
+                    _lib.check(lib.hgs_p2p_open(kf, C.byref(pf), self.dev_index), "hgs_p2p_open")
+                    self._opened.append(pf.value)
+                    bufs[k], flags[k] = pb.value, pf.value
+            except RuntimeError as e:
+                err = f"rank {self.rank}: {e}"
+            outcomes = [None] * self.world
+            dist.all_gather_object(outcomes, err)
+            failed = [e for e in outcomes if e]
+        if failed:
+            self._release()
+            raise DirectRouteUnavailable("; ".join(failed))
         self._bufs, self._flags = bufs, flags
         self.flat = torch.as_tensor(_DeviceArray(own_buf.value, padded), device=self.device)[:self.numel]
         self._flag_t = torch.as_tensor(_DeviceArray(own_flag.value, _lib.P2P_FLAG_BYTES // 4), device=self.device)
@@ -191,22 +269,28 @@ class DirectAllReduce:
                                                               self.dev_index), "hgs_p2p_allreduce_sum")
 
     def check(self):
-        """Raise if a barrier timed out (host sync)."""
+        """Raise if a barrier timed out (host sync).  The error word is sticky and the device side has already
+        replaced this rank's sums by NaN (csrc/p2p.hip): the step that timed out can not have been applied silently."""
         if int(self._flag_t.view(torch.int32)[3].item()) != 0:
-            raise RuntimeError("direct all-reduce: a peer did not reach a barrier in time")
+            raise RuntimeError("direct all-reduce: a peer did not reach a barrier within HGS_P2P_TIMEOUT_S; the "
+                               "gradient bucket of this step holds NaN -- the job must stop")
 
-    def close(self):
+    def _release(self):
         lib = self._lib.lib()
-        torch.cuda.synchronize(self.device)
-        dist.barrier()          # nobody still reads this rank's memory
         for ptr in self._opened:
             lib.hgs_p2p_close(self._C.c_void_p(ptr), self.dev_index)
         self._opened = []
         if self._own is not None:
             self.flat = self._flag_t = None
             for ptr in self._own:
-                lib.hgs_p2p_free(self._C.c_void_p(ptr), self.dev_index)
+                if ptr:
+                    lib.hgs_p2p_free(self._C.c_void_p(ptr), self.dev_index)
             self._own = None
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        dist.barrier()          # nobody still reads this rank's memory
+        self._release()
 
 
 def shard_views(num_views: int, rank: int, world: int) -> List[int]:
@@ -318,6 +402,11 @@ class DataParallelStep:
         """End of the step.  ``sh_backward``: optional callable that issues the batched SH backward of the step's
         views (it completes the means3D / shs gradients); the first all-reduce overlaps with it."""
         with self._on_backward_stream():
+            if self._views == 0:
+                # a rank that rendered no view this step (fewer views than ranks, or the uneven last round of
+                # shard_views) still holds the previous step's REDUCED gradients: it must contribute zeros
+                self.bucket.flat.zero_()
+                self.means2D_grad.zero_()
             early = self.bucket.all_reduce_async(self.EARLY)     # ordered after the last view's backward
             if sh_backward is not None:
                 sh_backward()
@@ -331,4 +420,5 @@ class DataParallelStep:
                 late.wait()
             self.optimizer.step_masked(mask, params=[self.params[k] for k in self.LATE])
         self.context.wait_backward_stream()
+        self.bucket.check_direct()      # direct route: a barrier timeout is fatal (periodic host check; NaN on device)
         return self._views

@@ -138,6 +138,27 @@ def make_scene(P, cam: Camera, seed=0, sh_degree=3, s_px=(0.5, 4.0), z_range=(2.
                  opac.contiguous(), shs.contiguous(), sh_degree)
 
 
+def make_scene_trained_like(P, cam: Camera, seed=0, sh_degree=3, median_px=2.0, sigma=1.0, max_px=100.0, aniso=0.05,
+                            z_range=(2.0, 20.0)) -> Scene:
+    """A footprint distribution closer to an optimised scene than the §8(d) benchmark spec: screen-space sigma
+    log-normal (median ``median_px``, log-sigma ``sigma``, clipped at ``max_px``: a few Gaussians cover hundreds of
+    tiles), one principal axis at that size and the other two log-uniform in [aniso, 1] of it (needles and discs),
+    opacities biased towards the ends of (0, 1).  Everything else as make_scene."""
+    base = make_scene(P, cam, seed=seed, sh_degree=sh_degree, z_range=z_range)
+    g = torch.Generator().manual_seed(seed + 7919)
+    U = lambda *s: torch.rand(*s, generator=g)
+    wv = cam.world_view_transform.double()
+    z = (torch.cat([base.means3D.double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ wv)[:, 2].float()
+    fx = cam.image_width / (2.0 * cam.tanfovx)
+    spx = torch.exp(math.log(median_px) + sigma * torch.randn(P, generator=g)).clamp(0.3, max_px)
+    ratios = torch.exp(U(P, 3) * math.log(aniso))
+    ratios[torch.arange(P), torch.randint(0, 3, (P,), generator=g)] = 1.0
+    scales = (z * spx / fx)[:, None] * ratios
+    u = U(P)
+    opac = (0.02 + 0.97 * (0.5 - 0.5 * torch.cos(math.pi * u)))[:, None]      # mass near 0 and 1
+    return Scene(base.means3D, scales.contiguous(), base.rotations, opac.contiguous(), base.shs, sh_degree)
+
+
 def upstream_grads(H, W, seed=1):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)

@@ -393,7 +393,10 @@ void hgs_hier_free(hgs_hier_host* h);
 #define HGS_P2P_MAX_WORLD 8
 #define HGS_P2P_HANDLE_BYTES 64
 #define HGS_P2P_FLAG_BYTES 256   /* size of a rank's flag block: barrier words 0..2, error word 3 */
-/* flags != 0: uncached fine-grained memory for the flag block; else ordinary device memory for the bucket */
+/* flags: bit 0 = uncached memory (the flag block); bit 1 = fine-grained device memory (a bucket that must be coherent
+ * across devices INSIDE a kernel; the protocol below only hands buckets over at kernel boundaries and uses ordinary
+ * memory, flags = 0); a barrier that waits longer than HGS_P2P_TIMEOUT_S (default 60) sets the sticky error word and
+ * makes the rank's reduce / gather write NaN (csrc/p2p.hip) */
 int hgs_p2p_alloc(size_t bytes, int32_t flags, void** ptr, int device);
 int hgs_p2p_free(void* ptr, int device);
 int hgs_p2p_export(void* ptr, uint8_t handle[HGS_P2P_HANDLE_BYTES], int device);

@@ -28,8 +28,8 @@ fi
 if has prof; then
   echo "== rocprofv3 kernel trace: drop-in schedule, then batched schedule"
   cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_dropin -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-stage-timing --no-secondary --schedule dropin > $R/gpurun_out/rocprof_dropin.log 2>&1; echo "rocprof dropin exit $?"
-  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_batched -o r -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-stage-timing --no-secondary --schedule batched > $R/gpurun_out/rocprof_batched.log 2>&1; echo "rocprof batched exit $?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_dropin -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --schedule dropin > $R/gpurun_out/rocprof_dropin.log 2>&1; echo "rocprof dropin exit $?"
+  timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_batched -o r -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --schedule batched > $R/gpurun_out/rocprof_batched.log 2>&1; echo "rocprof batched exit $?"
   cd $R
   python scripts/rocprof_summary.py $(ls gpurun_out/prof_dropin/*.db | head -1) > gpurun_out/kernel_stats_dropin.txt 2>/dev/null; head -22 gpurun_out/kernel_stats_dropin.txt
   python scripts/rocprof_summary.py $(ls gpurun_out/prof_batched/*.db | head -1) > gpurun_out/kernel_stats_batched.txt 2>/dev/null
@@ -37,7 +37,7 @@ fi
 if has pmc; then
   echo "== PMC passes (drop-in schedule)"
   cd /tmp
-  B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-stage-timing --no-secondary --schedule dropin"
+  B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --schedule dropin"
   timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $R/gpurun_out/pmc_SQ -o pmc -- $B > $R/gpurun_out/pmc_SQ.log 2>&1; echo "pmc SQ exit $?"
   timeout 600 rocprofv3 --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM SQ_BUSY_CYCLES --kernel-trace -d $R/gpurun_out/pmc_SQ2 -o pmc -- $B > $R/gpurun_out/pmc_SQ2.log 2>&1; echo "pmc SQ2 exit $?"
   for c in FETCH_SIZE WRITE_SIZE; do

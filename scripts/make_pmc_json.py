@@ -28,8 +28,12 @@ PER_FRAME = {}   # launches per frame of one kernel symbol when it is not 1
 def main():
     d = json.load(open(sys.argv[1]))
     run = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
-    traffic, valu = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT)}, {"_run": run,
-                                                                                   "_source": os.path.relpath(sys.argv[1], ROOT)}
+    sys.path.insert(0, ROOT)
+    import bench                      # kernel_source_sha(): bench.py only uses a summary collected on the build it runs
+    sha = d.get("_src_sha") or bench.kernel_source_sha()
+    head = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT), "_src_sha": sha}
+    traffic, valu = dict(head), dict(head)
+    d = {k: v for k, v in d.items() if not k.startswith("_")}
     for stage, pats in STAGES.items():
         tot = 0.0
         for p in pats:      # template variants of one kernel (accumulate on / off ...) are averaged, not added

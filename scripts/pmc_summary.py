@@ -31,6 +31,13 @@ def main():
         for k, cs in load(path).items():
             short = k.replace("_ZN3hgs12_GLOBAL__N_1", "hgs::").split("E15hgs")[0][:60]
             res[short].update(cs)
+    try:        # the build these counters were collected on (bench.py refuses summaries from another build)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        res["_src_sha"] = bench.kernel_source_sha()
+    except Exception:
+        pass
     print(json.dumps(res, indent=1, sort_keys=True))
 
 

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2",
-           "--gaussians", "30000", "--width", "640", "--height", "368", "--no-cpu-baseline"]
+           "--gaussians", "30000", "--width", "640", "--height", "368", "--no-cpu-baseline", "--extras", "config2_300k"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -33,3 +33,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["avg_ms"] * 1e-3) / 1e9) <= 1e-6 * rf["achieved"]
     assert d["batched"]["value"] > 0 and d["dropin"]["value"] == d["value"]
+    assert d["config"]["capacity_misses"] == 0 and len(d["kernel_source_sha"]) == 16
+    ex = d["extra"]["config2_300k"]                 # the other BASELINE configurations ride in the same line
+    assert "error" not in ex, ex
+    for k in ("value", "unit", "ms_per_step", "stages_ms", "roofline", "config"):
+        assert k in ex, k
+    assert ex["config"]["gaussians"] == 300_000 and ex["config"]["tile_instances"] > 500_000
+    assert abs(ex["roofline"]["frac"] - ex["roofline"]["achieved"] / 8000.0) < 1e-12

@@ -28,9 +28,9 @@ def _data(rank, n, epoch):
     return torch.randn(n, generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, extra_env=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port))
+                      MASTER_PORT=str(port), **(extra_env or {}))
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "hierarchical-3d-gaussians_amd"))
     sys.path.insert(0, os.path.dirname(HERE))
     from hgs import dp
@@ -74,12 +74,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 3])
-def test_direct_all_reduce_between_processes_sharing_the_gpu(gpu, world):
+@pytest.mark.parametrize("world,env", [(2, None), (3, None), (8, {"HGS_P2P_VERIFY": "2"}), (2, {"HGS_P2P_FINEGRAINED": "1"})])
+def test_direct_all_reduce_between_processes_sharing_the_gpu(gpu, world, env):
+    """world 8: the shard arithmetic of a full node (HGS_P2P_MAX_WORLD), with the HGS_P2P_VERIFY self-check armed for
+    the GradBucket exchanges; the last case allocates the buckets fine-grained."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, env)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -108,3 +110,38 @@ def test_direct_all_reduce_between_processes_sharing_the_gpu(gpu, world):
             assert np.array_equal(v, res[0]["bucket_direct"][k])
             ref = res[r]["bucket_dist"][k]
             assert np.abs(v - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), k
+
+
+def _fallback_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), HGS_P2P_INJECT_FAILURE="1")
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "hierarchical-3d-gaussians_amd"))
+    from hgs import dp
+    dp.init_from_env(backend="gloo")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    shapes = dict(means3D=(257, 3), opacities=(257, 1))
+    b = dp.GradBucket(shapes, dev, direct=True)          # rank 1 cannot export: EVERY rank falls back, nobody hangs
+    b.fill({k: torch.full(s, float(rank + 1), device=dev) for k, s in shapes.items()})
+    b.all_reduce()
+    torch.cuda.synchronize()
+    q.put((rank, b.direct is None, float(b.flat.min()), float(b.flat.max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_direct_route_falls_back_collectively_when_one_rank_cannot_export(gpu):
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=250) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, fell_back, lo, hi in res:
+        assert fell_back and lo == hi == 6.0, (rank, fell_back, lo, hi)

@@ -31,13 +31,13 @@ class _Ctx:           # what DataParallelStep needs of a RasterContext when the 
         pass
 
 
-def _run_steps(rank, world, n_steps, views_per_rank):
+def _run_steps(rank, world, n_steps, views_per_rank, n_views=None):
     sys.path.insert(0, HERE)
     import dp_common as dc
     import parity as pa
     from hgs import dp
     torch.set_num_threads(1)
-    n_views = world * views_per_rank
+    n_views = world * views_per_rank if n_views is None else n_views
     scene, cams, targets = dc.scene_and_cams(n_views)
     params = {k: getattr(scene, k).clone() for k in dc.NAMES}
     opt = dc.OracleAdam([dict(params=[params[k]], lr=dc.LRS[k]) for k in dc.NAMES])
@@ -65,13 +65,13 @@ def _upstream(target):
     return target[0] - 0.5, target[1] - 0.15
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_views=None):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, HERE)
     from hgs import dp
     dp.init_from_env(backend="gloo")
-    params, accum = _run_steps(rank, world, 2, 2)
+    params, accum = _run_steps(rank, world, 2, 2, n_views=n_views)
     # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
     q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
@@ -109,3 +109,34 @@ def test_dp_step_ranks_agree_and_match_one_process():
     for k, v in ref_accum.items():
         assert torch.equal(got[0][1][k], got[1][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
     assert float(ref_accum["denom"].max()) == 8.0 and float(ref_accum["denom"][hidden].max()) == 0.0
+
+
+@pytest.mark.timeout(600)
+def test_rank_without_a_view_contributes_zeros():
+    """Fewer views than ranks (shard_views hands rank 2 nothing): the idle rank still holds the previous step's REDUCED
+    gradients in its bucket -- it must contribute zeros, not those (DataParallelStep.finish).  2 views per step on 3
+    ranks for 2 steps = one process rendering the same 2 views per step."""
+    world, n_views = 3, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_views)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, params, accum = q.get(timeout=500)
+        got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ref_params, ref_accum = _run_steps(0, 1, 2, n_views)
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    for k in dc.NAMES:
+        for r in (1, 2):
+            assert torch.equal(got[0][0][k], got[r][0][k]), f"{k}: ranks diverged"
+        scale = float(ref_params[k].abs().max())
+        assert float((got[0][0][k] - ref_params[k]).abs().max()) <= 1e-6 * scale, k
+    for k, v in ref_accum.items():
+        assert torch.equal(got[0][1][k], got[2][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k

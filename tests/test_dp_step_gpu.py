@@ -57,7 +57,7 @@ def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
     return {k: v.detach().cpu() for k, v in params.items()}, {k: v.cpu() for k, v in accum.items()}
 
 
-def _worker(rank, world, port, q, route):
+def _worker(rank, world, port, q, route, views_per_rank=2):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HGS_DP_ALLREDUCE=route)
     sys.path.insert(0, HERE)
@@ -65,7 +65,7 @@ def _worker(rank, world, port, q, route):
     sys.path.insert(0, os.path.dirname(HERE))
     from hgs import dp
     dp.init_from_env(backend="gloo")
-    params, accum = _run_steps(rank, world, 3, 2)
+    params, accum = _run_steps(rank, world, 3, views_per_rank)
     # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
     q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
@@ -109,3 +109,35 @@ def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu, route):
         assert torch.equal(got[0][1][k], got[1][1][k]), k
         assert torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
     assert float(ref_accum["denom"].max()) == 12.0 and float(ref_accum["denom"][hidden].max()) == 0.0
+
+
+@pytest.mark.timeout(900)
+def test_eight_ranks_on_one_gpu_direct_route(gpu):
+    """The shape of a full node: 8 ranks (sharing the one GPU here), one view per rank per step, gradient exchange by
+    the direct peer-pointer all-reduce.  All ranks bit-identical after 3 steps and equal to one process accumulating
+    the 8 views itself."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "direct", 1)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, params, accum = q.get(timeout=800)
+        got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    ref_params, ref_accum = _run_steps(0, 1, 3, 8)
+    for k in dc.NAMES:
+        for r in range(1, world):
+            assert torch.equal(got[0][0][k], got[r][0][k]), f"{k}: rank {r} diverged"
+        scale = float(ref_params[k].abs().max())
+        err = float((got[0][0][k] - ref_params[k]).abs().max())
+        assert err <= 2e-6 * scale, (k, err, scale)
+    for k, v in ref_accum.items():
+        assert torch.equal(got[0][1][k], got[7][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k

@@ -22,10 +22,8 @@ from hgs import synth                    # noqa: E402
 TOL = 1e-5
 
 
-def main():
-    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-    dev = torch.device("cuda:0")
+def run_cases(n_cases, seed0, dev):
+    """Returns the report dict ({"worst": ..., "above_tolerance": [...], "index_mismatches": [...]})."""
     worst, bad, idx_bad = {}, [], []
     for c in range(n_cases):
         rng = np.random.default_rng(seed0 + c)
@@ -61,10 +59,17 @@ def main():
                 if e > TOL:
                     bad.append((seed0 + c, k, e, dict(W=W, H=H, P=P, deg=deg, fov=fov, s=(s_lo, s_hi), depth=depth, sm=sm,
                                                       fragile=st["fragile_frac"])))
-    print(json.dumps({"cases": n_cases, "first_seed": seed0, "tolerance": TOL,
-                      "worst": {k: {"err": v[0], "seed": v[1]} for k, v in worst.items()},
-                      "above_tolerance": bad, "index_mismatches": idx_bad}, default=str))
-    return 1 if bad or idx_bad else 0
+    return {"cases": n_cases, "first_seed": seed0, "tolerance": TOL,
+            "worst": {k: {"err": v[0], "seed": v[1]} for k, v in worst.items()},
+            "above_tolerance": bad, "index_mismatches": idx_bad}
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rep = run_cases(n_cases, seed0, torch.device("cuda:0"))
+    print(json.dumps(rep, default=str))
+    return 1 if rep["above_tolerance"] or rep["index_mismatches"] else 0
 
 
 if __name__ == "__main__":
