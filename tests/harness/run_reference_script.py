@@ -1,7 +1,12 @@
 """Launch one of the reference's entry scripts (train_single.py, train_post.py, render_hierarchy.py ...) UNMODIFIED as
 ``__main__`` on a machine without a GPU:
 
-    python tests/harness/run_reference_script.py train_single.py -s <scene> --model_path <out> --iterations 5 ...
+    python tests/harness/run_reference_script.py [--backend cpu|hip] train_single.py -s <scene> --model_path <out> ...
+
+``--backend hip`` (wherever a GPU AND a reference checkout exist; HGS_REFERENCE names the checkout): the scripts meet
+the REAL packages -- libhgs.so's HIP kernels through diff_gaussian_rasterization / gaussian_hierarchy._C /
+simple_knn._C, real ``torch.cuda`` -- and only ``sys.path`` is arranged.  ``--backend cpu`` (default, the build
+container):
 
 What this launcher adds around the script, and nothing else:
   * ``sys.path``: the reference checkout, this repository's drop-in packages (diff_gaussian_rasterization,
@@ -57,9 +62,24 @@ class _Event:
 
 
 def main():
+    backend = "cpu"
+    if len(sys.argv) > 2 and sys.argv[1] == "--backend":
+        backend = sys.argv[2]
+        del sys.argv[1:3]
+    if backend not in ("cpu", "hip"):
+        raise SystemExit("--backend must be cpu or hip")
     script = sys.argv[1]
     sys.path[:0] = [REF, os.path.join(ROOT, "tests", "shims"), os.path.join(ROOT, "hierarchical-3d-gaussians_amd"), ROOT,
                     os.path.join(ROOT, "tests")]
+    sys.argv = [os.path.join(REF, script)] + sys.argv[2:]
+    if backend == "hip":
+        # the acceptance sentence of BASELINE.json's north_star, literally: the unmodified script on the HIP op
+        if not torch.cuda.is_available():
+            raise SystemExit("--backend hip needs a GPU")
+        from hgs import _lib
+        _lib.lib()                                  # fail loudly if libhgs.so is absent: there is no fallback
+        runpy.run_path(os.path.join(REF, script), run_name="__main__")
+        return
     from harness import cpu_backends
     cpu_backends.install()
     torch.cuda.Event = _Event
@@ -67,7 +87,6 @@ def main():
     torch.cuda.empty_cache = lambda: None
     torch.cuda.set_device = lambda *a, **k: None
     torch.cuda.synchronize = lambda *a, **k: None
-    sys.argv = [os.path.join(REF, script)] + sys.argv[2:]
     with CudaToCpu():
         runpy.run_path(os.path.join(REF, script), run_name="__main__")
 

@@ -8,6 +8,11 @@ pixels and gradients'):
     L2 error <= REL_TOL, oracle in float64.  Pixels where the oracle reports a discrete blend
     decision within 1e-5 (relative) of its threshold ("fragile": alpha vs 1/255, T vs 1e-4)
     are excluded from the pixel comparison; their count is bounded by FRAGILE_FRAC.
+    The same pixels are excluded from the LOSS whose gradients are compared (``run_oracle`` zeroes the upstream
+    gradient there and hands the mask to the ``run_hip`` call that follows): a float32 and a float64 evaluation of
+    ``T (1 - alpha) < 1e-4`` legitimately disagree on a knife edge -- e.g. two stacked Gaussians capped at alpha = 0.99
+    give T = 9.99998e-5 in float32 (stop, as the float32 reference lineage does) and 1.0000000000000002e-4 in float64
+    (continue) -- and one such pixel changes a covering Gaussian's gradient by percents (found by fuzz seed 1002).
 """
 import numpy as np
 import torch
@@ -17,6 +22,7 @@ from oracle import raster_oracle as ro
 
 REL_TOL = 1e-5
 FRAGILE_FRAC = 1e-3
+_PAIRED = {}     # fragile-pixel mask of the last run_oracle, consumed by the next run_hip of the same image size
 
 
 def settings_kwargs(cam, bg, sh_degree, do_depth=True, debug=False, scale_modifier=1.0, device="cpu",
@@ -33,7 +39,7 @@ def settings_kwargs(cam, bg, sh_degree, do_depth=True, debug=False, scale_modifi
 
 
 def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
-               interpolation_weights=None, num_node_kids=None, do_depth=True, dtype=torch.float64):
+               interpolation_weights=None, num_node_kids=None, do_depth=True, dtype=torch.float64, mask_fragile=True):
     req = lambda t: None if t is None else t.clone().requires_grad_(True)
     m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
     sh = req(scene.shs) if colors_precomp is None else None
@@ -47,9 +53,15 @@ def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=Non
                        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform,
                        projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree, campos=cam.camera_center,
                        interpolation_weights=interpolation_weights, num_node_kids=num_node_kids, dtype=dtype)
-    loss = (out.color * gc.to(dtype)).sum()
+    # see the module docstring: undecidable pixels leave the loss
+    ok = torch.from_numpy(~out.fragile) if mask_fragile else torch.ones(out.fragile.shape, dtype=torch.bool)
+    out.grad_mask = ok
+    _PAIRED.clear()
+    if not bool(ok.all()):
+        _PAIRED[tuple(ok.shape)] = ok
+    loss = (out.color * (gc * ok).to(dtype)).sum()
     if do_depth:
-        loss = loss + (out.invdepth * gd.to(dtype)).sum()
+        loss = loss + (out.invdepth * (gd * ok).to(dtype)).sum()
     loss.backward()
     grads = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad)
     if sh is not None: grads["shs"] = sh.grad
@@ -60,8 +72,14 @@ def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=Non
 
 
 def run_hip(scene, cam, bg, gc, gd, device, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
-            interpolation_weights=None, num_node_kids=None, do_depth=True, debug=True):
+            interpolation_weights=None, num_node_kids=None, do_depth=True, debug=True, grad_mask="paired"):
+    """``grad_mask``: [H,W] bool mask applied to the upstream gradients; "paired" (default) = the fragile-pixel mask of
+    the ``run_oracle`` call that preceded this one (same image size; used once), None = no mask."""
     import diff_gaussian_rasterization as dgr
+    if isinstance(grad_mask, str):
+        grad_mask = _PAIRED.pop(tuple(gc.shape[-2:]), None)
+    if grad_mask is not None:
+        gc, gd = gc * grad_mask, gd * grad_mask
     req = lambda t: None if t is None else t.clone().to(device).requires_grad_(True)
     m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
     sh = req(scene.shs) if colors_precomp is None else None

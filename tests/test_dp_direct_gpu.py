@@ -125,7 +125,8 @@ def _fallback_worker(rank, world, port, q):
     b.fill({k: torch.full(s, float(rank + 1), device=dev) for k, s in shapes.items()})
     b.all_reduce()
     torch.cuda.synchronize()
-    q.put((rank, b.direct is None, float(b.flat.min()), float(b.flat.max())))
+    vals = torch.cat([v.reshape(-1) for v in b.views.values()])      # (the padding between the tensors stays 0)
+    q.put((rank, b.direct is None, float(vals.min()), float(vals.max())))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -100,9 +100,10 @@ def test_capacity_miss_retry_matches_oracle(gpu, monkeypatch):
 
 
 def test_capacity_miss_on_the_lod_shape_key(gpu, monkeypatch):
-    """In-op LOD path (shape key = the hierarchy, not the cut): a coarse cut followed by a fine one of the same
-    hierarchy overflows the speculative capacity; the retried render must equal the non-speculative one bit for bit,
-    forward and backward."""
+    """In-op LOD path (shape key = the hierarchy, not the cut): a fine cut (many small Gaussians, few tiles each)
+    followed by a coarse one of the same hierarchy (few nodes, each covering many tiles: 3.6 x the instances here)
+    overflows the speculative capacity; the retried render must equal the non-speculative one bit for bit, forward
+    and backward."""
     import diff_gaussian_rasterization as dgr
     from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
     from hgs import hierarchy
@@ -135,17 +136,17 @@ def test_capacity_miss_on_the_lod_shape_key(gpu, monkeypatch):
         return n, num, c.detach(), radii, {k: v.grad for k, v in L.items()}, m2.grad
 
     C._last_L.clear()
-    n_coarse, L_coarse, *_ = render(40.0)
+    n_fine, L_fine, *_ = render(0.0)
     misses0 = C.stats["capacity_misses"]
-    n_fine, L_fine, c1, r1, g1, m1 = render(0.0)
-    assert n_fine > 2 * n_coarse and L_fine > int(L_coarse * C.SPEC_GROWTH) + 64, (n_coarse, n_fine, L_coarse, L_fine)
+    n_coarse, L_coarse, c1, r1, g1, m1 = render(40.0)
+    assert n_fine > 2 * n_coarse and L_coarse > int(L_fine * C.SPEC_GROWTH) + 64, (n_coarse, n_fine, L_coarse, L_fine)
     assert C.stats["capacity_misses"] == misses0 + 1
     C.SPECULATIVE = False
     try:
-        _, L_ref, c2, r2, g2, m2 = render(0.0)
+        _, L_ref, c2, r2, g2, m2 = render(40.0)
     finally:
         C.SPECULATIVE = True
-    assert L_ref == L_fine and torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(m1, m2)
+    assert L_ref == L_coarse and torch.equal(c1, c2) and torch.equal(r1, r2) and torch.equal(m1, m2)
     for k in g1:
         assert torch.equal(g1[k], g2[k]), k
 

@@ -69,7 +69,7 @@ def check_raster_oracle(G, what):
         kw = dict(interpolation_weights=torch.from_numpy(G["interpolation_weights"]),
                   num_node_kids=torch.from_numpy(G["num_node_kids"]))
     oo, og = pa.run_oracle(scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]),
-                           do_depth=bool(G["do_depth"]), **kw)
+                           do_depth=bool(G["do_depth"]), mask_fragile=False, **kw)   # the golden's loss covers every pixel
     _compare_raster(oo.color.detach().numpy(), oo.radii.numpy(), oo.invdepth.detach().numpy(),
                     {k: v.numpy() for k, v in og.items()}, G, f"oracle, {what}")
 
@@ -82,7 +82,7 @@ def check_raster_hip(G, what, gpu):
         kw = dict(interpolation_weights=torch.from_numpy(G["interpolation_weights"]),
                   num_node_kids=torch.from_numpy(G["num_node_kids"]))
     hip = pa.run_hip(scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]), gpu,
-                     do_depth=bool(G["do_depth"]), **kw)
+                     do_depth=bool(G["do_depth"]), grad_mask=None, **kw)
     _compare_raster(hip["color"].numpy(), hip["radii"].numpy(), hip["invdepth"].numpy(),
                     {k: v.numpy() for k, v in hip["grads"].items()}, G, f"HIP, {what}")
 
