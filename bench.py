@@ -62,7 +62,7 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_f
     """SURVEY.md §8(d) byte model, per stage, for the measured P (Gaussians), V (visible), L (tile
     instances), N (pixels), T (tiles), M (SH coefficients).  Each boundary tensor is counted once
     read / once written; irreducible intermediates once written + once read; the sort as one pass."""
-    rec, inst = 64, 48
+    rec, inst = 64, 40
     ch = 4 if depth else 3
     b = {}
     b["preprocess_fwd"] = P * 44 + V * 12 * M + 4 * P + V * (rec + 12) + 8 * P
@@ -72,10 +72,9 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_f
     b["tile_depth_sort"] = 8 * T + 4 * L + 4 * L + 4 * L   # ids in, depth gather, ids out
     b["tile_ranges"] = 0                         # ranges come out of the tile binning (radix fallback only)
     b["render_fwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N + 8 * N
-    b["memset_bwd"] = inst * L
     b["render_bwd"] = 8 * T + 4 * L + rec * L + 4 * ch * N * 2 + inst * L
     b["preprocess_bwd"] = inst * L + P * 44 + V * 12 * M + 12 * P + P * (56 + 12 * M)
-    b["memset_bwd"] = 0                          # the forward's compositing kernel clears the scratch on the side
+    b["memset_bwd"] = 0                          # no clearing: the backward's compositing kernel writes every record
     if deferred_sh:
         # per view: geometry chain only (SH neither read nor written); per STEP: one pass over the coefficients
         b["preprocess_bwd"] = inst * L + P * 44 + 12 * P + P * 56 + 12 * P

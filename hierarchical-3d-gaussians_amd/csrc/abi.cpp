@@ -239,9 +239,7 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
   }
   if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
   if ((rc = launch_tile_order(b, T, s, a->debug))) return rc;     // ~3 us; counted with the compositing stage it serves
-  float* zero_ws = static_cast<float*>(a->bwd_ws_prezero);
-  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, zero_ws,
-                                                       zero_ws ? (size_t)L * kInstStride : 0, s));
+  return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
 }
 
 int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L,
@@ -324,11 +322,7 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
   const ImgWs im = ImgWs::carve_from(const_cast<void*>(img_ws), a->width, a->height);
   float* inst = static_cast<float*>(bwd_ws);
   float* drgb = bwd_ws_drgb(bwd_ws, L);
-  if (L > 0) {
-    if (a->bwd_ws_prezero != bwd_ws) {   // else: zero-filled by the forward's compositing kernel
-      StageTimer _t(ST_MEMSET_BWD, s);
-      HGS_HIP(hipMemsetAsync(inst, 0, (size_t)L * kInstStride * sizeof(float), s));
-    }
+  if (L > 0) {     // (the instance scratch needs no clearing: K7 writes every record, sums or zeros)
     if ((rc = HGS_TIMED(ST_RENDER_BWD, s, launch_render_bwd(*a, g, b, im, out_color, out_invdepth, dL_dcolor, dL_dinvdepth, inst, s)))) return rc;
   }
   hgs_raster_grads gr = *grads;

@@ -101,9 +101,8 @@ int launch_tile_order(const BinWs& b, int32_t T, hipStream_t s, bool debug);
 // fill_tile_ids: also write every instance's tile id into b.keys_out (the tile-binning path does not produce it)
 int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L, int32_t T,
                            bool fill_tile_ids, hipStream_t s);
-// zero_ws / zero_floats: optional buffer the kernel zero-fills on the side (hgs_raster_args.bwd_ws_prezero)
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
-                      float* out_color, float* out_invdepth, float* zero_ws, size_t zero_floats, hipStream_t s);
+                      float* out_color, float* out_invdepth, hipStream_t s);
 int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);

@@ -577,12 +577,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     double s[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) s[i] = 0.0;
-    const float4* ip = reinterpret_cast<const float4*>(inst) + (size_t)g.offsets[idx] * 3;
+    static_assert(kInstStride == 10, "instance record = the ten sums, 40 bytes");
+    const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
     for (uint32_t k = 0; k < n; ++k) {
-      const float4 v0 = ip[k * 3 + 0], v1 = ip[k * 3 + 1], v2 = ip[k * 3 + 2];
-      s[0] += v0.x; s[1] += v0.y; s[2] += v0.z; s[3] += v0.w;
-      s[4] += v1.x; s[5] += v1.y; s[6] += v1.z; s[7] += v1.w;
-      s[8] += v2.x; s[9] += v2.y;
+      const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
+      s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+      s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
+      s[8] += v4.x; s[9] += v4.y;
     }
     sums5 = (float)s[5]; sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----

@@ -5,20 +5,23 @@
 // backward entered from train_single.py:123 / train_post.py:142).
 //
 // CDNA4 design (not the CUDA 256-threads-one-pixel-each shape):
-//  * a 16x16 tile is cut into four 16x4 STRIPS; a lane owns four pixels (same x, y = y0 + 4*s) and ONE WAVE RENDERS
-//    A WHOLE TILE: the per-Gaussian record is read from LDS once per tile, no workgroup barrier is needed, and the
-//    backward's cross-lane reduction runs once per (tile, Gaussian).  Measured 0.53 / 0.37 / 0.35 ms forward for
-//    4 / 2 / 1 waves per tile before anything else was tuned (round 1).
-//  * the two strips of a PAIR (rows 0-7 resp. 8-15 of the tile) go through one instruction stream as float2 values;
-//    compares, selects, min / max, exp and rcp have no packed form and are halved by that (packed FMAs themselves cost
-//    as much as two plain ones on this chip: scripts/microbench/valu_issue.hip).
-//  * who is visited: K1 stores, per Gaussian, the half extents of the box around its alpha >= 1/255 region; the lane
-//    that stages a Gaussian into LDS tests that box against the tile's two halves, two ballots turn the answers
-//    into 64-bit masks in scalar registers, and the loop walks their set bits.  A Gaussian whose box misses the tile
-//    costs no vector instruction, one that reaches a single half never computes the other half's exponents.
-//  * inside a visited half: alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity).  If no pixel of the half is above
-//    that threshold (minus a 1e-3 guard band) the half is left after 5 vector instructions, before the exp; the exact
-//    alpha test still takes every borderline decision, so results do not depend on either pre-test.
+//  * ONE WAVE RENDERS A WHOLE 16x16 TILE and every lane owns four pixels -- no workgroup barrier, no inter-wave
+//    accumulation.
+//  * QUADRANT STREAMS (round 3).  A tile instance of the benchmark scene touches ~25 of the tile's 256 pixels; walking the
+//    tile's list wave-uniformly (rounds 1-2: every visited instance costs a pass over a 16x8 half = 128 pixel slots)
+//    leaves four lanes in five idle.  Here the four DPP ROWS of the wave (16 lanes each) own the four 8x8 QUADRANTS of
+//    the tile and each row walks ITS OWN list: the lane that stages an instance of the 64-instance batch tests K1's
+//    alpha >= 1/255 box against the four quadrants, four ballots give four 64-bit masks, and every set bit is filed --
+//    by its rank inside its mask -- into that quadrant's list in LDS.  An iteration of the inner loop then serves up
+//    to FOUR DIFFERENT (instance, quadrant) pairs at once: every row fetches the record of its own next instance
+//    (ds_read with a row-dependent address) and the same instruction stream composites it into the row's 64 pixels.
+//    Nothing is wave-uniform any more, so nothing diverges; a batch costs max(list lengths) iterations instead of one
+//    pass per (instance, half) -- 0.40 iterations per former half-visit on the benchmark scene, 0.43 on the heavy one
+//    (tests/tools/quad_stats.py).
+//  * a lane's four pixels share x (rows y0, y0+2, y0+4, y0+6 of its quadrant) and go through the instruction stream as
+//    two PACKED pairs (float2): compares, selects, min / max, exp and rcp have no packed form and are halved by that.
+//  * alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity): the per-lane candidate predicate; when no lane of the wave
+//    has a candidate the iteration ends before the exp.  The exact alpha test still takes every borderline decision.
 //  * pixel coordinates are TILE-RELATIVE: the record carries the pixel centre as hi + lo floats from K1's
 //    double-precision projection; (hi - tile_origin) + lo is exact to ~1e-6 px at any resolution.
 //  * a finished / outside pixel is moved to y = 1e18 (never a candidate again): "done" needs no flag.
@@ -27,10 +30,17 @@
 //        dL/dalpha_i = (q_i - A_i) T_i - T_final (dL/dC . bg) / (1 - alpha_i),   q = dL/dC . c + dL/dD / z
 //    (every term relatively accurate; a front-to-back variant using V - prefix was measured 10-80x
 //    less accurate on pixels with capped alphas and was dropped).
-//  * the 10 per-(tile,Gaussian) partial sums are reduced over the 4 strips in registers, over the
-//    wave with permlane swaps + bank-masked DPP adds (three registers of row partials share one reduction), and ten
-//    lanes store the instance record to its EMISSION slot with one instruction; K8 sums each Gaussian's
-//    contiguous run.  No LDS accumulator, no atomics of any kind, bit-reproducible.
+//  * the ten per-(instance, quadrant) sums are reduced INSIDE THE ROW -- the natural domain of DPP: 21 bank-masked DPP adds
+//    reduce all ten values of all four rows (four different instances) at once (rounds 1-2: ~30 instructions of
+//    permlane swaps + DPP per instance) -- and added to the instance's accumulator row in LDS (ds_add_f32, ten lanes
+//    per row: an instance seen by several quadrants is combined there, in an order-independent way).  At the end of a
+//    batch lane i stores the accumulator of instance i to its EMISSION slot (40 bytes); instances the tile never
+//    reaches store zeros, so the scratch needs no zero fill by anybody.  K8 sums each Gaussian's contiguous run.  No
+//    global atomics; bit-reproducible.
+//  * the record of the NEXT iteration is requested before the current one is composited (two iterations per trip of the
+//    loop): a row's record address depends on a list entry that is itself in LDS, and at 4 waves per SIMD two dependent
+//    LDS round trips per iteration are not hidden by the other waves (K7 0.426 -> 0.385 ms; with the pixels' colour
+//    gradients in registers instead of LDS 0.339).
 #include "common.h"
 
 namespace hgs {
@@ -40,46 +50,25 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kAlphaMax = 0.99f;
 constexpr float kTEps = 0.0001f;
 constexpr float kBig = 1.0e18f;   // y coordinate of a finished / outside pixel: its power is -inf-ish, never a candidate
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-// sum over each row of 16 lanes; every lane of the row ends with the row total
-__device__ __forceinline__ float row_sum16(float v) {
-  v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(v);   // row_half_mirror
-  v += dpp_mov<0x140>(v);   // row_mirror
-  return v;
-}
-// Three registers of 16-lane partial sums (every row of 16 lanes = one value) -> ONE register in which every quad of
-// a row holds a total: lanes 0-3 = sum of a's row, lanes 8-11 = b's, lanes 4-7 of rows 1 / 3 = c's summed over the row
-// PAIR (0,1) / (2,3).  The row is halved with bank-masked DPP adds that write their results next to each other
-// instead of into separate registers: 8 DPP adds where three full row reductions and the row-pair add take 13.
-// (s_nop: a DPP operand must not be read within two instructions of the vector instruction that wrote it, and the
-// compiler does not see into the asm block.)
-__device__ __forceinline__ float row_sum16_x3(float a, float b, float c) {
-  float ab, abc, c1;
-  asm("s_nop 1\n\t"
-      "v_add_f32_dpp %2, %5, %5 row_mirror row_mask:0xf bank_mask:0xf\n\t"        // c1: lanes i, 15-i = c[i] + c[15-i]
-      "v_add_f32_dpp %0, %3, %3 row_mirror row_mask:0xf bank_mask:0x3\n\t"        // lanes 0-7 : a[i] + a[15-i]
-      "v_add_f32_dpp %0, %4, %4 row_mirror row_mask:0xf bank_mask:0xc\n\t"        // lanes 8-15: b[i] + b[15-i]
-      "s_nop 0\n\t"
-      "v_add_f32_dpp %1, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"   // lanes 4-7, 12-15: c, four partials
-      "v_add_f32_dpp %1, %0, %0 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"   // lanes 0-3: a, lanes 8-11: b
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-      "s_nop 1\n\t"
-      // c's values (s8 / s9) occupy two rows each (0,1 / 2,3): lane 15 of rows 0 / 2 (a copy of c's row total) is
-      // added into the c quad (lanes 4-7) of rows 1 / 3
-      "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0x2"
-      : "=&v"(ab), "=&v"(abc), "=&v"(c1)
-      : "v"(a), "v"(b), "v"(c));
-  return abc;
-}
+#ifndef HGS_K6_BATCH
+#define HGS_K6_BATCH 64
+#endif
+#ifndef HGS_K7_BATCH
+#define HGS_K7_BATCH 64
+#endif
+#ifndef HGS_K6_PREFETCH
+#define HGS_K6_PREFETCH 1
+#endif
+#ifndef HGS_K7_PREFETCH
+#define HGS_K7_PREFETCH 1
+#endif
+#ifndef HGS_K7_LPIX_REGS
+#define HGS_K7_LPIX_REGS 1
+#endif
+// instances staged per batch (at most one per lane); row kBatch of the LDS arrays is a dummy instance that can never be
+// a candidate (rows whose list is exhausted fetch it)
+constexpr int kFwdBatch = HGS_K6_BATCH;
+constexpr int kBwdBatch = HGS_K7_BATCH;
 
 struct TileGeom {
   int tile, tx, ty;
@@ -102,16 +91,6 @@ __device__ __forceinline__ bool block_to_tile(int T, int gx, const uint32_t* __r
   return true;
 }
 
-// ================================================================================
-// The kernels: one wave per tile, the four strips processed as two PACKED pairs.
-//
-// Both compositing kernels are vector-issue-bound (profiles/pmc_valu.json: the vector ALUs are busy ~88 % of a launch)
-// and, at 6 - 8 waves per SIMD, sensitive to the dependent chain of an instance as well: the levers are instruction
-// count, cheap instruction forms (plain instead of packed where nothing is gained by packing, output modifiers,
-// mask algebra in scalar registers) and as few LDS round trips per instance as possible.  Non-live lanes are handled
-// by zeroing alpha (an alpha = 0 Gaussian is the identity for every recurrence used here), not by select-updating the
-// state.  The ISA of the two inner loops was read after every change (DESIGN.md, K6/K7 ladder).
-// ================================================================================
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -120,6 +99,41 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 // median into the instruction's clamp bit).  Also turns +inf / NaN inputs into 1 / 0.
 __device__ __forceinline__ float exp2_le1(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
+// number of set bits of `m` below this lane
+__device__ __forceinline__ uint32_t rank_below(uint64_t m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- lane <-> pixel map -------------------------------------------------------------------------------------------------
+// row (= lane >> 4) = quadrant: bit 0 -> right half, bit 1 -> lower half of the tile.  Inside a quadrant lanes 0-7 own
+// the columns of the even rows' first pixel: lane l of the row -> x = l & 7, y0 = (l >> 3) & 1, pixels at y0 + 2 s.
+struct LaneGeom {
+  int q, lx, ly0;   // quadrant, x inside the tile, y of pixel 0 inside the tile
+};
+__device__ __forceinline__ LaneGeom lane_geom(int lane) {
+  LaneGeom g;
+  g.q = lane >> 4;
+  g.lx = (lane & 7) + ((g.q & 1) << 3);
+  g.ly0 = ((lane >> 3) & 1) + ((g.q >> 1) << 3);
+  return g;
+}
+
+// What the staging lane decides for its instance: which quadrants the alpha >= 1/255 box (K1: ext_x, ext_y around the
+// tile-relative centre) can reach.
+struct QuadHit {
+  bool q0, q1, q2, q3;
+};
+__device__ __forceinline__ QuadHit quad_hit(float gxt, float gyt, float ex, float ey) {
+  const bool xl = (gxt - ex <= 7.0f) && (gxt + ex >= 0.0f);
+  const bool xr = (gxt - ex <= 15.0f) && (gxt + ex >= 8.0f);
+  const bool yt = (gyt - ey <= 7.0f) && (gyt + ey >= 0.0f);
+  const bool yb = (gyt - ey <= 15.0f) && (gyt + ey >= 8.0f);
+  return QuadHit{xl && yt, xr && yt, xl && yb, xr && yb};
+}
+
+// ================================================================================
+// forward
+// ================================================================================
 template <bool DEPTH>
 struct FwdPair {
   f2 fly, T, Cr, Cg, Cb, Dd;
@@ -136,12 +150,13 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
   const f2 araw = q1.y * G;
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-  // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band)
+  // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band);
+  // the dummy instance has opacity 0
   const bool live0 = alpha.x >= kAlphaMin;
   const bool live1 = alpha.y >= kAlphaMin;
   const f2 Tn = p.T * (1.0f - alpha);
-  // ONE compare per strip for the saturation test: "blend" and "stop" are both derived from its wave mask in scalar
-  // registers (written with booleans the compiler emits a second, complementary compare per strip)
+  // ONE compare per pixel for the saturation test: "blend" and "stop" are both derived from its wave mask in scalar
+  // registers (written with booleans the compiler emits a second, complementary compare per pixel)
   const uint64_t l0 = __ballot(live0), l1 = __ballot(live1);
   const uint64_t g0 = __ballot(!(Tn.x < kTEps)), g1 = __ballot(!(Tn.y < kTEps));
   const bool blend0 = __builtin_amdgcn_inverse_ballot_w64(l0 & g0), blend1 = __builtin_amdgcn_inverse_ballot_w64(l1 & g1);
@@ -157,50 +172,56 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   p.T = f2{blend0 ? Tn.x : p.T.x, blend1 ? Tn.y : p.T.y};
   p.last0 = blend0 ? idx1 : p.last0;
   p.last1 = blend1 ? idx1 : p.last1;
-  p.fly.x = stop0 ? kBig : p.fly.x;      // a saturated pixel leaves the tile (see above); whether the WHOLE tile
+  p.fly.x = stop0 ? kBig : p.fly.x;      // a saturated pixel leaves the tile (see above); whether a whole quadrant
   p.fly.y = stop1 ? kBig : p.fly.y;      // is finished is checked once per batch, not per stop event
 }
 
 template <bool DEPTH>
-__global__ __launch_bounds__(64) void render_fwd_packed_kernel(
+__global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, float4* __restrict__ zero_ws, uint32_t zero_vecs,
-    const uint32_t* __restrict__ order) {
-  constexpr int BATCH = 64;
+    uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order) {
+  constexpr int kB = kFwdBatch;
   constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
-  __shared__ float4 lrec[BATCH * kLds];
+  __shared__ float4 lrec[(kB + 1) * kLds];
+  // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
+  __shared__ uint32_t qlist[kB + 3];
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
   const int lane = threadIdx.x;
-  const int lx = lane & 15, ly0 = lane >> 4;
-  const int px = tg.tx * kTile + lx;
-  const int py0 = tg.ty * kTile + ly0;
-  const float flx = (float)lx;
+  const LaneGeom lg = lane_geom(lane);
+  const int px = tg.tx * kTile + lg.lx;
+  const int py0 = tg.ty * kTile + lg.ly0;
+  const float flx = (float)lg.lx;
   const float tile_x0 = (float)(tg.tx * kTile), tile_y0 = (float)(tg.ty * kTile);
 
   bool inside[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) inside[s] = (px < W) && (py0 + 4 * s < H);
+  for (int s = 0; s < 4; ++s) inside[s] = (px < W) && (py0 + 2 * s < H);
   FwdPair<DEPTH> P0, P1;
-  P0.fly = f2{inside[0] ? (float)ly0 : kBig, inside[1] ? (float)(ly0 + 4) : kBig};
-  P1.fly = f2{inside[2] ? (float)(ly0 + 8) : kBig, inside[3] ? (float)(ly0 + 12) : kBig};
+  P0.fly = f2{inside[0] ? (float)lg.ly0 : kBig, inside[1] ? (float)(lg.ly0 + 2) : kBig};
+  P1.fly = f2{inside[2] ? (float)(lg.ly0 + 4) : kBig, inside[3] ? (float)(lg.ly0 + 6) : kBig};
   P0.T = P1.T = splat(1.0f);
   P0.Cr = P0.Cg = P0.Cb = P0.Dd = P1.Cr = P1.Cg = P1.Cb = P1.Dd = splat(0.0f);
   P0.last0 = P0.last1 = P1.last0 = P1.last1 = 0;
 
   const uint32_t r0 = ranges[tg.tile * 2 + 0], r1 = ranges[tg.tile * 2 + 1];
-  bool wave_done = (__ballot(inside[0] || inside[1] || inside[2] || inside[3]) == 0);
+  // quadrants that still have an unfinished pixel (bits 16 q .. 16 q + 15 of the ballot)
+  uint64_t alive = __ballot(inside[0] || inside[1] || inside[2] || inside[3]);
+  if (lane == 0) {     // the dummy instance: opacity 0, threshold +inf
+    lrec[kB * kLds + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lrec[kB * kLds + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+  }
+  const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
 
-  for (uint32_t base = r0; base < r1 && !wave_done; base += BATCH) {
+  for (uint32_t base = r0; base < r1 && alive != 0; base += kB) {
     // wave-uniform by construction; readfirstlane tells the compiler so
-    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)BATCH, r1 - base));
+    const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)min((uint32_t)kB, r1 - base));
     __syncthreads();
-    // staging lane = one Gaussian of the batch: besides copying its record it decides which HALF of the tile (rows
-    // 0-7 = pair 0, rows 8-15 = pair 1) the Gaussian's alpha >= 1/255 box (K1: ext_x, ext_y) can reach at all
-    bool half0 = false, half1 = false;
+    QuadHit hit{false, false, false, false};
     if ((uint32_t)lane < n) {
       const uint32_t gid = point_list[base + lane];
       const float4* r = records + (size_t)gid * kRecVec;
@@ -208,46 +229,70 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       const float4 a3 = r[3];
       a0.x = (a0.x - tile_x0) + a3.x;       // tile-relative pixel centre, once per (tile, Gaussian)
       a0.y = (a0.y - tile_y0) + a3.y;
-      const float ex = a2.z, ey = a3.w;
-      const bool xok = (a0.x - ex <= 15.0f) && (a0.x + ex >= 0.0f);
-      half0 = xok && (a0.y - ey <= 7.0f) && (a0.y + ey >= 0.0f);
-      half1 = xok && (a0.y - ey <= 15.0f) && (a0.y + ey >= 8.0f);
+      hit = quad_hit(a0.x, a0.y, a2.z, a3.w);
       a2.z = a3.z;                           // skip threshold
       lrec[lane * kLds + 0] = a0;
       lrec[lane * kLds + 1] = r[1];
       lrec[lane * kLds + 2] = a2;
     }
-    const uint64_t m0 = __ballot(half0), m1 = __ballot(half1);   // scalar registers: one bit per Gaussian of the batch
+    // a finished quadrant takes no more instances
+    hit.q0 = hit.q0 && (alive & 0xffffull) != 0;
+    hit.q1 = hit.q1 && (alive & 0xffff0000ull) != 0;
+    hit.q2 = hit.q2 && (alive & 0xffff00000000ull) != 0;
+    hit.q3 = hit.q3 && (alive & 0xffff000000000000ull) != 0;
+    // one mask per quadrant in scalar registers
+    const uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
+    // the quadrants' lists, front to back: entry = rank of the instance inside its quadrant's mask.  (DS operations of
+    // one wave execute in order: the fill is complete before the byte stores.)
+    for (int i = lane; i < kB + 3; i += 64) qlist[i] = 0x01010101u * (uint32_t)kB;
+    uint8_t* ql8 = reinterpret_cast<uint8_t*>(qlist);
+    if (hit.q0) ql8[rank_below(m0) * 4 + 0] = (uint8_t)lane;
+    if (hit.q1) ql8[rank_below(m1) * 4 + 1] = (uint8_t)lane;
+    if (hit.q2) ql8[rank_below(m2) * 4 + 2] = (uint8_t)lane;
+    if (hit.q3) ql8[rank_below(m3) * 4 + 3] = (uint8_t)lane;
+    const int nmax = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
+                         max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
     __syncthreads();
-    // only Gaussians whose box reaches the tile are visited (22 % of the instances of the benchmark scene do not:
-    // their 3-sigma rectangle touches the tile, their alpha >= 1/255 region does not), and only for the half they reach
-    for (uint64_t todo = m0 | m1; todo != 0; todo &= todo - 1) {
-      const uint32_t j = (uint32_t)__builtin_ctzll(todo);
-      const float4 q0 = lrec[j * kLds + 0];
-      const float4 q1 = lrec[j * kLds + 1];
-      const float4 q2 = lrec[j * kLds + 2];
+    // one (instance, quadrant) pair per row of the wave
+    auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2) {
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
       const float thr = q2.z;
       const uint32_t idx1 = base - r0 + j + 1;
-      // per flagged half: exponents of its two strips, then the exact wave-wide candidate test ("max of the pair >=
-      // thr": one compare per ballot); a finished / outside pixel sits at y = kBig and is never a candidate
-      if ((m0 >> j) & 1) {
-        const f2 dy0 = gyt - P0.fly;
-        const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
-        if (__ballot(fmaxf(pw0.x, pw0.y) >= thr) != 0) fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
+      const f2 dy0 = gyt - P0.fly;
+      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+      const f2 dy1 = gyt - P1.fly;
+      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      // nobody in the wave is a candidate (boxes are conservative): leave before the exp.  A finished / outside pixel
+      // sits at y = kBig and is never a candidate.
+      if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) return;
+      fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
+      fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
+    };
+#if HGS_K6_PREFETCH
+    uint32_t jA = myq[0], jB = myq[4];
+    float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
+    for (int it = 0; it < nmax; it += 2) {
+      const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
+      const uint32_t jA2 = myq[(it + 2) * 4];
+      visit(jA, A0, A1, A2);
+      if (it + 1 < nmax) {
+        A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
+        const uint32_t jB2 = myq[(it + 3) * 4];
+        visit(jB, B0, B1, B2);
+        jB = jB2;
       }
-      if ((m1 >> j) & 1) {
-        const f2 dy1 = gyt - P1.fly;
-        const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-        if (__ballot(fmaxf(pw1.x, pw1.y) >= thr) != 0) fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
-      }
+      jA = jA2;
     }
-    // every pixel saturated?  (finished pixels sit at y = kBig: the rest of a batch costs them only the
-    // no-candidate path above)
-    wave_done = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig) == 0;
+#else
+    for (int it = 0; it < nmax; ++it) {
+      const uint32_t j = myq[it * 4];      // this row's next instance (kB: none)
+      visit(j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
+    }
+#endif
+    alive = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig);
   }
 
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
@@ -261,7 +306,7 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (inside[s]) {
-      const size_t pix = (size_t)(py0 + 4 * s) * W + px;
+      const size_t pix = (size_t)(py0 + 2 * s) * W + px;
       out_color[pix] = cr[s] + Tf[s] * b0;
       out_color[plane + pix] = cg[s] + Tf[s] * b1;
       out_color[2 * plane + pix] = cb[s] + Tf[s] * b2;
@@ -270,33 +315,30 @@ __global__ __launch_bounds__(64) void render_fwd_packed_kernel(
       n_contrib[pix] = la[s];
     }
   }
-  // Side job (hgs_raster_args.bwd_ws_prezero): every tile clears its share of the backward's instance scratch.
-  // This kernel is ALU-bound with HBM mostly idle, so the stores ride along for free; they are issued last so that
-  // nothing in this wave waits for them.
-  if (zero_ws) {
-    const uint32_t per = (zero_vecs + (uint32_t)T - 1) / (uint32_t)T;
-    const uint32_t z0 = (uint32_t)tg.tile * per;
-    const uint32_t z1 = min(z0 + per, zero_vecs);
-    for (uint32_t i = z0 + (uint32_t)lane; i < z1; i += 64u) zero_ws[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
 }
 
-// ---- packed backward ------------------------------------------------------------------
+// ================================================================================
+// backward
+// ================================================================================
 struct BwdPair {
   f2 fly, T, A, bgd, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
+#if HGS_K7_LPIX_REGS
+  f2 c0, c1, c2;           // dL/dC (r, g, b) of the pair's two pixels
+#else
   const f2* pix;           // LDS: this lane's dL/dC (r, g, b) of the pair's two pixels at [0], [64], [128] (see the kernel)
+#endif
   uint32_t nc0, nc1;
 };
-// Per-lane partial sums of one (tile, Gaussian) over the lane's four pixels, as plain floats.  All four pixels of a lane
-// share x, so the three sums that carry dx (sum X dx, sum X dx^2, sum X dx dy) are formed from a0 / a1 just before the
-// cross-lane reduction instead of being accumulated per pixel pair.
+// Per-lane partial sums of one (instance, quadrant) over the lane's four pixels, as plain floats.  All four pixels of a
+// lane share x, so the three sums that carry dx (sum X dx, sum X dx^2, sum X dx dy) are formed from a0 / a1 just before
+// the cross-lane reduction instead of being accumulated per pixel pair.
 struct BwdSums {
   float a0, a1, a4, s5, s6, s7, s8, s9;   // sum X, sum X dy, sum X dy^2, sum G dL/dalpha, sum w dL/dC_rgb, sum w dL/dD
 };
 
-// FIRST: the sums are assigned, not accumulated (the first visited half of an instance: no zero-filled accumulators)
+// FIRST: the sums are assigned, not accumulated (the first pair of an instance: no zero-filled accumulators)
 template <bool DEPTH, bool FIRST>
-__device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, float dx, bool c0, bool c1,
+__device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, bool c0, bool c1,
                                               const float4& q1, f2 q2) {   // q2 = (blue, 1/z)
   // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
   // keeps G finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
@@ -305,13 +347,16 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const bool live0 = c0 && (alpha.x >= kAlphaMin);   // = blended by the forward
   const bool live1 = c1 && (alpha.y >= kAlphaMin);
-  // (no wave-level "nobody live" exit: the candidate test already is the alpha test up to its 1e-3 guard band)
   // non-live lanes take part with alpha = 0: identity for T, for the A recurrence and for every sum
   const f2 ae = {live0 ? alpha.x : 0.0f, live1 ? alpha.y : 0.0f};
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
   const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
+#if HGS_K7_LPIX_REGS
+  const f2 g0 = p.c0, g1 = p.c1, g2 = p.c2;
+#else
   const f2 g0 = p.pix[0], g1 = p.pix[64], g2 = p.pix[128];
+#endif
   f2 q = fma2(g2, splat(q2.x), fma2(g1, splat(q1.w), g0 * q1.z));
   if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
   const f2 qA = q - p.A;
@@ -344,53 +389,98 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   p.A = fma2(ae, qA, p.A);                                      // A_(i-1) = alpha_i q_i + (1 - alpha_i) A_i
 }
 
-__device__ __forceinline__ float swap32_add(float a, float b) {   // [a.lo+a.hi | b.lo+b.hi]
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float swap16_add(float a, float b) {   // rows: [a.r0+a.r1, b.r0+b.r1, a.r2+a.r3, b.r2+b.r3]
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+// Ten registers of per-lane partial sums -> row totals, for all four rows of the wave at once (every row = another
+// instance).  The row is halved three times with DPP adds whose bank masks write the halves of DIFFERENT values next to
+// each other, so the registers are packed as the lane count shrinks: 10 registers (16 partials each) -> 5 (2 x 8) -> 3
+// (4 x 4) -> totals in every lane of a quad.  21 DPP adds, no cross-row traffic, no LDS.
+//   ta: quad b of a row (lanes 4 b .. 4 b + 3) holds the total of v{0,2,1,3}[b]
+//   tb: ... of v{4,6,5,7}[b]
+//   tc: quads 0, 1: v8; quads 2, 3: v9
+// (A DPP operand must not be read within two instructions of the vector instruction that wrote it; the order below
+// keeps every such pair at least three instructions apart, the leading s_nop covers the inputs.)
+__device__ __forceinline__ void row_reduce10(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                             float v7, float v8, float v9, float& ta, float& tb, float& tc) {
+  float r01, r23, r45, r67, r89;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %3, %8, %8 row_mirror row_mask:0xf bank_mask:0x3\n\t"       // r01 lanes 0-7 : v0[i] + v0[15-i]
+      "v_add_f32_dpp %3, %9, %9 row_mirror row_mask:0xf bank_mask:0xc\n\t"       // r01 lanes 8-15: v1
+      "v_add_f32_dpp %4, %10, %10 row_mirror row_mask:0xf bank_mask:0x3\n\t"     // r23: v2 | v3
+      "v_add_f32_dpp %4, %11, %11 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %12, %12 row_mirror row_mask:0xf bank_mask:0x3\n\t"     // r45: v4 | v5
+      "v_add_f32_dpp %5, %13, %13 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %6, %14, %14 row_mirror row_mask:0xf bank_mask:0x3\n\t"     // r67: v6 | v7
+      "v_add_f32_dpp %6, %15, %15 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %7, %16, %16 row_mirror row_mask:0xf bank_mask:0x3\n\t"     // r89: v8 | v9
+      "v_add_f32_dpp %7, %17, %17 row_mirror row_mask:0xf bank_mask:0xc\n\t"
+      // 8 partials per half row -> 4: quads 0 / 2 from the first register, quads 1 / 3 from the second
+      "v_add_f32_dpp %0, %3, %3 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"  // ta quad 0: v0, quad 2: v1
+      "v_add_f32_dpp %0, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"  // ta quad 1: v2, quad 3: v3
+      "v_add_f32_dpp %1, %5, %5 row_half_mirror row_mask:0xf bank_mask:0x5\n\t"  // tb quad 0: v4, quad 2: v5
+      "v_add_f32_dpp %1, %6, %6 row_half_mirror row_mask:0xf bank_mask:0xa\n\t"  // tb quad 1: v6, quad 3: v7
+      "v_add_f32_dpp %2, %7, %7 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"  // tc quads 0,1: v8, quads 2,3: v9
+      // 4 partials per quad -> the total in every lane of the quad
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+      : "=&v"(ta), "=&v"(tb), "=&v"(tc), "=&v"(r01), "=&v"(r23), "=&v"(r45), "=&v"(r67), "=&v"(r89)
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9));
 }
 
+#ifndef HGS_K7_WAVES
+#define HGS_K7_WAVES 4
+#endif
 template <bool DEPTH>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void render_bwd_packed_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES, HGS_K7_WAVES))) void render_bwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order) {
-  constexpr int BATCH = 64;
-  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,emission offset,rect)
-  __shared__ float4 lrec[BATCH * kLds];
-  __shared__ float lthr[BATCH];          // skip threshold
+  constexpr int kB = kBwdBatch;
+  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
+  __shared__ float4 lrec[(kB + 1) * kLds];
+  // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
+  __shared__ uint32_t qlist[kB + 3];
+  // The batch's instance sums, one array for the upper and one for the lower quadrants: a box reaches 1, 2 or all 4
+  // quadrants, so each array receives at most TWO additions per value -- commutative, whatever order the rows' lists
+  // reach the instance in -- and the two are added in a fixed order at the end of the batch: the result does not depend
+  // on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute changes no bit)
+  constexpr int kAccRows = (kB + 1) * kInstStride;
+  __shared__ __attribute__((aligned(8))) float acc[2 * kAccRows];
+#if !HGS_K7_LPIX_REGS
   // The colour gradients of a lane's four pixels are constants that only the live path reads: they sit in LDS ([pair][r,
-  // g, b][lane] as float2; written and read by the SAME lane, so no barrier), not in 12 registers -- the kernel then
-  // fits 80 registers = 6 waves per SIMD (6.3 KB of LDS per wave: 24 waves per CU; same time alone, 2.5 % more
-  // frames/s when the other stream's streaming kernels run beside it)
+  // g, b][lane] as float2; written and read by the SAME lane, so no barrier), not in 12 registers
   __shared__ f2 lpix[2 * 3 * 64];
+#endif
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
   const int lane = threadIdx.x;
-  const int lx = lane & 15, ly0 = lane >> 4;
-  const int px = tg.tx * kTile + lx;
-  const int py0 = tg.ty * kTile + ly0;
-  const float flx = (float)lx;
+  const LaneGeom lg = lane_geom(lane);
+  const int px = tg.tx * kTile + lg.lx;
+  const int py0 = tg.ty * kTile + lg.ly0;
+  const float flx = (float)lg.lx;
   const float tile_x0 = (float)(tg.tx * kTile), tile_y0 = (float)(tg.ty * kTile);
   const size_t plane = (size_t)W * H;
   const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+  const uint32_t r0 = ranges[tg.tile * 2 + 0], r1 = ranges[tg.tile * 2 + 1];
+  const uint32_t total = r1 - r0;
+  if (total == 0) return;
 
   float fly[4], Tr[4], bgd[4], g0[4], g1[4], g2[4], gd[4];
   uint32_t nc[4];
   uint32_t maxnc = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
-    const int py = py0 + 4 * s;
+    const int py = py0 + 2 * s;
     fly[s] = kBig; Tr[s] = 1.0f; bgd[s] = 0.f; g0[s] = g1[s] = g2[s] = gd[s] = 0.f; nc[s] = 0;
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      fly[s] = (float)(ly0 + 4 * s);
+      fly[s] = (float)(lg.ly0 + 2 * s);
       g0[s] = dL_dcolor[pix];
       g1[s] = dL_dcolor[plane + pix];
       g2[s] = dL_dcolor[2 * plane + pix];
@@ -404,34 +494,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
   maxnc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxnc);   // uniform: loop counters live in scalar registers
-  if (maxnc == 0) return;
   BwdPair P0, P1;
   P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
   P0.T = f2{Tr[0], Tr[1]};     P1.T = f2{Tr[2], Tr[3]};
   P0.bgd = f2{bgd[0], bgd[1]}; P1.bgd = f2{bgd[2], bgd[3]};
+#if HGS_K7_LPIX_REGS
+  P0.c0 = f2{g0[0], g0[1]}; P0.c1 = f2{g1[0], g1[1]}; P0.c2 = f2{g2[0], g2[1]};
+  P1.c0 = f2{g0[2], g0[3]}; P1.c1 = f2{g1[2], g1[3]}; P1.c2 = f2{g2[2], g2[3]};
+#else
   P0.pix = lpix + lane; P1.pix = lpix + 3 * 64 + lane;
   lpix[0 * 64 + lane] = f2{g0[0], g0[1]}; lpix[3 * 64 + lane] = f2{g0[2], g0[3]};
   lpix[1 * 64 + lane] = f2{g1[0], g1[1]}; lpix[4 * 64 + lane] = f2{g1[2], g1[3]};
   lpix[2 * 64 + lane] = f2{g2[0], g2[1]}; lpix[5 * 64 + lane] = f2{g2[2], g2[3]};
+#endif
   P0.gd = f2{gd[0], gd[1]};    P1.gd = f2{gd[2], gd[3]};
   P0.A = P1.A = splat(0.0f);
   P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
-  const uint32_t r0 = ranges[tg.tile * 2 + 0];
-  // which float of the 12-float instance record this lane stores after the reduction (-1: none).  Rows carry the
-  // values {0,2,1,3}[row] of each group of four (permlane swap order); within a row, quad 0 holds s0..s3's, quad 2
-  // s4..s7's, quad 1 s8 (row 1) / s9 (row 3) -- see row_sum16_x3
-  const int row = lane >> 4, quad = (lane >> 2) & 3;
-  const int slot = ((row & 1) << 1) | (row >> 1);
-  int store_k = -1;
-  if ((lane & 3) == 0) {
-    if (quad == 0) store_k = slot;
-    else if (quad == 2) store_k = 4 + slot;
-    else if (quad == 1 && (row & 1)) store_k = 8 + (row >> 1);
+  if (lane == 0) {     // the dummy instance: opacity 0, threshold +inf
+    lrec[kB * kLds + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lrec[kB * kLds + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
   }
-  for (int bstart = (int)((maxnc - 1) / BATCH) * BATCH; bstart >= 0; bstart -= BATCH) {
-    const int n = min(BATCH, (int)maxnc - bstart);
+  const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
+  float* const myacc = acc + (lg.q >> 1) * kAccRows;
+  // which float of the instance record this lane adds after the row reduction (see row_reduce10): only the first lane
+  // of every quad takes part
+  const int quad = (lane >> 2) & 3;
+  const bool adder = (lane & 3) == 0;
+  const int ka = ((quad & 1) << 1) | (quad >> 1);          // {0,2,1,3}[quad]
+  const int kc = 8 + (quad >> 1);                          // quads 0 / 2 add v8 / v9
+  const bool adder_c = adder && (quad & 1) == 0;
+
+  // Batches back to front.  The first batch is the one holding the last contributor; instances behind it (and every
+  // instance of a tile whose pixels blended nothing) only get their zero record written (tail loop below).
+  const int top = maxnc ? (int)((maxnc - 1) / kB) * kB : -kB;
+  for (int bstart = top; bstart >= 0; bstart -= kB) {
+    const int n = min(kB, (int)total - bstart);
     __syncthreads();
-    bool half0 = false, half1 = false;          // see the forward kernel: which half of the tile the Gaussian can reach
+    QuadHit hit{false, false, false, false};
+    uint32_t my_off = 0, my_rect = 0;
     if (lane < n) {
       const uint32_t gid = point_list[r0 + bstart + lane];
       const float4* r = records + (size_t)gid * kRecVec;
@@ -439,111 +540,131 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6, 6))) void
       const float4 a3 = r[3];
       a0.x = (a0.x - tile_x0) + a3.x;           // tile-relative pixel centre, once per (tile, Gaussian)
       a0.y = (a0.y - tile_y0) + a3.y;
-      const float ex = a2.z, ey = a3.w;
-      const bool xok = (a0.x - ex <= 15.0f) && (a0.x + ex >= 0.0f);
-      half0 = xok && (a0.y - ey <= 7.0f) && (a0.y + ey >= 0.0f);
-      half1 = xok && (a0.y - ey <= 15.0f) && (a0.y + ey >= 8.0f);
-      a2.z = __uint_as_float(offsets[gid]);     // emission offset of this Gaussian's instance run
+      if ((uint32_t)(bstart + lane) < maxnc) hit = quad_hit(a0.x, a0.y, a2.z, a3.w);   // behind every pixel's last
+      my_off = offsets[gid];                                                            // contributor: nothing to do
+      my_rect = __float_as_uint(a2.w);
+      a2.z = a3.z;                               // skip threshold
       lrec[lane * kLds + 0] = a0;
       lrec[lane * kLds + 1] = r[1];
       lrec[lane * kLds + 2] = a2;
-      lthr[lane] = a3.z;
     }
-    const uint64_t m0 = __ballot(half0), m1 = __ballot(half1);
+    const uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
+    const bool any_hit = hit.q0 || hit.q1 || hit.q2 || hit.q3;
+    // the quadrants' lists, BACK to front: entry = number of the mask's set bits ABOVE the instance.  (DS operations of
+    // one wave execute in order: the fill is complete before the byte stores.)
+    for (int i = lane; i < kB + 3; i += 64) qlist[i] = 0x01010101u * (uint32_t)kB;
+    uint8_t* ql8 = reinterpret_cast<uint8_t*>(qlist);
+    const int c0n = __builtin_popcountll(m0), c1n = __builtin_popcountll(m1);
+    const int c2n = __builtin_popcountll(m2), c3n = __builtin_popcountll(m3);
+    if (hit.q0) ql8[(c0n - 1 - (int)rank_below(m0)) * 4 + 0] = (uint8_t)lane;
+    if (hit.q1) ql8[(c1n - 1 - (int)rank_below(m1)) * 4 + 1] = (uint8_t)lane;
+    if (hit.q2) ql8[(c2n - 1 - (int)rank_below(m2)) * 4 + 2] = (uint8_t)lane;
+    if (hit.q3) ql8[(c3n - 1 - (int)rank_below(m3)) * 4 + 3] = (uint8_t)lane;
+    if (any_hit) {      // this instance's accumulator rows
+      f2* row = reinterpret_cast<f2*>(acc + lane * kInstStride);
+#pragma unroll
+      for (int k = 0; k < kInstStride / 2; ++k) row[k] = row[kAccRows / 2 + k] = splat(0.0f);
+    }
+    const int nmax = max(max(c0n, c1n), max(c2n, c3n));
     __syncthreads();
-    // back to front over the Gaussians whose box reaches the tile
-    for (uint64_t todo = m0 | m1; todo != 0;) {
-      const int j = 63 - __builtin_clzll(todo);
-      todo &= ~(1ull << j);
-      const uint32_t rel = (uint32_t)(bstart + j);
-      const float4 q0 = lrec[j * kLds + 0];
-      const float4 q1 = lrec[j * kLds + 1];
+
+    // one (instance, quadrant) pair per row of the wave
+    auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
+      const uint32_t rel = (uint32_t)bstart + j;
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const float thr = lthr[j];
-      // per flagged half: exponents, per-strip candidate predicates (log-domain alpha test AND "the forward blended
-      // this Gaussian into the pixel", i.e. rel < n_contrib) and the wave-uniform "half has a candidate" from the
-      // ballots of the plain compares combined in scalar registers
-      // (read only under b0 / b1, i.e. only when assigned: left uninitialised on purpose -- a zero initialiser costs
-      // four vector moves per instance on the path of a half that is not visited)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wsometimes-uninitialized"
-#pragma clang diagnostic ignored "-Wconditional-uninitialized"
-      f2 dy0, dy1, pw0, pw1;
-      bool c0 = false, c1 = false, c2 = false, c3 = false, b0 = false, b1 = false;
-      if ((m0 >> j) & 1) {
-        dy0 = gyt - P0.fly;
-        pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
-        c0 = (pw0.x >= thr) && (rel < P0.nc0);
-        c1 = (pw0.y >= thr) && (rel < P0.nc1);
-        b0 = ((__ballot(pw0.x >= thr) & __ballot(rel < P0.nc0)) | (__ballot(pw0.y >= thr) & __ballot(rel < P0.nc1))) != 0;
-      }
-      if ((m1 >> j) & 1) {
-        dy1 = gyt - P1.fly;
-        pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-        c2 = (pw1.x >= thr) && (rel < P1.nc0);
-        c3 = (pw1.y >= thr) && (rel < P1.nc1);
-        b1 = ((__ballot(pw1.x >= thr) & __ballot(rel < P1.nc0)) | (__ballot(pw1.y >= thr) & __ballot(rel < P1.nc1))) != 0;
-      }
-      if (!(b0 || b1)) continue;
-      // the record's third float4 in two halves: (blue, 1/z) now, for the live path; (emission offset, rectangle) next
-      // to the reduction that hides its latency -- read as one float4 here, the two scalars it feeds into the store's
-      // address make the compiler wait for the whole read before the live path starts
-      const f2 q2 = *reinterpret_cast<const f2*>(&lrec[j * kLds + 2]);
+      const float thr = q2v.z;
+      const f2 dy0 = gyt - P0.fly;
+      const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
+      const f2 dy1 = gyt - P1.fly;
+      const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
+      // per-pixel candidate predicates: log-domain alpha test AND "the forward blended this Gaussian into the pixel"
+      // (rel < n_contrib); combined in scalar registers
+      const uint64_t k0 = __ballot(pw0.x >= thr) & __ballot(rel < P0.nc0);
+      const uint64_t k1 = __ballot(pw0.y >= thr) & __ballot(rel < P0.nc1);
+      const uint64_t k2 = __ballot(pw1.x >= thr) & __ballot(rel < P1.nc0);
+      const uint64_t k3 = __ballot(pw1.y >= thr) & __ballot(rel < P1.nc1);
+      if ((k0 | k1 | k2 | k3) == 0) return;        // nobody in the wave: the accumulators keep their zeros
+      const bool c0 = __builtin_amdgcn_inverse_ballot_w64(k0), c1 = __builtin_amdgcn_inverse_ballot_w64(k1);
+      const bool c2 = __builtin_amdgcn_inverse_ballot_w64(k2), c3 = __builtin_amdgcn_inverse_ballot_w64(k3);
+      const f2 q2 = f2{q2v.x, q2v.y};
       BwdSums S;
       if (!DEPTH) S.s9 = 0.0f;
-      if (b0) {
-        bwd_pair_live<DEPTH, true>(P0, S, pw0, dy0, dx, c0, c1, q1, q2);
-        if (b1) bwd_pair_live<DEPTH, false>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
-      } else {
-        bwd_pair_live<DEPTH, true>(P1, S, pw1, dy1, dx, c2, c3, q1, q2);
+      bwd_pair_live<DEPTH, true>(P0, S, pw0, dy0, c0, c1, q1, q2);
+      bwd_pair_live<DEPTH, false>(P1, S, pw1, dy1, c2, c3, q1, q2);
+      const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
+      const float s2 = dx * s0;                        // sum X dx^2
+      float ta, tb, tc;
+      row_reduce10(s0, S.a1, s2, s3, S.a4, S.s5, S.s6, S.s7, S.s8, S.s9, ta, tb, tc);
+      // combine with what other quadrants found for the same instance (dummy: row kB, never read)
+      if (adder) {
+        float* row = myacc + j * kInstStride;
+        atomicAdd(row + ka, ta);
+        atomicAdd(row + 4 + ka, tb);
+        if (adder_c) atomicAdd(row + kc, tc);
       }
-      {
-        // 10 sums x 64 lanes -> 10 floats of the instance record: halve the lane
-        // count twice with permlane32 / permlane16 swaps (two values share a register afterwards: rows of the two
-        // registers = (s0,s2,s1,s3) and (s4,s6,s5,s7); s8 / s9 keep two rows each), then ONE packed row reduction of the
-        // three registers (row_sum16_x3) that also joins the row pairs of s8 / s9.
-        const uint2 slot = *reinterpret_cast<const uint2*>(reinterpret_cast<const float*>(&lrec[j * kLds + 2]) + 2);
-        const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
-        const float s2 = dx * s0;                        // sum X dx^2
-        const float u0 = swap32_add(s0, S.a1);
-        const float u1 = swap32_add(s2, s3);
-        const float u2 = swap32_add(S.a4, S.s5);
-        const float u3 = swap32_add(S.s6, S.s7);
-        const float u4 = swap32_add(S.s8, S.s9);
-        const float v = row_sum16_x3(swap16_add(u0, u1), swap16_add(u2, u3), u4);
-        __builtin_amdgcn_sched_barrier(0);              // (keep the scalar address arithmetic behind the reduction)
-        if (store_k >= 0) {
-          const uint32_t off = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot.x);
-          const uint32_t rb = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot.y);
-          const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
-          const uint32_t e = off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
-          inst[(size_t)e * kInstStride + store_k] = v;     // ONE store: ten lanes, 40 of the record's 48 bytes
-        }
+    };
+#if HGS_K7_PREFETCH
+    // Two iterations per trip, the record of the NEXT iteration and the list entry of the one after it requested
+    // before the current one is composited: every row's record address depends on a list entry that is itself in LDS,
+    // and at 4 - 5 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
+    uint32_t jA = myq[0], jB = myq[4];
+    float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
+    for (int it = 0; it < nmax; it += 2) {
+      const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
+      const uint32_t jA2 = myq[(it + 2) * 4];
+      visit(jA, A0, A1, A2);
+      if (it + 1 < nmax) {
+        A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
+        const uint32_t jB2 = myq[(it + 3) * 4];
+        visit(jB, B0, B1, B2);
+        jB = jB2;
       }
+      jA = jA2;
     }
+#else
+    for (int it = 0; it < nmax; ++it) {
+      const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
+      visit(j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
+    }
+#endif
+    __syncthreads();
+    // lane i stores instance i's record to its emission slot: every staged instance is written, reached or not
+    if (lane < n) {
+      const uint32_t minx = my_rect & 1023u, miny = (my_rect >> 10) & 1023u, rw = my_rect >> 20;
+      const uint32_t e = my_off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
+      f2* dst = reinterpret_cast<f2*>(inst + (size_t)e * kInstStride);
+      const f2* row = reinterpret_cast<const f2*>(acc + lane * kInstStride);
+#pragma unroll
+      for (int k = 0; k < kInstStride / 2; ++k) dst[k] = any_hit ? row[k] + row[kAccRows / 2 + k] : splat(0.0f);
+    }
+  }
+  // instances behind the last contributor of every pixel: zero records
+  for (int i = top + kB + lane; i < (int)total; i += 64) {
+    const uint32_t gid = point_list[r0 + i];
+    const uint32_t rb = __float_as_uint(reinterpret_cast<const float*>(records + (size_t)gid * kRecVec + 2)[3]);
+    const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
+    const uint32_t e = offsets[gid] + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
+    f2* dst = reinterpret_cast<f2*>(inst + (size_t)e * kInstStride);
+#pragma unroll
+    for (int k = 0; k < kInstStride / 2; ++k) dst[k] = splat(0.0f);
   }
 }
 
 }  // namespace
 
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
-                      float* out_color, float* out_invdepth, float* zero_ws, size_t zero_floats, hipStream_t s) {
-  if (zero_ws && (zero_floats >> 2) > 0xfff00000ull) {   // the side job counts float4s in 32 bits
-    HGS_HIP(hipMemsetAsync(zero_ws, 0, zero_floats * sizeof(float), s));
-    zero_ws = nullptr;
-  }
+                      float* out_color, float* out_invdepth, hipStream_t s) {
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = ((T + 7) / 8) * 8;
   const bool depth = a.do_depth && out_invdepth;
-  auto kern = depth ? render_fwd_packed_kernel<true> : render_fwd_packed_kernel<false>;
+  auto kern = depth ? render_fwd_quad_kernel<true> : render_fwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
-                     out_invdepth, im.final_T, im.n_contrib, reinterpret_cast<float4*>(zero_ws),
-                     (uint32_t)(zero_floats >> 2), b.tile_order);
-  HGS_LAUNCH_CHECK("render_fwd_packed", s, a.debug);
+                     out_invdepth, im.final_T, im.n_contrib, b.tile_order);
+  HGS_LAUNCH_CHECK("render_fwd_quad", s, a.debug);
   return HGS_OK;
 }
 
@@ -554,11 +675,11 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = ((T + 7) / 8) * 8;
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
-  auto kern = depth ? render_bwd_packed_kernel<true> : render_bwd_packed_kernel<false>;
+  auto kern = depth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
                      im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order);
-  HGS_LAUNCH_CHECK("render_bwd_packed", s, a.debug);
+  HGS_LAUNCH_CHECK("render_bwd_quad", s, a.debug);
   return HGS_OK;
 }
 

@@ -156,9 +156,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                         prefiltered, debug, render_indices, parent_indices, interpolation_weights,
                         num_node_kids, do_depth, sh_rest=None, activations=0, prepare_backward=False, lod=None):
     """Forward.  Returns (num_rendered, color[3,H,W], radii[P], geomBuffer, binningBuffer, imgBuffer,
-    invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward.  ``prepare_backward``: allocate
-    the backward's scratch now and let the forward's compositing kernel zero-fill it on the side
-    (hgs_raster_args.bwd_ws_prezero) instead of a memset in the backward."""
+    invdepth[1,H,W], call) -- ``call`` carries the argument block for the backward.  ``prepare_backward``: a backward
+    will follow (hgs_raster_args.prepare_backward: K1 also stores d(rgb)/d(direction) for the SH backward)."""
     if lod is None and ((render_indices is not None and render_indices.numel() > 0) or
                         (parent_indices is not None and parent_indices.numel() > 0)):
         raise RuntimeError("rasterize_gaussians expects already gathered rows; non-empty render_indices / "
@@ -195,16 +194,12 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         stats["speculative_calls"] += 1
         _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
         binb = torch.empty(sz[1].value, **u8)
-        if prepare_backward:
-            scratch = torch.empty(sz[3].value, **u8)
-            a.bwd_ws_prezero = scratch.data_ptr()
         rc = lib.hgs_raster_fwd(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws, _lib.ptr(radii),
                                 _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None, C.byref(L),
                                 _stream(dev), devi)
         if rc == _lib.ERR_CAPACITY:
-            binb = scratch = None   # the scene grew by more than 25 %: finish on the exact two-stage path
+            binb = None   # the scene grew by more than 25 %: finish on the exact two-stage path
             stats["capacity_misses"] += 1
-            a.bwd_ws_prezero = None
         else:
             _lib.check(rc, "hgs_raster_fwd")
     else:
@@ -214,9 +209,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         L_ws = L.value
         _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
         binb = torch.empty(sz[1].value, **u8)
-        if prepare_backward and P > 0:
-            scratch = torch.empty(sz[3].value, **u8)
-            a.bwd_ws_prezero = scratch.data_ptr()
         _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
@@ -294,14 +286,12 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     g.dL_dshs_rest = p(d_shr)
     a.accumulate_grads = int(bool(accumulate and out is not None))
     a.defer_sh_bwd = int(bool(defer_sh and sh is not None and sh_rest is None))
-    scratch = call.scratch           # allocated and zero-filled by the forward (prepare_backward), single use
-    call.scratch = None
-    if scratch is None:
-        a.bwd_ws_prezero = None
-        bwd_bytes = C.c_size_t()
-        _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
-                   "hgs_raster_ws_sizes")
-        scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
+    # the backward's scratch (instance records + per-Gaussian colour gradients): needs no initialisation, K7 writes
+    # every instance record
+    bwd_bytes = C.c_size_t()
+    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
+               "hgs_raster_ws_sizes")
+    scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
     _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L_ws,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),

@@ -36,9 +36,9 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 4
+#define HGS_ABI_VERSION 5
 #define HGS_TILE 16
-#define HGS_INST_GRAD_STRIDE 12 /* floats per (tile, Gaussian) instance in the backward scratch */
+#define HGS_INST_GRAD_STRIDE 10 /* floats per (tile, Gaussian) instance in the backward scratch (40 bytes: the ten sums) */
 
 enum {
   HGS_OK = 0,
@@ -95,11 +95,10 @@ typedef struct hgs_raster_args {
   int32_t activations;      /* OR of HGS_ACT_*; 0 = inputs are already activated (the reference's call) */
   int32_t defer_sh_bwd;     /* backward: skip the SH part (dL_dshs and the view-direction term of dL_dmeans3D); the
                              * caller finishes it for several views at once with hgs_raster_sh_bwd_batched */
-  /* Optional: the bwd_ws buffer the matching hgs_raster_bwd call will receive (bwd_bytes of hgs_raster_ws_sizes
-   * for the same L).  The forward then zero-fills its instance-gradient part from inside the compositing kernel --
-   * that kernel is ALU-bound and leaves HBM idle, so the 48 B per instance of zeroes cost nothing there -- and the
-   * backward, seeing the same pointer, skips its own memset.  NULL: the backward clears the scratch itself. */
-  void* bwd_ws_prezero;
+  /* Unused since ABI 5 (was bwd_ws_prezero: the forward zero-filled the backward's instance scratch).  The backward's
+   * compositing kernel now writes EVERY instance record itself -- sums, or zeros for instances no pixel blended -- so
+   * bwd_ws needs no initialisation by anybody.  Kept so that the struct layout does not move. */
+  void* reserved0;
   /* The caller will run hgs_raster_bwd on the workspaces of this forward (must hold the SAME value in the forward and
    * in the backward call).  The forward's per-Gaussian kernel then also stores, next to the colour, the 3x3 Jacobian
    * d(rgb)/d(view direction) (36 bytes per Gaussian, in geom_ws): it has the SH coefficients in registers anyway, and

@@ -91,11 +91,11 @@ def test_capacity_miss_retry_matches_oracle(gpu, monkeypatch):
     cam, scene, gc, gd = pa.default_case(4000, 208, 144, seed=31)
     bg = torch.tensor([0.1, 0.2, 0.3])
     C._last_L.clear()
-    pa.run_hip(scene, cam, bg, gc, gd, gpu, scale_modifier=0.3, debug=False)
+    pa.run_hip(scene, cam, bg, gc, gd, gpu, scale_modifier=0.3, debug=False, grad_mask=None)
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, scale_modifier=1.5)     # (before its run_hip: fragile-pixel pairing)
     misses0 = C.stats["capacity_misses"]
     hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, scale_modifier=1.5, debug=False)
     assert C.stats["capacity_misses"] == misses0 + 1
-    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, scale_modifier=1.5)
     _assert_case("capacity_retry", hip, oo, og)
 
 
