@@ -566,7 +566,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   float d_rot[4] = {0.f, 0.f, 0.f, 0.f};
   float d_c3[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float d_col[3] = {0.f, 0.f, 0.f};
-  float sums5 = 0.f, sums6 = 0.f, sums7 = 0.f, sums8 = 0.f;
+  float sums6 = 0.f, sums7 = 0.f, sums8 = 0.f;
 
   if (n == 0) {
     // culled: all-zero gradients (K8b zero-fills dL/dSH)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
       s[8] += v4.x; s[9] += v4.y;
     }
-    sums5 = (float)s[5]; sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
+    sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
     const uint32_t flags = g.flags[idx];
     float p[3];
@@ -720,8 +720,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       float dod = 1.0f;
       double dact = 1.0;
       const float o_act = load_opacity<LOD>(a, idx, &dact);
+      float o_rec = o_act;      // the opacity K1 put into the record (same functions, same float)
       if (a.interpolation_weights && a.num_node_kids)
-        (void)lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
+        o_rec = lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
+      // the instance records carry sum X = sum (o G) dL/dalpha; dL/do = sum G dL/dalpha = (sum X) / o.  o <= 0: never
+      // blended, sum X = 0
+      const float sums5 = o_rec > 0.0f ? (float)(s[5] / (double)o_rec) : 0.0f;
       d_op = a.activations ? (float)((double)sums5 * (double)dod * dact) : sums5 * dod;
     }
 

@@ -41,6 +41,8 @@
 //    loop): a row's record address depends on a list entry that is itself in LDS, and at 4 waves per SIMD two dependent
 //    LDS round trips per iteration are not hidden by the other waves (K7 0.426 -> 0.385 ms; with the pixels' colour
 //    gradients in registers instead of LDS 0.339).
+#include <type_traits>
+
 #include "common.h"
 
 namespace hgs {
@@ -61,6 +63,9 @@ constexpr float kBig = 1.0e18f;   // y coordinate of a finished / outside pixel:
 #endif
 #ifndef HGS_K7_PREFETCH
 #define HGS_K7_PREFETCH 1
+#endif
+#ifndef HGS_K7_NCSPEC
+#define HGS_K7_NCSPEC 0
 #endif
 #ifndef HGS_K7_LPIX_REGS
 #define HGS_K7_LPIX_REGS 1
@@ -333,7 +338,7 @@ struct BwdPair {
 // lane share x, so the three sums that carry dx (sum X dx, sum X dx^2, sum X dx dy) are formed from a0 / a1 just before
 // the cross-lane reduction instead of being accumulated per pixel pair.
 struct BwdSums {
-  float a0, a1, a4, s5, s6, s7, s8, s9;   // sum X, sum X dy, sum X dy^2, sum G dL/dalpha, sum w dL/dC_rgb, sum w dL/dD
+  float a0, a1, a4, s6, s7, s8, s9;   // sum X, sum X dy, sum X dy^2, sum w dL/dC_rgb, sum w dL/dD
 };
 
 // FIRST: the sums are assigned, not accumulated (the first pair of an instance: no zero-filled accumulators)
@@ -341,14 +346,15 @@ template <bool DEPTH, bool FIRST>
 __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, bool c0, bool c1,
                                               const float4& q1, f2 q2) {   // q2 = (blue, 1/z)
   // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
-  // keeps G finite on the non-live lanes, whose contributions are multiplied by an exact 0 below
+  // keeps G finite on the non-live lanes
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
-  const f2 araw = q1.y * G;
-  const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
-  const bool live0 = c0 && (alpha.x >= kAlphaMin);   // = blended by the forward
-  const bool live1 = c1 && (alpha.y >= kAlphaMin);
-  // non-live lanes take part with alpha = 0: identity for T, for the A recurrence and for every sum
-  const f2 ae = {live0 ? alpha.x : 0.0f, live1 ? alpha.y : 0.0f};
+  const f2 araw0 = q1.y * G;
+  const bool live0 = c0 && (araw0.x >= kAlphaMin);   // = blended by the forward (alpha = min(0.99, araw) >= 1/255)
+  const bool live1 = c1 && (araw0.y >= kAlphaMin);
+  // non-live lanes take part with o G = 0: alpha = 0 is the identity for T and for the A recurrence, and every sum is
+  // a multiple of o G (dL/dopacity = sum G dL/dalpha = (sum X) / o is formed by K8 from sum X: no sum of its own)
+  const f2 araw = {live0 ? araw0.x : 0.0f, live1 ? araw0.y : 0.0f};
+  const f2 ae = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
   const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
@@ -360,8 +366,7 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   f2 q = fma2(g2, splat(q2.x), fma2(g1, splat(q1.w), g0 * q1.z));
   if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
   const f2 qA = q - p.A;
-  const f2 dfull = fma2(qA, Tcur, -(p.bgd * rinv));
-  const f2 dLda = {live0 ? dfull.x : 0.0f, live1 ? dfull.y : 0.0f};
+  const f2 dLda = fma2(qA, Tcur, -(p.bgd * rinv));              // finite on non-live lanes, multiplied by 0 below
   const f2 w = ae * Tcur;
   const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
   const f2 Xdy = X * dy;
@@ -370,7 +375,6 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
     S.a0 = X.x + X.y;
     S.a1 = Xdy.x + Xdy.y;
     S.a4 = fmaf(Xdy.y, dy.y, Xdy.x * dy.x);
-    S.s5 = fmaf(G.y, dLda.y, G.x * dLda.x);
     S.s6 = fmaf(w.y, g0.y, w.x * g0.x);
     S.s7 = fmaf(w.y, g1.y, w.x * g1.x);
     S.s8 = fmaf(w.y, g2.y, w.x * g2.x);
@@ -379,7 +383,6 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
     S.a0 += X.x + X.y;
     S.a1 += Xdy.x + Xdy.y;
     S.a4 = fmaf(Xdy.y, dy.y, fmaf(Xdy.x, dy.x, S.a4));
-    S.s5 = fmaf(G.y, dLda.y, fmaf(G.x, dLda.x, S.s5));
     S.s6 = fmaf(w.y, g0.y, fmaf(w.x, g0.x, S.s6));
     S.s7 = fmaf(w.y, g1.y, fmaf(w.x, g1.x, S.s7));
     S.s8 = fmaf(w.y, g2.y, fmaf(w.x, g2.x, S.s8));
@@ -471,16 +474,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
   const uint32_t total = r1 - r0;
   if (total == 0) return;
 
-  float fly[4], Tr[4], bgd[4], g0[4], g1[4], g2[4], gd[4];
+  float Tr[4], bgd[4], g0[4], g1[4], g2[4], gd[4];
   uint32_t nc[4];
   uint32_t maxnc = 0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const int py = py0 + 2 * s;
-    fly[s] = kBig; Tr[s] = 1.0f; bgd[s] = 0.f; g0[s] = g1[s] = g2[s] = gd[s] = 0.f; nc[s] = 0;
+    Tr[s] = 1.0f; bgd[s] = 0.f; g0[s] = g1[s] = g2[s] = gd[s] = 0.f; nc[s] = 0;   // outside the image: n_contrib 0
     if (px < W && py < H) {
       const size_t pix = (size_t)py * W + px;
-      fly[s] = (float)(lg.ly0 + 2 * s);
       g0[s] = dL_dcolor[pix];
       g1[s] = dL_dcolor[plane + pix];
       g2[s] = dL_dcolor[2 * plane + pix];
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
   for (int off = 32; off > 0; off >>= 1) maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, off, 64));
   maxnc = (uint32_t)__builtin_amdgcn_readfirstlane((int)maxnc);   // uniform: loop counters live in scalar registers
   BwdPair P0, P1;
-  P0.fly = f2{fly[0], fly[1]}; P1.fly = f2{fly[2], fly[3]};
+  const float flyb = (float)lg.ly0;                              // y of pixel 0; the pairs' fly is set per batch
   P0.T = f2{Tr[0], Tr[1]};     P1.T = f2{Tr[2], Tr[3]};
   P0.bgd = f2{bgd[0], bgd[1]}; P1.bgd = f2{bgd[2], bgd[3]};
 #if HGS_K7_LPIX_REGS
@@ -567,9 +569,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
     }
     const int nmax = max(max(c0n, c1n), max(c2n, c3n));
     __syncthreads();
+    // "The forward blended this Gaussian into the pixel" <=> rel < n_contrib.  A pixel whose last contributor lies in a
+    // LATER batch passes for every instance of this one; a pixel whose last contributor lies in an EARLIER batch (or
+    // outside the image: n_contrib 0) fails for every instance and is parked at y = kBig for the batch; only a batch
+    // that holds some pixel's last contributor needs the per-instance compare (one batch in five on the benchmark).
+    const uint32_t bs = (uint32_t)bstart;
+    P0.fly = f2{P0.nc0 > bs ? flyb : kBig, P0.nc1 > bs ? flyb + 2.0f : kBig};
+    P1.fly = f2{P1.nc0 > bs ? flyb + 4.0f : kBig, P1.nc1 > bs ? flyb + 6.0f : kBig};
+    const bool mixed = __ballot((P0.nc0 > bs && P0.nc0 < bs + kB) || (P0.nc1 > bs && P0.nc1 < bs + kB) ||
+                                (P1.nc0 > bs && P1.nc0 < bs + kB) || (P1.nc1 > bs && P1.nc1 < bs + kB)) != 0;
 
     // one (instance, quadrant) pair per row of the wave
-    auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
+    auto visit = [&](auto nc_tag, uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
+      constexpr bool NC = decltype(nc_tag)::value;
       const uint32_t rel = (uint32_t)bstart + j;
       const float gyt = q0.y;
       const float dx = q0.x - flx;
@@ -580,12 +592,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 dy1 = gyt - P1.fly;
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-      // per-pixel candidate predicates: log-domain alpha test AND "the forward blended this Gaussian into the pixel"
-      // (rel < n_contrib); combined in scalar registers
-      const uint64_t k0 = __ballot(pw0.x >= thr) & __ballot(rel < P0.nc0);
-      const uint64_t k1 = __ballot(pw0.y >= thr) & __ballot(rel < P0.nc1);
-      const uint64_t k2 = __ballot(pw1.x >= thr) & __ballot(rel < P1.nc0);
-      const uint64_t k3 = __ballot(pw1.y >= thr) & __ballot(rel < P1.nc1);
+      // per-pixel candidate predicates: log-domain alpha test AND (NC batches) "the forward blended this Gaussian into
+      // the pixel" (rel < n_contrib); combined in scalar registers
+      uint64_t k0 = __ballot(pw0.x >= thr), k1 = __ballot(pw0.y >= thr);
+      uint64_t k2 = __ballot(pw1.x >= thr), k3 = __ballot(pw1.y >= thr);
+      if (NC) {
+        k0 &= __ballot(rel < P0.nc0); k1 &= __ballot(rel < P0.nc1);
+        k2 &= __ballot(rel < P1.nc0); k3 &= __ballot(rel < P1.nc1);
+      }
       if ((k0 | k1 | k2 | k3) == 0) return;        // nobody in the wave: the accumulators keep their zeros
       const bool c0 = __builtin_amdgcn_inverse_ballot_w64(k0), c1 = __builtin_amdgcn_inverse_ballot_w64(k1);
       const bool c2 = __builtin_amdgcn_inverse_ballot_w64(k2), c3 = __builtin_amdgcn_inverse_ballot_w64(k3);
@@ -597,7 +611,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
       const float s2 = dx * s0;                        // sum X dx^2
       float ta, tb, tc;
-      row_reduce10(s0, S.a1, s2, s3, S.a4, S.s5, S.s6, S.s7, S.s8, S.s9, ta, tb, tc);
+      row_reduce10(s0, S.a1, s2, s3, S.a4, S.a0, S.s6, S.s7, S.s8, S.s9, ta, tb, tc);
       // combine with what other quadrants found for the same instance (dummy: row kB, never read)
       if (adder) {
         float* row = myacc + j * kInstStride;
@@ -606,29 +620,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
         if (adder_c) atomicAdd(row + kc, tc);
       }
     };
+    auto run = [&](auto nc_tag) {
 #if HGS_K7_PREFETCH
-    // Two iterations per trip, the record of the NEXT iteration and the list entry of the one after it requested
-    // before the current one is composited: every row's record address depends on a list entry that is itself in LDS,
-    // and at 4 - 5 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
-    uint32_t jA = myq[0], jB = myq[4];
-    float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
-    for (int it = 0; it < nmax; it += 2) {
-      const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
-      const uint32_t jA2 = myq[(it + 2) * 4];
-      visit(jA, A0, A1, A2);
-      if (it + 1 < nmax) {
-        A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
-        const uint32_t jB2 = myq[(it + 3) * 4];
-        visit(jB, B0, B1, B2);
-        jB = jB2;
+      // Two iterations per trip, the record of the NEXT iteration and the list entry of the one after it requested
+      // before the current one is composited: every row's record address depends on a list entry that is itself in
+      // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
+      uint32_t jA = myq[0], jB = myq[4];
+      float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
+      for (int it = 0; it < nmax; it += 2) {
+        const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
+        const uint32_t jA2 = myq[(it + 2) * 4];
+        visit(nc_tag, jA, A0, A1, A2);
+        if (it + 1 < nmax) {
+          A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
+          const uint32_t jB2 = myq[(it + 3) * 4];
+          visit(nc_tag, jB, B0, B1, B2);
+          jB = jB2;
+        }
+        jA = jA2;
       }
-      jA = jA2;
-    }
 #else
-    for (int it = 0; it < nmax; ++it) {
-      const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
-      visit(j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
-    }
+      for (int it = 0; it < nmax; ++it) {
+        const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
+        visit(nc_tag, j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
+      }
+#endif
+    };
+#if HGS_K7_NCSPEC
+    if (mixed) run(std::true_type{}); else run(std::false_type{});
+#else
+    (void)mixed;
+    run(std::true_type{});
 #endif
     __syncthreads();
     // lane i stores instance i's record to its emission slot: every staged instance is written, reached or not
