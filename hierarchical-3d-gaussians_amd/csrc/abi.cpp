@@ -97,7 +97,7 @@ size_t GeomWs::bytes(int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
   const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
   return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
-         align_up((nblk + 1) * 4) + align_up(p * 9 * 4) + kAlign;
+         align_up((nblk + 1) * 4) + align_up((nblk + 1) * kBands * 4) + align_up(p * 9 * 4) + kAlign;
 }
 GeomWs GeomWs::carve_from(void* base, int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
@@ -111,6 +111,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
   g.offsets = carve<uint32_t>(c, p);
   g.flags = carve<uint32_t>(c, p);
   g.block_sums = carve<uint32_t>(c, nblk + 1);
+  g.block_band = carve<uint32_t>(c, (nblk + 1) * kBands);
   g.shjac = carve<float>(c, p * 9);
   return g;
 }
@@ -215,7 +216,7 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
   *L_out_host = 0;
   if (a->P == 0) return HGS_OK;
   if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
-  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   HGS_HIP(hipMemcpyAsync(L_out_host, g.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   HGS_HIP(hipStreamSynchronize(s));
@@ -227,10 +228,11 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
                           const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
   int rc;
-  if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, s)))) return rc;   // also zeroes b.ranges
   const bool bin = L > 0 && tile_bin_supported(T);
-  if (bin) {            // counting pass + scatter pass; writes the tile ranges too
-    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, L_dev, T, b.ranges, b.big_tiles, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, bin, s)))) return rc;   // also zeroes b.ranges
+  if (bin) {            // counting pass + scatter pass per tile band; writes the tile ranges too
+    const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
+    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, g.block_band, nblk, T, b.ranges, b.big_tiles, s, a->debug)))) return rc;
   } else {              // very large tile grids: stable radix sort by tile id, then ranges off the sorted ids
     if (L > 0) {
       if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
@@ -274,7 +276,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   *L_out_host = 0;
   if (a->P == 0) return enqueue_stage2(a, g, b, im, 0, nullptr, T, out_color, out_invdepth, s);
   if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
-  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g.block_sums, a->P, s, a->debug)))) return rc;
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   const uint32_t* L_dev = g.block_sums + nblk;
   ThreadHost* th = thread_host(device);

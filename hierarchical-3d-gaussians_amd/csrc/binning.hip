@@ -82,6 +82,140 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
 }
 
 
+// Inclusive prefix sum over the 64 lanes of a wave in six DPP adds (row_shr 1 / 2 / 4 / 8 inside each row of 16, then
+// row_bcast 15 / 31 across the rows) -- __shfl_up is a ds_bpermute per step, through the LDS pipe.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add_u32(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  v = dpp_add_u32<0x111, 0xf>(v);    // row_shr:1
+  v = dpp_add_u32<0x112, 0xf>(v);    // row_shr:2
+  v = dpp_add_u32<0x114, 0xf>(v);    // row_shr:4
+  v = dpp_add_u32<0x118, 0xf>(v);    // row_shr:8
+  v = dpp_add_u32<0x142, 0xa>(v);    // row_bcast:15 -> rows 1, 3
+  v = dpp_add_u32<0x143, 0xc>(v);    // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// The same expansion with ONE OUTPUT STREAM PER TILE BAND (common.h: kBands): an instance goes to the stream of the band
+// its tile lies in, at  band base + this workgroup's exclusive offset in the band (K1 counted, the scan kernel
+// accumulated: g.block_band) + the number of the workgroup's EARLIER Gaussians' instances in that band + the
+// instance's rank among its own Gaussian's instances in that band.  A rectangle's tiles are emitted in ascending tile
+// id, so that rank is  k - (# of the rectangle's tiles below the band's first tile), both in closed form: the slot loop
+// needs no ballots and no barriers.  The key is the BAND-LOCAL tile id.  The tile-binning kernels then run band x's
+// workgroups on XCD x, the XCD that later composites those tiles: every list is assembled in one L2.  Deterministic:
+// no atomics, the order inside a stream is (workgroup, emission order).
+__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P, int gx, int T, int per, GeomWs g,
+                                                                           uint32_t cap,
+                                                                           uint32_t* __restrict__ tile_keys,
+                                                                           uint32_t* __restrict__ vals,
+                                                                           uint32_t* __restrict__ ranges, int n_ranges) {
+  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
+  __shared__ uint32_t excl[kPreBlock + 1];
+  __shared__ uint2 lrect[kPreBlock];
+  __shared__ uint32_t wave_tot[kPreBlock / 64][kBands + 1];   // [.][kBands]: all bands
+  __shared__ uint32_t bpos[kBands];                 // where this workgroup's part of each band's stream begins
+  __shared__ uint32_t rb[kBands][kPreBlock];        // per band and Gaussian: (earlier Gaussians' instances in the band) -
+                                                    // (own tiles below the band): position of instance k = bpos + rb + k
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = blockIdx.x * kPreBlock + tid;
+  const uint32_t gid = (uint32_t)i;
+  const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
+  const uint32_t cnt = rect_count(myrect);
+  lrect[tid] = myrect;
+  // own instances per band (as K1 counted them)
+  uint32_t cb[kBands];
+#pragma unroll
+  for (int b = 0; b < kBands; ++b) cb[b] = 0u;
+  if (cnt) {
+    const int minx = (int)(myrect.x & 0xffffu), miny = (int)(myrect.x >> 16);
+    const int maxx = (int)(myrect.y & 0xffffu), maxy = (int)(myrect.y >> 16);
+    const int w = maxx - minx;
+    const int t_first = miny * gx + minx, t_last = (maxy - 1) * gx + maxx - 1;
+    int b_first = 0, b_last = 0;
+#pragma unroll
+    for (int b = 1; b < kBands; ++b) {
+      b_first += (t_first >= b * per) ? 1 : 0;
+      b_last += (t_last >= b * per) ? 1 : 0;
+    }
+    if (b_first == b_last) {
+#pragma unroll
+      for (int b = 0; b < kBands; ++b) cb[b] = (b == b_first) ? cnt : 0u;
+    } else {
+      int prev = 0;
+#pragma unroll
+      for (int b = 0; b < kBands; ++b) {
+        const int x = min((b + 1) * per, T);
+        const int xr = x / gx, xc = x - xr * gx;
+        int c = (min(max(xr, miny), maxy) - miny) * w;
+        if (xr >= miny && xr < maxy) c += min(max(xc - minx, 0), w);
+        cb[b] = (uint32_t)(c - prev);
+        prev = c;
+      }
+    }
+  }
+  // inclusive scans over the workgroup's Gaussians: all instances (emission offsets) and each band's
+  const uint32_t inc = wave_scan_incl(cnt);
+  uint32_t incb[kBands];
+#pragma unroll
+  for (int b = 0; b < kBands; ++b) incb[b] = wave_scan_incl(cb[b]);
+  if (lane == 63) {
+    wave_tot[wave][kBands] = inc;
+#pragma unroll
+    for (int b = 0; b < kBands; ++b) wave_tot[wave][b] = incb[b];
+  }
+  const int col = gridDim.x + 1;                          // column stride of g.block_band
+  if (tid < kBands) {                                     // band base = the totals of the bands before it
+    uint32_t base = 0;
+    for (int b = 0; b < tid; ++b) base += g.block_band[(size_t)b * col + gridDim.x];
+    bpos[tid] = base + g.block_band[(size_t)tid * col + blockIdx.x];
+  }
+  __syncthreads();
+  uint32_t wbase = 0;
+  for (int w = 0; w < wave; ++w) wbase += wave_tot[w][kBands];
+  const uint32_t my_excl = wbase + inc - cnt;
+  excl[tid] = my_excl;
+  if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
+  {
+    uint32_t below = 0;                                   // own tiles in the bands before b
+#pragma unroll
+    for (int b = 0; b < kBands; ++b) {
+      uint32_t wb = 0;
+      for (int w = 0; w < wave; ++w) wb += wave_tot[w][b];
+      rb[b][tid] = wb + incb[b] - cb[b] - below;          // (may wrap: added to k >= below modulo 2^32)
+      below += cb[b];
+    }
+  }
+  const uint32_t block_base = g.block_sums[blockIdx.x];
+  if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run (K7 / K8 slots)
+  __syncthreads();
+  const uint32_t total = excl[kPreBlock];
+  for (uint32_t s = tid; s < total; s += kPreBlock) {
+    // largest j with excl[j] <= s (zero-count entries are skipped: the search lands on the LAST index whose start is <= s)
+    int lo = 0, hi = kPreBlock;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int mid = (lo + hi) >> 1;
+      if (excl[mid] <= s) lo = mid; else hi = mid;
+    }
+    const uint32_t gg = blockIdx.x * kPreBlock + lo;
+    const uint32_t k = s - excl[lo];
+    const uint2 rc = lrect[lo];
+    const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
+    const uint32_t w = (rc.y & 0xffffu) - minx;
+    const uint32_t tile = (miny + k / w) * (uint32_t)gx + minx + k % w;
+    uint32_t band = 0;                                    // number of band boundaries <= tile: no per-lane division
+#pragma unroll
+    for (int b = 1; b < kBands; ++b) band += (tile >= (uint32_t)(b * per)) ? 1u : 0u;
+    const uint32_t pos = bpos[band] + rb[band][lo] + k;
+    if (pos < cap) {       // cap < L only when a speculative capacity was too small (caller retries)
+      tile_keys[pos] = tile - band * (uint32_t)per;
+      vals[pos] = gg;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Per-tile depth sort.  vals[r0..r1) holds a tile's Gaussian ids in ascending order; afterwards it
 // holds them ordered by (depth bits, id).
@@ -397,12 +531,17 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 }  // namespace
 
-int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s) {
+int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
+                           hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0 && L_cap > 0) {
     const int T = grid_x(a.width) * grid_y(a.height);
-    hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
-                       b.keys_in, b.vals_in, b.ranges, T * 2);
+    if (banded)
+      hipLaunchKernelGGL(duplicate_tiles_banded_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), T,
+                         band_tiles(T), g, L_cap, b.keys_in, b.vals_in, b.ranges, T * 2);
+    else
+      hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
+                         b.keys_in, b.vals_in, b.ranges, T * 2);
     HGS_LAUNCH_CHECK("duplicate_tiles", s, a.debug);
   } else {
     HGS_HIP(hipMemsetAsync(b.ranges, 0, (size_t)grid_x(a.width) * grid_y(a.height) * 2 * sizeof(uint32_t), s));

@@ -48,6 +48,11 @@ constexpr int kRecFloats = 16;              // per-Gaussian 2D record, 4 x float
 constexpr int kRecVec = kRecFloats / 4;
 constexpr int kInstStride = HGS_INST_GRAD_STRIDE;
 constexpr int kPreBlock = 256;              // Gaussians per preprocess / binning workgroup
+// Tile BANDS: band x = tiles [x * per, (x + 1) * per), per = ceil(T / 8) -- the eighth of the frame that XCD x composites
+// (render.hip: block_to_tile).  The binning keeps one instance stream per band and runs the kernels that touch band x's
+// lists on XCD x (workgroup b runs on XCD b % 8), so that a list's cache lines are assembled in ONE L2.
+constexpr int kBands = 8;
+__host__ __device__ inline int band_tiles(int T) { return (T + kBands - 1) / kBands; }
 
 // ---- workspace layouts ------------------------------------------------------
 struct GeomWs {
@@ -58,6 +63,8 @@ struct GeomWs {
   uint32_t* offsets;       // [P] exclusive
   uint32_t* flags;         // [P] bit0..2 colour clamp, bit3 tx clamped, bit4 ty clamped
   uint32_t* block_sums;    // [nblk+1] exclusive scan of per-workgroup instance counts (index order); [nblk] = L
+  uint32_t* block_band;    // [kBands][nblk+1] the same per tile band: column b = exclusive scan of the workgroups' counts of
+                           // instances whose tile lies in band b; [b][nblk] = the band's total
   float* shjac;            // [P,9] d(rgb)/d(view direction), rows = direction component (hgs_raster_args.prepare_backward)
   static size_t bytes(int32_t P);
   static GeomWs carve_from(void* base, int32_t P);
@@ -93,8 +100,11 @@ inline int tile_bits(int T) {
 
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
-int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug);
-int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, hipStream_t s);
+// scans block_sums and the kBands columns of block_band (one launch, one workgroup per array)
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug);
+// banded: one instance stream per tile band (b.keys_in = band-local tile ids), else one stream of global tile ids
+int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
+                           hipStream_t s);
 int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug);
 // b.tile_order from the final b.ranges (one small workgroup; counting sort over quantised instance counts)
 int launch_tile_order(const BinWs& b, int32_t T, hipStream_t s, bool debug);
@@ -148,8 +158,11 @@ inline size_t bwd_ws_bytes(uint32_t L, int32_t P) {
 // tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
 bool tile_bin_supported(int32_t T);
 size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);
+// keys / vals: the banded streams of launch_duplicate_tiles; band_totals: g.block_band (column stride nblk + 1, totals in
+// row nblk)
 int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
-                    const uint32_t* L_dev, int32_t T, uint32_t* ranges, uint32_t* big, hipStream_t s, bool debug);
+                    const uint32_t* band_totals, int32_t nblk, int32_t T, uint32_t* ranges, uint32_t* big, hipStream_t s,
+                    bool debug);
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);

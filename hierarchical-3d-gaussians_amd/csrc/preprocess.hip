@@ -273,6 +273,9 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds_sh = reinterpret_cast<float*>(smem_raw);
   __shared__ uint32_t wave_tot[kPreBlock / 64];
+  __shared__ uint32_t band_cnt[kBands];          // this workgroup's instances per tile band (binning: band streams)
+  if (threadIdx.x < kBands) band_cnt[threadIdx.x] = 0u;
+  __syncthreads();
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const int gx = (a.width + kTile - 1) / kTile;
   const int gy = (a.height + kTile - 1) / kTile;
@@ -464,6 +467,32 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
     g.tiles_touched[idx] = touched;
     g.flags[idx] = flags;
   }
+  if (idx < a.P && pr.visible) {
+      // instances per tile band.  Almost every rectangle lies inside ONE band (first and last tile in the same band:
+      // seven compares each, no division); one that straddles boundaries counts (# of its tiles with id < x) at the
+      // boundaries x = b * per it spans, in closed form.
+      const int T = gx * gy, per = band_tiles(T), w = pr.maxx - pr.minx;
+      const int t_first = pr.miny * gx + pr.minx, t_last = (pr.maxy - 1) * gx + pr.maxx - 1;
+      int b_first = 0, b_last = 0;
+#pragma unroll
+      for (int b = 1; b < kBands; ++b) {
+        b_first += (t_first >= b * per) ? 1 : 0;
+        b_last += (t_last >= b * per) ? 1 : 0;
+      }
+      if (b_first == b_last) {
+        atomicAdd(&band_cnt[b_first], touched);
+      } else {
+        int prev = 0;
+        for (int b = b_first; b <= b_last; ++b) {
+          const int x = min((b + 1) * per, T);
+          const int xr = x / gx, xc = x - xr * gx;
+          int cnt = (min(max(xr, pr.miny), pr.maxy) - pr.miny) * w;
+          if (xr >= pr.miny && xr < pr.maxy) cnt += min(max(xc - pr.minx, 0), w);
+          if (cnt > prev) atomicAdd(&band_cnt[b], (uint32_t)(cnt - prev));
+          prev = cnt;
+        }
+      }
+    }
   // per-workgroup instance count (feeds the offsets scan)
   const uint32_t ws = wave_sum_u32(touched);
   if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
@@ -474,10 +503,14 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
     for (int w = 0; w < kPreBlock / 64; ++w) t += wave_tot[w];
     g.block_sums[blockIdx.x] = t;
   }
+  if (threadIdx.x < kBands) g.block_band[(size_t)threadIdx.x * (gridDim.x + 1) + blockIdx.x] = band_cnt[threadIdx.x];
 }
 
-// Exclusive scan of the per-workgroup sums (single workgroup; nblk = P/256).
-__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums, int n) {
+// Exclusive scan of the per-workgroup sums (nblk = P/256): workgroup 0 scans block_sums, workgroups 1..kBands the
+// columns of block_band; every array has n + 1 entries, the total lands in entry n.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums0,
+                                                               uint32_t* __restrict__ bands, int n) {
+  uint32_t* __restrict__ sums = blockIdx.x == 0 ? sums0 : bands + (size_t)(blockIdx.x - 1) * (n + 1);
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1252,9 +1285,9 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   return HGS_OK;
 }
 
-int launch_scan_block_sums(uint32_t* sums, int32_t P, hipStream_t s, bool debug) {
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nblk);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band, nblk);
   HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
   return HGS_OK;
 }
