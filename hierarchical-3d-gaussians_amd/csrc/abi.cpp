@@ -232,7 +232,7 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
   if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, bin, s)))) return rc;   // also zeroes b.ranges
   if (bin) {            // counting pass + scatter pass per tile band; writes the tile ranges too
     const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
-    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, g.block_band, nblk, T, b.ranges, b.big_tiles, s, a->debug)))) return rc;
+    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, g.block_band, nblk, T, b.ranges, b.big_tiles, b.tile_order, s, a->debug)))) return rc;
   } else {              // very large tile grids: stable radix sort by tile id, then ranges off the sorted ids
     if (L > 0) {
       if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
@@ -240,7 +240,7 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
     if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
   }
   if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
-  if ((rc = launch_tile_order(b, T, s, a->debug))) return rc;     // ~3 us; counted with the compositing stage it serves
+  if (!bin && (rc = launch_tile_order(b, T, s, a->debug))) return rc;   // (the binning path orders inside its scatter launch)
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
 }
 

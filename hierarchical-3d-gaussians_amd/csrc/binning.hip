@@ -358,7 +358,7 @@ __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths,
   }
 }
 
-constexpr uint32_t kWaveCap = 512;      // one wave, 8 keys per lane
+constexpr uint32_t kWaveCap = 1024;     // one wave, 16 keys per lane
 
 // One wave per tile (4 tiles per workgroup, no inter-wave communication).  Tiles above kWaveCap instances are filed
 // into the class lists: big[0] / big[1] / big[2] = number of large / huge / medium tiles; big + 3: large list [T],
@@ -385,21 +385,21 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_
   }
   if (n <= 128) wave_sort_tile<2>(depths, vals, r0, n, lane);
   else if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
-  else wave_sort_tile<8>(depths, vals, r0, n, lane);
+  else if (n <= 512) wave_sort_tile<8>(depths, vals, r0, n, lane);
+  else wave_sort_tile<16>(depths, vals, r0, n, lane);
 }
 
-// Medium class (kWaveCap < n <= kSmallCap): 256-lane bitonic sort in 16 KiB of LDS, one workgroup per listed tile.
-__global__ __launch_bounds__(256) void tile_depth_sort_medium_kernel(const uint32_t* __restrict__ ranges,
-                                                                     const float* __restrict__ depths,
-                                                                     uint32_t* __restrict__ vals,
-                                                                     const uint32_t* __restrict__ big, int T) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Medium class (kWaveCap < n <= kSmallCap): bitonic sort in LDS, one workgroup per listed tile (same launch as the two
+// larger classes: above 1024 instances per tile all three lists are short, a launch of their own costs more than the work)
+__device__ __forceinline__ void sort_medium_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
+                                                  const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                                  const uint32_t* __restrict__ big, int T) {
   const uint32_t count = big[2];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
     const uint32_t tile = big[3 + 2 * T + e];
     const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
     __syncthreads();
-    sort_tile_in_lds<256>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
+    sort_tile_in_lds<1024>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
   }
 }
 
@@ -494,7 +494,7 @@ __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ran
   }   // tile loop
 }
 
-// One launch for both oversized classes (their lists are almost always empty: a second launch would cost more
+// One launch for the three oversized classes (their lists are almost always empty: a launch each would cost more
 // than the work).  128 KiB of dynamic LDS for the large class + 18 KiB static for the huge class.
 __global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
@@ -504,6 +504,8 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_
                                                                    uint32_t* __restrict__ scratch_k2,
                                                                    const uint32_t* __restrict__ big, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  sort_medium_tiles(smem, ranges, depths, vals, big, T);
+  __syncthreads();
   sort_large_tiles(smem, ranges, depths, vals, big, T);
   __syncthreads();
   sort_huge_tiles(ranges, depths, vals, scratch_k, scratch_v, scratch_k2, big, T);
@@ -571,10 +573,6 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out,
                      b.big_tiles, T, fill_tile_ids ? b.keys_out : nullptr);
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
-  const int med_grid = T < 2048 ? T : 2048;
-  hipLaunchKernelGGL(tile_depth_sort_medium_kernel, dim3(med_grid), dim3(256), kSmallCap * 8, s, b.ranges, g.depths,
-                     b.vals_out, b.big_tiles, T);
-  HGS_LAUNCH_CHECK("tile_depth_sort_medium", s, a.debug);
   const int big_grid = T < 256 ? T : 256;
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   hipLaunchKernelGGL(tile_depth_sort_big_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,

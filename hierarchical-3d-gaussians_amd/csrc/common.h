@@ -161,8 +161,8 @@ size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);
 // keys / vals: the banded streams of launch_duplicate_tiles; band_totals: g.block_band (column stride nblk + 1, totals in
 // row nblk)
 int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
-                    const uint32_t* band_totals, int32_t nblk, int32_t T, uint32_t* ranges, uint32_t* big, hipStream_t s,
-                    bool debug);
+                    const uint32_t* band_totals, int32_t nblk, int32_t T, uint32_t* ranges, uint32_t* big,
+                    uint32_t* tile_order, hipStream_t s, bool debug);
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);

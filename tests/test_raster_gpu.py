@@ -296,10 +296,12 @@ def test_4k_8m_gaussians_forward_backward(gpu):
     assert worst <= 1e-5
 
 
-@pytest.mark.parametrize("P,W,H", [(150_000, 64, 64), (1_500_000, 64, 48)])
-def test_crowded_tiles_sort_paths(gpu, P, W, H):
-    """Tiles holding thousands (LDS sort with 1024 lanes) and > 16 Ki (global radix fallback) instances:
-    the sorted instance list must still be bit-exact.  Forward only; oracle = geometry + binning spec."""
+@pytest.mark.parametrize("P,W,H,lo,hi", [(6_000, 64, 48, 512, 1024), (12_000, 64, 48, 1024, 2048),
+                                         (130_000, 64, 64, 2048, 16384), (1_500_000, 64, 48, 16384, 1 << 30)])
+def test_crowded_tiles_sort_paths(gpu, P, W, H, lo, hi):
+    """Every class of the per-tile depth sort: one wave with 16 keys per lane (513 .. 1024 instances), the LDS sorts
+    (.. 2048 and .. 16 Ki, 1024 lanes) and the global radix fallback (> 16 Ki): the sorted instance list must still
+    be bit-exact.  Forward only; oracle = geometry + binning spec."""
     import diff_gaussian_rasterization as dgr
     from oracle import raster_oracle as ro
     cam = synth.make_camera(W, H)
@@ -311,7 +313,7 @@ def test_crowded_tiles_sort_paths(gpu, P, W, H):
                             cam.tanfovx, cam.tanfovy, 1.0)
     binning = ro.binning_spec(geom)
     per_tile = binning.ranges[:, 1] - binning.ranges[:, 0]
-    assert per_tile.max() > (16384 if P > 1_000_000 else 2048), per_tile.max()
+    assert lo < per_tile.max() <= hi, per_tile.max()
     rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
     sc = scene.to(gpu)
     with torch.no_grad():
