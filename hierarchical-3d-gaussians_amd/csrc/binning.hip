@@ -220,7 +220,6 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
 // Per-tile depth sort.  vals[r0..r1) holds a tile's Gaussian ids in ascending order; afterwards it
 // holds them ordered by (depth bits, id).
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kSmallCap = 2048;    // 256-thread workgroup, 16 KiB LDS
 constexpr uint32_t kLargeCap = 16384;   // 1024-thread workgroup, 128 KiB LDS
 
 template <int THREADS>
@@ -359,38 +358,111 @@ __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths,
 }
 
 constexpr uint32_t kWaveCap = 1024;     // one wave, 16 keys per lane
+constexpr uint32_t kQuadCap = 4096;     // the four waves of a workgroup together
 
-// One wave per tile (4 tiles per workgroup, no inter-wave communication).  Tiles above kWaveCap instances are filed
-// into the class lists: big[0] / big[1] / big[2] = number of large / huge / medium tiles; big + 3: large list [T],
-// huge list [T], medium list [T].
+// ---- 1025 .. 4096 instances: the workgroup's FOUR waves sort one tile together ------------------------------------------
+// Every wave sorts a block of 1024 keys in registers (the network above, blocks alternately ascending / descending: the
+// direction bits of `base` include the wave), then the remaining stages of the bitonic network over 2048 and 4096 keys
+// run: a stage whose partner distance is >= 1024 pairs keys of two WAVES and goes through LDS (write the block, barrier,
+// read the partner's key: three such round trips in all), the stages below it are again in registers.  The LDS-only
+// network used for larger tiles pays a workgroup barrier for each of its 78 stages at this size.
+template <int K>
+__device__ __forceinline__ void quad_cross_stage(uint64_t (&key)[16], uint64_t* lk, uint32_t base, int J) {
+  __syncthreads();                              // the previous round trip's reads are done
+#pragma unroll
+  for (int e = 0; e < 16; ++e) lk[base + e] = key[e];
+  __syncthreads();
+  const bool lower = (base & (uint32_t)J) == 0;
+  const bool up = (base & (uint32_t)K) == 0;
+  const bool keep_min = lower == up;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint64_t other = lk[(base + e) ^ (uint32_t)J];
+    const bool other_less = other < key[e];
+    key[e] = (other_less == keep_min) ? other : key[e];
+  }
+}
+
+__device__ __forceinline__ void quad_sort_tile(uint64_t* lk, const float* __restrict__ depths,
+                                               uint32_t* __restrict__ vals, uint32_t r0, uint32_t n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t key[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {                // coalesced load: any permutation inside the wave's block will do
+    const uint32_t i = (uint32_t)(wave * 1024 + e * 64 + lane);
+    uint64_t k = ~0ull;
+    if (i < n) {
+      const uint32_t gid = vals[r0 + i];
+      k = ((uint64_t)__float_as_uint(depths[gid]) << 32) | gid;
+    }
+    key[e] = k;
+  }
+  const uint32_t base = (uint32_t)(wave * 1024 + lane * 16);
+  wave_sort_network<16, 2>(key, lane, base);                  // blocks of 1024, directions by bit 10 of the index
+  quad_cross_stage<2048>(key, lk, base, 1024);
+  wave_sort_block<16, 2048, 512>(key, lane, base);
+  if (n > 2048) {                                             // uniform
+    quad_cross_stage<4096>(key, lk, base, 2048);
+    quad_cross_stage<4096>(key, lk, base, 1024);
+    wave_sort_block<16, 4096, 512>(key, lane, base);
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const uint32_t i = base + (uint32_t)e;
+    if (i < n) vals[r0 + i] = (uint32_t)key[e];
+  }
+}
+
+// One wave per tile (4 tiles per workgroup) up to kWaveCap instances.  QUAD: a tile with up to kQuadCap is then sorted
+// by the workgroup's four waves together (32 KiB of LDS: chosen by the host when the frame's mean list length says such
+// tiles are common; it costs the one-wave path a fifth of its occupancy).  Larger tiles are filed into the class lists:
+// big[0] / big[1] / big[2] = number of large / huge / medium tiles; big + 3: large list [T], huge list [T], medium list
+// [T] (medium = kWaveCap < n <= kSmallCap, only without QUAD).
+constexpr uint32_t kSmallCap = 2048;
+template <bool QUAD>
 __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
                                                                    uint32_t* __restrict__ vals, uint32_t* big, int T,
                                                                    uint32_t* __restrict__ tile_ids) {
-  const int lane = threadIdx.x & 63;
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tile >= T) return;
-  const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
-  const uint32_t n = r1 - r0;
+  __shared__ uint64_t lk[QUAD ? kQuadCap : 1];
+  __shared__ uint32_t quad_n[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int tile = blockIdx.x * 4 + wave;
+  uint32_t r0 = 0, n = 0;
+  if (tile < T) {
+    r0 = ranges[tile * 2 + 0];
+    n = ranges[tile * 2 + 1] - r0;
+  }
   if (tile_ids)          // sorted tile-id column (introspection / parity tests) when no global sort produced it
     for (uint32_t i = (uint32_t)lane; i < n; i += 64u) tile_ids[r0 + i] = (uint32_t)tile;
-  if (n <= 1) return;
-  if (n > kWaveCap) {
-    if (lane == 0) {
-      const int cls = n > kLargeCap ? 1 : (n > kSmallCap ? 0 : 2);
+  if (lane == 0) {
+    if (QUAD) quad_n[wave] = (n > kWaveCap && n <= kQuadCap) ? n : 0u;
+    if (n > (QUAD ? kQuadCap : kWaveCap)) {
+      const int cls = n > kLargeCap ? 1 : ((QUAD || n > kSmallCap) ? 0 : 2);
       const uint32_t slot = atomicAdd(&big[cls], 1u);
       big[3 + cls * T + slot] = (uint32_t)tile;
     }
-    return;
   }
-  if (n <= 128) wave_sort_tile<2>(depths, vals, r0, n, lane);
-  else if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
-  else if (n <= 512) wave_sort_tile<8>(depths, vals, r0, n, lane);
-  else wave_sort_tile<16>(depths, vals, r0, n, lane);
+  if (n > 1 && n <= kWaveCap) {
+    if (n <= 128) wave_sort_tile<2>(depths, vals, r0, n, lane);
+    else if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
+    else if (n <= 512) wave_sort_tile<8>(depths, vals, r0, n, lane);
+    else wave_sort_tile<16>(depths, vals, r0, n, lane);
+  }
+  if constexpr (QUAD) {
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {                 // uniform: the four tiles of this workgroup, one after the other
+      const uint32_t qn = quad_n[w];
+      if (qn == 0) continue;
+      const int t = blockIdx.x * 4 + w;
+      quad_sort_tile(lk, depths, vals, ranges[t * 2 + 0], qn);
+      __syncthreads();
+    }
+  }
 }
 
-// Medium class (kWaveCap < n <= kSmallCap): bitonic sort in LDS, one workgroup per listed tile (same launch as the two
-// larger classes: above 1024 instances per tile all three lists are short, a launch of their own costs more than the work)
+// Medium class without QUAD (kWaveCap < n <= kSmallCap): bitonic sort in LDS, one workgroup per listed tile (same launch
+// as the two larger classes: a launch of their own costs more than the work when the lists are short)
 __device__ __forceinline__ void sort_medium_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
                                                   const float* __restrict__ depths, uint32_t* __restrict__ vals,
                                                   const uint32_t* __restrict__ big, int T) {
@@ -494,8 +566,8 @@ __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ran
   }   // tile loop
 }
 
-// One launch for the three oversized classes (their lists are almost always empty: a launch each would cost more
-// than the work).  128 KiB of dynamic LDS for the large class + 18 KiB static for the huge class.
+// One launch for the oversized classes (their lists are almost always empty: a launch each would cost more than the
+// work).  128 KiB of dynamic LDS for the large class + 18 KiB static for the huge class.
 __global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
                                                                    uint32_t* __restrict__ vals,
@@ -570,8 +642,11 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
     attr_set = true;
   }
-  hipLaunchKernelGGL(tile_depth_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out,
-                     b.big_tiles, T, fill_tile_ids ? b.keys_out : nullptr);
+  // lists of more than 1024 instances are common when the mean list is long: then the four-wave variant
+  const bool quad = (uint64_t)L > (uint64_t)T * 512u;
+  auto kern = quad ? tile_depth_sort_wave_kernel<true> : tile_depth_sort_wave_kernel<false>;
+  hipLaunchKernelGGL(kern, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out, b.big_tiles, T,
+                     fill_tile_ids ? b.keys_out : nullptr);
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
   const int big_grid = T < 256 ? T : 256;
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done

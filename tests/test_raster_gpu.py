@@ -333,6 +333,40 @@ def test_crowded_tiles_sort_paths(gpu, P, W, H, lo, hi):
     assert torch.equal(color, color2)
 
 
+def test_one_crowded_tile_in_a_light_frame(gpu):
+    """A light frame (mean list far below 512: the one-wave depth sort without the four-wave stage) with ONE tile holding
+    ~1 500 instances: that tile goes through the class list and the LDS sort of the oversized-classes launch."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W, H = 640, 368
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(20_000, cam, seed=17, s_px=(0.4, 1.5))
+    g = torch.Generator().manual_seed(18)
+    n = 1500                                   # a cluster projecting into the tile around pixel (328, 200)
+    z = 4.0 + 2.0 * torch.rand(n, generator=g)
+    fx = W / (2.0 * cam.tanfovx)
+    scene.means3D[:n, 0] = (328.0 + 6.0 * (torch.rand(n, generator=g) - 0.5) - W / 2) / fx * z
+    scene.means3D[:n, 1] = (200.0 + 6.0 * (torch.rand(n, generator=g) - 0.5) - H / 2) / fx * z
+    scene.means3D[:n, 2] = torch.round(z * 8) / 8          # depth ties: the Gaussian-index tie-break
+    scene.scales[:n] = (z * 0.5 / fx)[:, None] * torch.ones(n, 3)
+    geom = ro.geometry_spec(scene.means3D.numpy(), scene.scales.numpy(), scene.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            cam.tanfovx, cam.tanfovy, 1.0)
+    binning = ro.binning_spec(geom)
+    per_tile = binning.ranges[:, 1] - binning.ranges[:, 0]
+    assert 1024 < per_tile.max() <= 2048 and binning.num_rendered < 400 * per_tile.shape[0], (per_tile.max(), binning.num_rendered)
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    sc = scene.to(gpu)
+    L, color, radii, geomb, binb, img, invd, call = dgr._C.rasterize_gaussians(
+        rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+        rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+        rs.interpolation_weights, rs.num_node_kids, True)
+    v = dgr._C.raster_views(call)
+    assert L == binning.num_rendered
+    assert np.array_equal(v["ranges"].cpu().numpy(), binning.ranges)
+    assert np.array_equal(v["point_list"].cpu().numpy(), binning.point_list)
+
+
 def test_gradient_accumulation_into_caller_buffers(gpu):
     """Data-parallel host path (RasterContext.grad_buffers): the backward writes straight into a flat bucket and
     ACCUMULATES the second view's gradients in place; the result must equal the sum of the two views' separately
