@@ -212,10 +212,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
-    if len(_last_L) > 64:
-        _last_L.clear()
     # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
+    _last_L.pop(shape_key, None)                       # (re-inserted at the end: the dict is kept in order of last use)
     _last_L[shape_key] = L.value if lod is None else max(L.value, int(0.9 * (prev or 0)))
+    while len(_last_L) > 64:                           # forget the shape that was used longest ago
+        _last_L.pop(next(iter(_last_L)))
     stats["last_L"] = L.value
     call = _Call()
     call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
