@@ -742,11 +742,15 @@ def main():
                 sb, stages, dom,
                 "SURVEY.md §8(d): render_bwd = 24 N + 44 L + 40 V (N pixels, L tile instances, V visible Gaussians: means "
                 "over the views of THIS run); avg_ms = hipEvents around every launch inside the timed steps",
-                {"traffic": traffic,
+                {"traffic": traffic, "traffic_upper": (traffic_db or {}).get(dom + "_upper"),
                  "traffic_source": (f"{traffic_path}['{dom}'] (run id {traffic_db.get('_run', 'unknown')}, kernel sources "
                                     f"{src_sha} = this build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                    "command, (2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction) -- a "
-                                    "committed profile, NOT measured in this run") if traffic else
+                                    "command -- a committed profile, NOT measured in this run.  Streaming kernels: "
+                                    "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction of the guide); the "
+                                    "compositing kernels read 64-byte records at random places, for which FETCH_SIZE "
+                                    "is exact (profiles/r03_microbench_gather_fetch.txt): FETCH_SIZE KiB + half of "
+                                    "the streamed reads of the byte model + WRITE_SIZE KiB; traffic_upper = the "
+                                    "uncorrected 2*FETCH_SIZE figure") if traffic else
                                    (f"dropped: profiles/pmc_traffic.json (run {stale_t}) was collected on another "
                                     "build of the kernels" if stale_t else None),
                  "impl_bytes": ab[dom], "impl_achieved": ab[dom] / sec / 1e9,

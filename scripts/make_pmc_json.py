@@ -6,7 +6,11 @@ per-kernel PMC summary written by scripts/pmc_summary.py, and stamp them with th
     python scripts/make_pmc_json.py profiles/r02_runNN_pmc.json r02_runNN [profiles/r02_microbench_valu_issue.txt]
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB and gfx950's
-FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section).
+FETCH_SIZE counts 128-byte requests as 64 (MI355X_MICROARCH.md, HBM / rocprofv3 section).  That correction holds for
+wide streaming reads.  The two compositing kernels read 64-byte records at random places: there FETCH_SIZE is exact
+(profiles/r03_microbench_gather_fetch.txt: 255 MiB counted for 256 MiB gathered), so for them
+HBM bytes = FETCH_SIZE * 1024 + S / 2 + WRITE_SIZE * 1024 with S = the kernel's STREAMED reads by the byte model (pixel
+planes + the tiles' id lists, counted at half by the counter); the uncorrected 2 * FETCH figure is kept as `*_upper`.
 The VALU roof (``_peak_ginst_s``) is taken from the issue-rate microbenchmark (scripts/microbench/valu_issue.hip): the
 line of K7's instruction mix at 5 waves per SIMD, the occupancy K7 runs at."""
 import json
@@ -33,19 +37,31 @@ def main():
     sha = d.get("_src_sha") or bench.kernel_source_sha()
     head = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT), "_src_sha": sha}
     traffic, valu = dict(head), dict(head)
-    d = {k: v for k, v in d.items() if not k.startswith("_")}
+    d = {k: v for k, v in d.items() if not k.startswith("_") or k == "_L"}
+    # streamed reads of the gather kernels at the configuration the PMC passes run (bench.py defaults: 1920x1080, L from
+    # the run): K6 reads the id list (4 L); K7 the id list + dL/dcolor, dL/dinvdepth, final_T, n_contrib (24 N)
+    N, L = 1920 * 1080, float(d.get("_L", 2_660_211))
+    streamed = {"render_fwd": 4 * L, "render_bwd": 4 * L + 24 * N}
     for stage, pats in STAGES.items():
-        tot = 0.0
+        tot = upper = 0.0
         for p in pats:      # template variants of one kernel (accumulate on / off ...) are averaged, not added
-            vals = [(2 * cs["FETCH_SIZE"] + cs.get("WRITE_SIZE", 0.0)) * 1024 for k, cs in d.items()
-                    if p in k and "FETCH_SIZE" in cs]
-            if vals:
-                tot += sum(vals) / len(vals) * PER_FRAME.get(p, 1)
+            sel = [cs for k, cs in d.items() if isinstance(cs, dict) and p in k and "FETCH_SIZE" in cs]
+            if not sel:
+                continue
+            up = sum((2 * cs["FETCH_SIZE"] + cs.get("WRITE_SIZE", 0.0)) * 1024 for cs in sel) / len(sel)
+            if stage in streamed:
+                val = sum((cs["FETCH_SIZE"] + cs.get("WRITE_SIZE", 0.0)) * 1024 for cs in sel) / len(sel) + streamed[stage] / 2
+            else:
+                val = up
+            tot += val * PER_FRAME.get(p, 1)
+            upper += up * PER_FRAME.get(p, 1)
         if tot:
             traffic[stage] = tot
+            if stage in streamed:
+                traffic[stage + "_upper"] = upper
     for stage in ("render_bwd", "render_fwd"):
         for k, cs in d.items():
-            if STAGES[stage][0] in k and "SQ_INSTS_VALU" in cs:
+            if isinstance(cs, dict) and STAGES[stage][0] in k and "SQ_INSTS_VALU" in cs:
                 w = cs.get("SQ_WAVES", 0.0) or 1.0
                 valu[stage] = {"valu_insts_per_launch": cs["SQ_INSTS_VALU"], "salu_insts_per_launch": cs.get("SQ_INSTS_SALU"),
                                "waves": cs.get("SQ_WAVES"),
