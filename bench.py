@@ -348,11 +348,14 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     tau = (2 * tau_px + 1) * cam.tanfovx / (0.5 * W)                   # render_hierarchy.py:55-56
     m2 = torch.zeros(G, 3, device=dev)
     sc, zero3 = torch.exp(h.log_scales), torch.zeros(3)
-    st = {"i": 0, "n": [], "L": []}
+    st = {"i": 0, "n": [], "L": [], "cut_s": 0.0}
+    from diff_gaussian_rasterization import _C as dgrC
 
     def frame():
         j = st["i"] % len(cams); st["i"] += 1
-        n = expand_to_size(h.nodes, h.boxes, tau, vps[j][0], zero3, ri, pi, ni)
+        t_a = time.perf_counter()
+        n = expand_to_size(h.nodes, h.boxes, tau, vps[j][0], zero3, ri, pi, ni)     # returns the count: host sync
+        st["cut_s"] += time.perf_counter() - t_a
         get_interpolation_weights(ni[:n], tau, h.nodes, h.boxes, vps[j][1], zero3, w, ns)
         rs = _settings(dgr, cams[j], dev, do_depth=False, interpolation_weights=w, num_node_kids=ns,
                        render_indices=ri[:n], parent_indices=pi)
@@ -366,12 +369,14 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     for _ in range(warmup):
         frame()
     torch.cuda.synchronize()
-    st["n"].clear(); st["L"].clear()
+    st["n"].clear(); st["L"].clear(); st["cut_s"] = 0.0
+    miss0 = dgrC.stats["capacity_misses"]
     t0 = time.perf_counter()
     for _ in range(steps):
         frame()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    cut_ms, misses = st["cut_s"] / steps * 1e3, dgrC.stats["capacity_misses"] - miss0
     _lib.timing_read(reset=True)
     _lib.timing_enable(True)
     for _ in range(3):
@@ -386,7 +391,9 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
            "metric": "rendered frames/s @ 3840x2160", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
            "config": {"hierarchy_nodes": G, "leaves": leaves, "tau_px": tau_px, "mean_cut": nm, "width": W, "height": H,
-                      "hierarchy_build_s": t_build, "resident_bytes": int(G * (59 * 4 + 28 + 32))},
+                      "hierarchy_build_s": t_build, "resident_bytes": int(G * (59 * 4 + 28 + 32)),
+                      "capacity_misses": misses,
+                      "expand_to_size_ms": cut_ms},     # host time of the cut incl. the wait for everything enqueued before it
            "stages_ms": stages}
     if stages.get("render_fwd") and stages.get("preprocess_fwd"):
         N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)

@@ -20,8 +20,8 @@
 //    (tests/tools/quad_stats.py).
 //  * a lane's four pixels share x (rows y0, y0+2, y0+4, y0+6 of its quadrant) and go through the instruction stream as
 //    two PACKED pairs (float2): compares, selects, min / max, exp and rcp have no packed form and are halved by that.
-//  * alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity): the per-lane candidate predicate; when no lane of the wave
-//    has a candidate the iteration ends before the exp.  The exact alpha test still takes every borderline decision.
+//  * alpha >= 1/255  <=>  power2 >= log2(1/255) - log2(opacity): the backward's per-lane candidate predicate (log domain,
+//    before the exp).  The exact alpha test still takes every borderline decision.
 //  * pixel coordinates are TILE-RELATIVE: the record carries the pixel centre as hi + lo floats from K1's
 //    double-precision projection; (hi - tile_origin) + lo is exact to ~1e-6 px at any resolution.
 //  * a finished / outside pixel is moved to y = 1e18 (never a candidate again): "done" needs no flag.
@@ -303,15 +303,13 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const float thr = q2.z;
       const uint32_t idx1 = base - r0 + j + 1;
       const f2 dy0 = gyt - P0.fly;
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 dy1 = gyt - P1.fly;
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-      // nobody in the wave is a candidate (boxes are conservative): leave before the exp.  A finished / outside pixel
-      // sits at y = kBig and is never a candidate.
-      if (__ballot(fmaxf(fmaxf(pw0.x, pw0.y), fmaxf(pw1.x, pw1.y)) >= thr) == 0) return;
+      // (no wave-level "nobody is a candidate" exit: with the exact quadrant test it almost never fires, and the three
+      // maxima and the compare it needs cost 4 % of the kernel)
       fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
       fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
     };
@@ -649,7 +647,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
         k0 &= __ballot(rel < P0.nc0); k1 &= __ballot(rel < P0.nc1);
         k2 &= __ballot(rel < P1.nc0); k3 &= __ballot(rel < P1.nc1);
       }
-      if ((k0 | k1 | k2 | k3) == 0) return;        // nobody in the wave: the accumulators keep their zeros
+      // (no "nobody in the wave is a candidate" exit: with the exact quadrant test it almost never fires, and the branch
+      // costs the scheduler more than it saves)
       const bool c0 = __builtin_amdgcn_inverse_ballot_w64(k0), c1 = __builtin_amdgcn_inverse_ballot_w64(k1);
       const bool c2 = __builtin_amdgcn_inverse_ballot_w64(k2), c3 = __builtin_amdgcn_inverse_ballot_w64(k3);
       const f2 q2 = f2{q2v.x, q2v.y};
