@@ -121,7 +121,15 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blockIdx.x * kPreBlock + tid;
   const uint32_t gid = (uint32_t)i;
+  // every global load of the prologue is issued here, together: the kernel is latency-bound (3 900 small workgroups)
   const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
+  const uint32_t block_base = g.block_sums[blockIdx.x];
+  const int col = gridDim.x + 1;                          // column stride of g.block_band
+  uint32_t band_tot = 0, band_off = 0;                    // lanes 0..7 of wave 0: total of band `tid`, this workgroup's offset in it
+  if (tid < kBands) {
+    band_tot = g.block_band[(size_t)tid * col + gridDim.x];
+    band_off = g.block_band[(size_t)tid * col + blockIdx.x];
+  }
   const uint32_t cnt = rect_count(myrect);
   lrect[tid] = myrect;
   // own instances per band (as K1 counted them)
@@ -165,11 +173,9 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
 #pragma unroll
     for (int b = 0; b < kBands; ++b) wave_tot[wave][b] = incb[b];
   }
-  const int col = gridDim.x + 1;                          // column stride of g.block_band
-  if (tid < kBands) {                                     // band base = the totals of the bands before it
-    uint32_t base = 0;
-    for (int b = 0; b < tid; ++b) base += g.block_band[(size_t)b * col + gridDim.x];
-    bpos[tid] = base + g.block_band[(size_t)tid * col + blockIdx.x];
+  if (wave == 0) {                                        // band base = the totals of the bands before it
+    const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
+    if (tid < kBands) bpos[tid] = incl - band_tot + band_off;
   }
   __syncthreads();
   uint32_t wbase = 0;
@@ -187,7 +193,6 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
       below += cb[b];
     }
   }
-  const uint32_t block_base = g.block_sums[blockIdx.x];
   if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run (K7 / K8 slots)
   __syncthreads();
   const uint32_t total = excl[kPreBlock];
