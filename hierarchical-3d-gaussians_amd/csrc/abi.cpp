@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <pthread.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -46,8 +47,9 @@ struct StageTimer {
 
 static thread_local char g_err[512] = "";
 
-// Per calling thread: 4 bytes of pinned host memory (a D2H copy into pageable memory blocks the host until the
-// copy has run, which would defeat enqueue-ahead in hgs_raster_fwd) and ONE reusable event.  Both are released by a
+// Per calling thread: 4 bytes of pinned, device-mapped host memory (the scan kernel stores the instance count there --
+// no copy command in the stream; where the mapping is refused, a D2H copy into it: a copy into pageable memory would
+// block the host until it has run, which would defeat enqueue-ahead in hgs_raster_fwd) and ONE reusable event per device.  Both are released by a
 // pthread key destructor when the thread ends (autograd worker threads come and go); a thread that is still alive
 // at process exit leaves them to the driver's teardown, which is the only safe order.
 constexpr int kMaxDevices = 16;
@@ -73,7 +75,7 @@ static ThreadHost* thread_host(int device) {
   ThreadHost* h = static_cast<ThreadHost*>(pthread_getspecific(g_host_key));
   if (!h) {
     h = new ThreadHost();
-    if (hipHostMalloc(reinterpret_cast<void**>(&h->pinned_L), sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void**>(&h->pinned_L), sizeof(uint32_t), hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) {
       thread_host_free(h);
       return nullptr;
     }
@@ -276,14 +278,19 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   *L_out_host = 0;
   if (a->P == 0) return enqueue_stage2(a, g, b, im, 0, nullptr, T, out_color, out_invdepth, s);
   if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
-  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
-  const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
-  const uint32_t* L_dev = g.block_sums + nblk;
   ThreadHost* th = thread_host(device);
   if (!th) { set_error("cannot allocate pinned host memory / event (device %d)", device); return HGS_ERR_NOMEM; }
   hipEvent_t ev = th->ev[device];
   uint32_t* stage = th->pinned_L;
-  HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+  // the scan kernel stores the count into the mapped host word itself (visible to the host once the event after the
+  // kernel has fired: a kernel's writes are released to system scope when it ends)
+  static const bool by_copy = getenv("HGS_COUNT_BY_COPY") != nullptr;     // diagnostic: the copy command instead
+  void* mirror = nullptr;
+  if (by_copy || hipHostGetDevicePointer(&mirror, stage, 0) != hipSuccess) { (void)hipGetLastError(); mirror = nullptr; }
+  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug, static_cast<uint32_t*>(mirror))))) return rc;
+  const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
+  const uint32_t* L_dev = g.block_sums + nblk;
+  if (!mirror) HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
   hipError_t e = hipEventRecord(ev, s);
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
   if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);

@@ -101,7 +101,7 @@ inline int tile_bits(int T) {
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
 // scans block_sums and the kBands columns of block_band (one launch, one workgroup per array)
-int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug);
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror = nullptr);
 // banded: one instance stream per tile band (b.keys_in = band-local tile ids), else one stream of global tile ids
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
                            hipStream_t s);

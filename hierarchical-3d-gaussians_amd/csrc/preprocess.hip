@@ -508,8 +508,11 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
 
 // Exclusive scan of the per-workgroup sums (nblk = P/256): workgroup 0 scans block_sums, workgroups 1..kBands the
 // columns of block_band; every array has n + 1 entries, the total lands in entry n.
+// `total_mirror` (may be null): a second home for the grand total -- mapped host memory, so that the host learns the
+// instance count without a copy command in the stream (a 4-byte D2H copy + its barriers cost the stream ~10 us).
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums0,
-                                                               uint32_t* __restrict__ bands, int n) {
+                                                               uint32_t* __restrict__ bands, int n,
+                                                               uint32_t* __restrict__ total_mirror) {
   uint32_t* __restrict__ sums = blockIdx.x == 0 ? sums0 : bands + (size_t)(blockIdx.x - 1) * (n + 1);
   __shared__ uint32_t wave_tot[16];
   __shared__ uint32_t carry_s;
@@ -535,7 +538,10 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
     if (tid == 1023) carry_s = carry + wbase + inc;
     __syncthreads();
   }
-  if (tid == 0) sums[n] = carry_s;
+  if (tid == 0) {
+    sums[n] = carry_s;
+    if (blockIdx.x == 0 && total_mirror) *total_mirror = carry_s;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1285,9 +1291,10 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
   return HGS_OK;
 }
 
-int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug) {
+int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band, nblk);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band, nblk,
+                     total_mirror);
   HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
   return HGS_OK;
 }

@@ -70,6 +70,9 @@ constexpr float kBig = 1.0e18f;   // y coordinate of a finished / outside pixel:
 #ifndef HGS_K7_LPIX_REGS
 #define HGS_K7_LPIX_REGS 1
 #endif
+#ifndef HGS_K7_THR_CMP
+#define HGS_K7_THR_CMP 0
+#endif
 // instances staged per batch (at most one per lane); row kBatch of the LDS arrays is a dummy instance that can never be
 // a candidate (rows whose list is exhausted fetch it)
 constexpr int kFwdBatch = HGS_K6_BATCH;
@@ -103,6 +106,14 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 // exp2(min(x, 0)) = min(exp2(x), 1) as ONE instruction: the [0, 1] output clamp of v_exp_f32 (the compiler folds the
 // median into the instruction's clamp bit).  Also turns +inf / NaN inputs into 1 / 0.
 __device__ __forceinline__ float exp2_le1(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
+
+// the three float4 of staged instance j (a list entry: < 256): the byte offset as ONE 24-bit multiply (across the look-ahead's
+// loop-carried registers the compiler loses the value range and emits the quarter-rate 32-bit multiply)
+__device__ __forceinline__ const float4* staged(const float4* lrec, uint32_t j) {
+  uint32_t off;
+  asm("v_mul_u32_u24 %0, 48, %1" : "=v"(off) : "v"(j));
+  return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lrec) + off);
+}
 
 // number of set bits of `m` below this lane
 __device__ __forceinline__ uint32_t rank_below(uint64_t m) {
@@ -315,13 +326,13 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     };
 #if HGS_K6_PREFETCH
     uint32_t jA = myq[0], jB = myq[4];
-    float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
+    float4 A0 = staged(lrec, jA)[0], A1 = staged(lrec, jA)[1], A2 = staged(lrec, jA)[2];
     for (int it = 0; it < nmax; it += 2) {
-      const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
+      const float4 B0 = staged(lrec, jB)[0], B1 = staged(lrec, jB)[1], B2 = staged(lrec, jB)[2];
       const uint32_t jA2 = myq[(it + 2) * 4];
       visit(jA, A0, A1, A2);
       if (it + 1 < nmax) {
-        A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
+        A0 = staged(lrec, jA2)[0]; A1 = staged(lrec, jA2)[1]; A2 = staged(lrec, jA2)[2];
         const uint32_t jB2 = myq[(it + 3) * 4];
         visit(jB, B0, B1, B2);
         jB = jB2;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
 #else
     for (int it = 0; it < nmax; ++it) {
       const uint32_t j = myq[it * 4];      // this row's next instance (kB: none)
-      visit(j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
+      visit(j, staged(lrec, j)[0], staged(lrec, j)[1], staged(lrec, j)[2]);
     }
 #endif
     alive = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig);
@@ -634,23 +645,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const float thr = q2v.z;
       const f2 dy0 = gyt - P0.fly;
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 dy1 = gyt - P1.fly;
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
-      // per-pixel candidate predicates: log-domain alpha test AND (NC batches) "the forward blended this Gaussian into
-      // the pixel" (rel < n_contrib); combined in scalar registers
+      // per-pixel predicate "the forward blended this Gaussian into the pixel": rel < n_contrib here, alpha >= 1/255 in
+      // bwd_pair_live (exactly the forward's test; a parked pixel and the dummy instance have alpha 0).
+#if HGS_K7_THR_CMP
+      // (+ the log-domain candidate test power2 >= thr before the exp: implied by alpha >= 1/255 -- it has a guard band
+      // -- so it decides nothing; four compares per visit, K7 0.314 -> see DESIGN.md)
+      const float thr = q2v.z;
       uint64_t k0 = __ballot(pw0.x >= thr), k1 = __ballot(pw0.y >= thr);
       uint64_t k2 = __ballot(pw1.x >= thr), k3 = __ballot(pw1.y >= thr);
       if (NC) {
         k0 &= __ballot(rel < P0.nc0); k1 &= __ballot(rel < P0.nc1);
         k2 &= __ballot(rel < P1.nc0); k3 &= __ballot(rel < P1.nc1);
       }
-      // (no "nobody in the wave is a candidate" exit: with the exact quadrant test it almost never fires, and the branch
-      // costs the scheduler more than it saves)
       const bool c0 = __builtin_amdgcn_inverse_ballot_w64(k0), c1 = __builtin_amdgcn_inverse_ballot_w64(k1);
       const bool c2 = __builtin_amdgcn_inverse_ballot_w64(k2), c3 = __builtin_amdgcn_inverse_ballot_w64(k3);
+#else
+      const bool c0 = !NC || rel < P0.nc0, c1 = !NC || rel < P0.nc1;
+      const bool c2 = !NC || rel < P1.nc0, c3 = !NC || rel < P1.nc1;
+#endif
       const f2 q2 = f2{q2v.x, q2v.y};
       BwdSums S;
       if (!DEPTH) S.s9 = 0.0f;
@@ -674,13 +690,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       // before the current one is composited: every row's record address depends on a list entry that is itself in
       // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
       uint32_t jA = myq[0], jB = myq[4];
-      float4 A0 = lrec[jA * kLds + 0], A1 = lrec[jA * kLds + 1], A2 = lrec[jA * kLds + 2];
+      float4 A0 = staged(lrec, jA)[0], A1 = staged(lrec, jA)[1], A2 = staged(lrec, jA)[2];
       for (int it = 0; it < nmax; it += 2) {
-        const float4 B0 = lrec[jB * kLds + 0], B1 = lrec[jB * kLds + 1], B2 = lrec[jB * kLds + 2];
+        const float4 B0 = staged(lrec, jB)[0], B1 = staged(lrec, jB)[1], B2 = staged(lrec, jB)[2];
         const uint32_t jA2 = myq[(it + 2) * 4];
         visit(nc_tag, jA, A0, A1, A2);
         if (it + 1 < nmax) {
-          A0 = lrec[jA2 * kLds + 0]; A1 = lrec[jA2 * kLds + 1]; A2 = lrec[jA2 * kLds + 2];
+          A0 = staged(lrec, jA2)[0]; A1 = staged(lrec, jA2)[1]; A2 = staged(lrec, jA2)[2];
           const uint32_t jB2 = myq[(it + 3) * 4];
           visit(nc_tag, jB, B0, B1, B2);
           jB = jB2;
@@ -690,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
 #else
       for (int it = 0; it < nmax; ++it) {
         const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
-        visit(nc_tag, j, lrec[j * kLds + 0], lrec[j * kLds + 1], lrec[j * kLds + 2]);
+        visit(nc_tag, j, staged(lrec, j)[0], staged(lrec, j)[1], staged(lrec, j)[2]);
       }
 #endif
     };

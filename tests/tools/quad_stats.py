@@ -36,7 +36,8 @@ def main(P=1_000_000, W=1920, H=1080, n_tiles=400, s_px=(0.5, 4.0), batch=64):
     ok = (T2 > 0) & (det > 0)
     ex = np.where(ok, np.sqrt(np.maximum(T2 * C / np.where(ok, det, 1), 0)) * 1.0001 + 5e-3, -1.0)
     ey = np.where(ok, np.sqrt(np.maximum(T2 * A / np.where(ok, det, 1), 0)) * 1.0001 + 5e-3, -1.0)
-    tot = dict(instances=0, visited=0, half_visits=0, quad_visits=0, quad_iterations=0, batches=0)
+    tot = dict(instances=0, visited=0, half_visits=0, quad_visits=0, quad_iterations=0, batches=0,
+               quad_iterations_b128=0, quad_iterations_unbatched=0)
     for t in tiles:
         s, e = b.ranges[t]
         if e <= s:
@@ -59,6 +60,10 @@ def main(P=1_000_000, W=1920, H=1080, n_tiles=400, s_px=(0.5, 4.0), batch=64):
             q = quads[b0:b0 + batch].sum(0)
             tot["quad_iterations"] += int(q.max())
             tot["batches"] += 1
+        for b0 in range(0, n, 2 * batch):
+            tot["quad_iterations_b128"] += int(quads[b0:b0 + 2 * batch].sum(0).max())
+        # rows that never wait for each other at batch boundaries: the longest of the tile's four lists
+        tot["quad_iterations_unbatched"] += int(quads.sum(0).max())
     out = dict(scene=f"{P} Gaussians, {W}x{H}, s_px {s_px}", tiles=n_tiles, batch=batch, totals=tot,
                per_instance={k: v / tot["instances"] for k, v in tot.items() if k != "instances"},
                quad_list_balance=tot["quad_visits"] / (4.0 * tot["quad_iterations"]),
