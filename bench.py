@@ -220,13 +220,20 @@ class DropIn:
 
 
 def _settings(dgr, cam, dev, sh_degree=3, **over):
-    e_i = torch.empty(0, dtype=torch.int32, device=dev)
-    e_f = torch.empty(0, dtype=torch.float32, device=dev)
+    # the camera's tensors live on the GPU, as the reference's Camera objects do (scene/cameras.py): building the settings
+    # of a frame must not cost host-to-device copies (each is a blocking call; on a loaded / virtualised host their
+    # wake-ups were seen to add milliseconds to a 10 ms frame)
+    cache = cam.__dict__.setdefault("_bench_dev", {})
+    if dev not in cache:
+        cache[dev] = dict(bg=torch.zeros(3, device=dev), viewmatrix=cam.world_view_transform.to(dev),
+                          projmatrix=cam.full_proj_transform.to(dev), campos=cam.camera_center.to(dev),
+                          e_i=torch.empty(0, dtype=torch.int32, device=dev),
+                          e_f=torch.empty(0, dtype=torch.float32, device=dev))
+    c = cache[dev]
     kw = dict(image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy,
-              bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=cam.world_view_transform.to(dev),
-              projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
-              prefiltered=False, debug=False, do_depth=True, render_indices=e_i, parent_indices=e_i,
-              interpolation_weights=e_f, num_node_kids=e_i)
+              bg=c["bg"], scale_modifier=1.0, viewmatrix=c["viewmatrix"], projmatrix=c["projmatrix"], sh_degree=sh_degree,
+              campos=c["campos"], prefiltered=False, debug=False, do_depth=True, render_indices=c["e_i"],
+              parent_indices=c["e_i"], interpolation_weights=c["e_f"], num_node_kids=c["e_i"])
     kw.update(over)
     return dgr.GaussianRasterizationSettings(**kw)
 
@@ -371,12 +378,38 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     torch.cuda.synchronize()
     st["n"].clear(); st["L"].clear(); st["cut_s"] = 0.0
     miss0 = dgrC.stats["capacity_misses"]
+    seg0 = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0)
+    diag = bool(os.environ.get("HGS_BENCH_DIAG"))
+    marks = []
     t0 = time.perf_counter()
     for _ in range(steps):
         frame()
+        if diag:
+            marks.append((time.perf_counter() - t0, torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0,
+                          torch.cuda.memory_stats(dev).get("reserved_bytes.all.current", 0) / 1e9))
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if diag:
+        import sys
+        print("diag host time after each frame (ms), segments allocated so far, reserved GB:",
+              [(round(a * 1e3, 2), b, round(c, 2)) for a, b, c in marks], "n", st["n"], file=sys.stderr)
     cut_ms, misses = st["cut_s"] / steps * 1e3, dgrC.stats["capacity_misses"] - miss0
+    seg_allocs = torch.cuda.memory_stats(dev).get("segment.all.allocated", 0) - seg0
+    if os.environ.get("HGS_BENCH_DIAG"):      # phase by phase, a device sync after each
+        import sys
+        for it in range(8):
+            j = it % len(cams)
+            tt = [time.perf_counter()]
+            n = expand_to_size(h.nodes, h.boxes, tau, vps[j][0], zero3, ri, pi, ni); torch.cuda.synchronize(); tt.append(time.perf_counter())
+            get_interpolation_weights(ni[:n], tau, h.nodes, h.boxes, vps[j][1], zero3, w, ns); torch.cuda.synchronize(); tt.append(time.perf_counter())
+            rs = _settings(dgr, cams[j], dev, do_depth=False, interpolation_weights=w, num_node_kids=ns, render_indices=ri[:n], parent_indices=pi)
+            with torch.no_grad():
+                dgr.GaussianRasterizer(rs)(means3D=h.xyz, means2D=m2, shs=h.shs, opacities=h.alpha, scales=sc, rotations=h.rots)
+            tt.append(time.perf_counter()); torch.cuda.synchronize(); tt.append(time.perf_counter())
+            print("diag frame", it, "expand/weights/render-host/render-sync ms", [round((b - a) * 1e3, 3) for a, b in zip(tt, tt[1:])],
+                  "segments", torch.cuda.memory_stats(dev).get("segment.all.allocated", 0), file=sys.stderr)
+        print("diag free-running ms/frame", elapsed / steps * 1e3, "timed-region device allocations", seg_allocs,
+              "reserved GB", torch.cuda.memory_stats(dev).get("reserved_bytes.all.current", 0) / 1e9, file=sys.stderr)
     _lib.timing_read(reset=True)
     _lib.timing_enable(True)
     for _ in range(3):
@@ -393,6 +426,7 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
            "config": {"hierarchy_nodes": G, "leaves": leaves, "tau_px": tau_px, "mean_cut": nm, "width": W, "height": H,
                       "hierarchy_build_s": t_build, "resident_bytes": int(G * (59 * 4 + 28 + 32)),
                       "capacity_misses": misses,
+                      "device_allocations_in_timed_region": seg_allocs,   # hipMalloc calls of the caching allocator
                       "expand_to_size_ms": cut_ms},     # host time of the cut incl. the wait for everything enqueued before it
            "stages_ms": stages}
     if stages.get("render_fwd") and stages.get("preprocess_fwd"):
@@ -408,6 +442,9 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     return out
 
 
+C5_STEPS = (10, 3)      # (steps, warmup) of the configs[4] extra
+
+
 def run_extras(args, dev, measure):
     from hgs import synth
     out = {}
@@ -421,7 +458,7 @@ def run_extras(args, dev, measure):
                                          measure, 20, 5, "the metric configuration with heavier footprints: 1 M Gaussians, "
                                          "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
         "config3_train_post": lambda: extra_train_post(dev, measure, 20, 5),
-        "config5_50m_4k_render": lambda: extra_config5(dev, 10, 3),
+        "config5_50m_4k_render": lambda: extra_config5(dev, *C5_STEPS),
     }
     for name in wanted:
         if name not in jobs:

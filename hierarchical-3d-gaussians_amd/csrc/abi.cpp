@@ -4,6 +4,7 @@
 
 #include <pthread.h>
 #include <stdlib.h>
+#include <time.h>
 #include <string.h>
 
 #include <mutex>
@@ -86,6 +87,38 @@ static ThreadHost* thread_host(int device) {
     return nullptr;
   }
   return h;
+}
+
+static bool blocking_waits() {
+  static const bool b = getenv("HGS_BLOCKING_WAIT") != nullptr;
+  return b;
+}
+template <typename Query>
+static bool poll_done(Query query, hipError_t* result) {
+  if (blocking_waits()) return false;
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned i = 0;; ++i) {
+    const hipError_t q = query();
+    if (q != hipErrorNotReady) { *result = q; return true; }
+    (void)hipGetLastError();                       // "not ready" is not an error to keep
+    __builtin_ia32_pause();
+    if ((i & 255u) == 255u) {
+      timespec t;
+      clock_gettime(CLOCK_MONOTONIC, &t);
+      if ((t.tv_sec - t0.tv_sec) * 1000000000LL + (t.tv_nsec - t0.tv_nsec) > 200000000LL) return false;
+    }
+  }
+}
+hipError_t wait_stream(hipStream_t s) {
+  hipError_t r;
+  if (poll_done([&] { return hipStreamQuery(s); }, &r)) return r;
+  return hipStreamSynchronize(s);
+}
+hipError_t wait_event(hipEvent_t e) {
+  hipError_t r;
+  if (poll_done([&] { return hipEventQuery(e); }, &r)) return r;
+  return hipEventSynchronize(e);
 }
 
 void set_error(const char* fmt, ...) {
@@ -221,7 +254,7 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
   if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug)))) return rc;
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   HGS_HIP(hipMemcpyAsync(L_out_host, g.block_sums + nblk, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  HGS_HIP(hipStreamSynchronize(s));
+  HGS_HIP(wait_stream(s));
   return HGS_OK;
 }
 
@@ -294,7 +327,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   hipError_t e = hipEventRecord(ev, s);
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
   if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);
-  if (e == hipSuccess) e = hipEventSynchronize(ev);
+  if (e == hipSuccess) e = wait_event(ev);
   if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
   *L_out_host = *stage;
   if (rc) return rc;

@@ -98,6 +98,60 @@ inline int tile_bits(int T) {
   return b < 1 ? 1 : b;
 }
 
+#ifdef __HIPCC__
+// In-place exclusive scan of sums[0 .. n) by ONE 1024-thread workgroup; the total goes to sums[n] and is returned to every
+// thread.  A thread owns PER consecutive entries per round (1024 PER entries per round: 50 M hierarchy nodes / 25 M cut
+// rows give ~100-200 k workgroup sums -- with one entry per thread and round those scans cost 0.11 / 0.24 ms).
+template <int PER>
+__device__ __forceinline__ uint32_t workgroup_scan_inplace(uint32_t* __restrict__ sums, int n) {
+  __shared__ uint32_t scan_wave_tot[16];
+  __shared__ uint32_t scan_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) scan_carry = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024 * PER) {
+    const int i0 = base + tid * PER;
+    uint32_t v[PER], mine = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      v[k] = (i0 + k < n) ? sums[i0 + k] : 0u;
+      mine += v[k];
+    }
+    uint32_t inc = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    if (lane == 63) scan_wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wave; ++w) wbase += scan_wave_tot[w];
+    const uint32_t carry = scan_carry;
+    uint32_t run = carry + wbase + inc - mine;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (i0 + k < n) sums[i0 + k] = run;
+      run += v[k];
+    }
+    __syncthreads();
+    if (tid == 1023) scan_carry = carry + wbase + inc;
+    __syncthreads();
+  }
+  const uint32_t total = scan_carry;
+  if (tid == 0) sums[n] = total;
+  return total;
+}
+#endif
+
+// Host waits of the hot path (the instance count after K1 + scan, the size of an LOD cut): the awaited work is tens of
+// microseconds to a few milliseconds away and the GPU idles until the host has reacted, so the host POLLS the
+// completion signal instead of sleeping on the interrupt (hipStreamSynchronize / hipEventSynchronize block after a short
+// spin; the wake-up was measured at milliseconds on virtualised hosts: 16.5 instead of 10.2 ms per frame of the
+// 50 M-node render loop).  After 200 ms of polling, or with HGS_BLOCKING_WAIT set, the blocking call takes over.
+hipError_t wait_stream(hipStream_t s);
+hipError_t wait_event(hipEvent_t e);
+
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
 // scans block_sums and the kBands columns of block_band (one launch, one workgroup per array)

@@ -121,31 +121,7 @@ __global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __r
 }
 
 __global__ __launch_bounds__(1024) void lod_scan_sums_kernel(uint32_t* __restrict__ sums, int n) {
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = (i < n) ? sums[i] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < n) sums[i] = carry + wbase + inc - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + inc;
-    __syncthreads();
-  }
-  if (tid == 0) sums[n] = carry_s;
+  (void)workgroup_scan_inplace<8>(sums, n);
 }
 
 __global__ __launch_bounds__(256) void lod_emit_kernel(const int32_t* __restrict__ nodes,
@@ -258,7 +234,7 @@ static int expand_finish(const int32_t* nodes, const ExpandTmp& t, int32_t N, in
   HGS_LAUNCH_CHECK("lod_emit", s, false);
   uint32_t total = 0;
   HGS_HIP(hipMemcpyAsync(&total, t.block_sums + nblk, 4, hipMemcpyDeviceToHost, s));
-  HGS_HIP(hipStreamSynchronize(s));
+  HGS_HIP(wait_stream(s));
   if (total > (uint32_t)capacity) {
     set_error("expand_to_size: %u entries exceed the output capacity %d", total, capacity);
     return HGS_ERR_INVALID;
@@ -305,7 +281,7 @@ int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, floa
     }
     uint32_t next = 0;
     HGS_HIP(hipMemcpyAsync(&next, t.counts + level, 4, hipMemcpyDeviceToHost, s));
-    HGS_HIP(hipStreamSynchronize(s));
+    HGS_HIP(wait_stream(s));
     if (next == 0) finished = true;
     else if (level >= kMaxLevels) { set_error("hierarchy deeper than %d levels", kMaxLevels); return HGS_ERR_INVALID; }
   }
@@ -351,7 +327,7 @@ int hgs_hier_boxes_nested(const int32_t* nodes, const float* boxes, int32_t N, v
   HGS_LAUNCH_CHECK("lod_nested", s, false);
   uint32_t bad = 0;
   HGS_HIP(hipMemcpyAsync(&bad, flag, 4, hipMemcpyDeviceToHost, s));
-  HGS_HIP(hipStreamSynchronize(s));
+  HGS_HIP(wait_stream(s));
   *nested_out_host = bad ? 0 : 1;
   return HGS_OK;
 }

@@ -514,34 +514,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restr
                                                                uint32_t* __restrict__ bands, int n,
                                                                uint32_t* __restrict__ total_mirror) {
   uint32_t* __restrict__ sums = blockIdx.x == 0 ? sums0 : bands + (size_t)(blockIdx.x - 1) * (n + 1);
-  __shared__ uint32_t wave_tot[16];
-  __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024) {
-    const int i = base + tid;
-    const uint32_t v = (i < n) ? sums[i] : 0u;
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += wave_tot[w];
-    const uint32_t carry = carry_s;
-    if (i < n) sums[i] = carry + wbase + inc - v;
-    __syncthreads();
-    if (tid == 1023) carry_s = carry + wbase + inc;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    sums[n] = carry_s;
-    if (blockIdx.x == 0 && total_mirror) *total_mirror = carry_s;
-  }
+  const uint32_t total = workgroup_scan_inplace<8>(sums, n);
+  if (threadIdx.x == 0 && blockIdx.x == 0 && total_mirror) *total_mirror = total;
 }
 
 // ---------------------------------------------------------------------------

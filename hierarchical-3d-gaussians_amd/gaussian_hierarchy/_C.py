@@ -3,6 +3,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import time
 import weakref
 
 import numpy as np
@@ -12,10 +13,29 @@ from hgs import _lib
 
 
 def _vec3(t) -> "C.Array":
+    """The C-ABI takes viewpoints as host floats; the reference passes ``camera_center`` as a GPU tensor
+    (train_post.py:96, render_hierarchy.py:63).  Reading it back waits for everything enqueued before it -- the previous
+    frame's render in a viewer loop -- so (a) the host copy is remembered ON the tensor object (keyed by its version
+    counter: an in-place edit re-reads it), and (b) the wait polls the stream instead of sleeping in the blocking copy
+    (the wake-up of a sleeping wait was measured at milliseconds on virtualised hosts)."""
+    if torch.is_tensor(t) and t.is_cuda:
+        cached = getattr(t, "_hgs_vec3", None)
+        if cached is not None and cached[0] == t._version:
+            return cached[1]
+        stream = torch.cuda.current_stream(t.device)
+        deadline = time.perf_counter() + 0.2
+        while not stream.query() and time.perf_counter() < deadline:
+            pass
     v = t.detach().to("cpu", torch.float32).reshape(-1) if torch.is_tensor(t) else torch.tensor(t, dtype=torch.float32)
     if v.numel() != 3:
         raise RuntimeError("expected a 3-vector")
-    return (C.c_float * 3)(*[float(x) for x in v])
+    out = (C.c_float * 3)(*[float(x) for x in v])
+    if torch.is_tensor(t) and t.is_cuda:
+        try:
+            t._hgs_vec3 = (t._version, out)
+        except Exception:       # (a tensor subclass without a __dict__)
+            pass
+    return out
 
 
 def _check_hier(nodes, boxes):
