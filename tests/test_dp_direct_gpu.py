@@ -6,7 +6,6 @@ all buckets, gather of the other shards).  What one GPU cannot show is the traff
 Checked: whole-bucket and sub-range reductions over several epochs give, on every rank, bit-identical results equal
 to the float32 sum in rank order; a GradBucket on the direct route gives what the torch.distributed route gives."""
 import os
-import socket
 import sys
 
 import numpy as np
@@ -15,12 +14,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from mp_util import run_world
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 def _data(rank, n, epoch):
@@ -78,19 +76,7 @@ def _worker(rank, world, port, q, extra_env=None):
 def test_direct_all_reduce_between_processes_sharing_the_gpu(gpu, world, env):
     """world 8: the shard arithmetic of a full node (HGS_P2P_MAX_WORLD), with the HGS_P2P_VERIFY self-check armed for
     the GradBucket exchanges; the last case allocates the buckets fine-grained."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, env)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = {}
-    for _ in range(world):
-        r, out = q.get(timeout=500)
-        res[r] = out
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = dict(run_world(_worker, world, extra=(env,), timeout=500, join_timeout=120))
     n = 1_000_003
     for epoch in range(4):
         parts = [_data(r, n, epoch).numpy() for r in range(world)]
@@ -134,15 +120,6 @@ def _fallback_worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 def test_direct_route_falls_back_collectively_when_one_rank_cannot_export(gpu):
     world = 3
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_fallback_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=250) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = run_world(_fallback_worker, world, timeout=250, join_timeout=60)
     for rank, fell_back, lo, hi in res:
         assert fell_back and lo == hi == 6.0, (rank, fell_back, lo, hi)

@@ -2,7 +2,6 @@
 bench.py uses with RCCL.  The per-view renderer here is the CPU oracle (tests may use it); the property
 checked is the exchange: all-reduced bucket == sum of the per-view gradients."""
 import os
-import socket
 import sys
 
 import pytest
@@ -10,9 +9,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from mp_util import run_world
 
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 def _view_grads(rank, world):
@@ -49,16 +47,7 @@ def _worker(rank, world, port, q):
 @pytest.mark.timeout(300)
 def test_bucket_allreduce_equals_sum_of_view_grads():
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = dict(q.get(timeout=240) for _ in range(world))
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    got = dict(run_world(_worker, world, timeout=240, join_timeout=60))
     expect = None
     for r in range(world):
         _, g = _view_grads(r, world)

@@ -8,7 +8,6 @@ SURVEY.md section 8(e):
   * ``relevant`` taken from the REDUCED opacity gradient (train_single.py:170-174),
   * every rank ends the step with bit-identical parameters, equal to one process stepping through all views."""
 import os
-import socket
 import sys
 
 import pytest
@@ -16,11 +15,10 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from mp_util import run_world
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 class _Ctx:           # what DataParallelStep needs of a RasterContext when the op itself is not in play
@@ -81,19 +79,9 @@ def _worker(rank, world, port, q, n_views=None):
 @pytest.mark.timeout(600)
 def test_dp_step_ranks_agree_and_match_one_process():
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
-    for p in procs:
-        p.start()
     got = {}
-    for _ in range(world):
-        r, params, accum = q.get(timeout=500)
+    for r, params, accum in run_world(_worker, world, timeout=500, join_timeout=60):
         got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
     ref_params, ref_accum = _run_steps(0, 1, 2, 4)          # one process, the same 4 views per step
     sys.path.insert(0, HERE)
     import dp_common as dc
@@ -117,19 +105,9 @@ def test_rank_without_a_view_contributes_zeros():
     gradients in its bucket -- it must contribute zeros, not those (DataParallelStep.finish).  2 views per step on 3
     ranks for 2 steps = one process rendering the same 2 views per step."""
     world, n_views = 3, 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_views)) for r in range(world)]
-    for p in procs:
-        p.start()
     got = {}
-    for _ in range(world):
-        r, params, accum = q.get(timeout=500)
+    for r, params, accum in run_world(_worker, world, extra=(n_views,), timeout=500, join_timeout=60):
         got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
     ref_params, ref_accum = _run_steps(0, 1, 2, n_views)
     sys.path.insert(0, HERE)
     import dp_common as dc

@@ -7,7 +7,6 @@ bench.py); the protocol, the buffers and every kernel are those of the RCCL run.
 rank: both ranks hold bit-identical parameters, equal (<= 1e-6 of the tensor's magnitude) to ONE process accumulating
 all 4 views of a step itself; the densification statistics agree exactly."""
 import os
-import socket
 import sys
 
 import pytest
@@ -15,12 +14,11 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
+from mp_util import run_world
+
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-
-def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
 def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
@@ -78,19 +76,9 @@ def test_two_ranks_on_one_gpu_agree_and_match_one_process(gpu, route):
     """route: the bucket's exchange -- torch.distributed's all-reduce (gloo here, RCCL in production) or the direct
     peer-pointer all-reduce (hgs_p2p_*, HGS_DP_ALLREDUCE=direct)."""
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, route)) for r in range(world)]
-    for p in procs:
-        p.start()
     got = {}
-    for _ in range(world):
-        r, params, accum = q.get(timeout=800)
+    for r, params, accum in run_world(_worker, world, extra=(route,), timeout=800, join_timeout=120):
         got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
     sys.path.insert(0, HERE)
     import dp_common as dc
     ref_params, ref_accum = _run_steps(0, 1, 3, 4)            # one process, all 4 views of every step, two streams
@@ -117,19 +105,9 @@ def test_eight_ranks_on_one_gpu_direct_route(gpu):
     the direct peer-pointer all-reduce.  All ranks bit-identical after 3 steps and equal to one process accumulating
     the 8 views itself."""
     world = 8
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "direct", 1)) for r in range(world)]
-    for p in procs:
-        p.start()
     got = {}
-    for _ in range(world):
-        r, params, accum = q.get(timeout=800)
+    for r, params, accum in run_world(_worker, world, extra=("direct", 1,), timeout=800, join_timeout=120):
         got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
     sys.path.insert(0, HERE)
     import dp_common as dc
     ref_params, ref_accum = _run_steps(0, 1, 3, 8)
