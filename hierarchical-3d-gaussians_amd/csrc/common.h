@@ -66,6 +66,7 @@ struct GeomWs {
   uint32_t* block_band;    // [kBands][nblk+1] the same per tile band: column b = exclusive scan of the workgroups' counts of
                            // instances whose tile lies in band b; [b][nblk] = the band's total
   float* shjac;            // [P,9] d(rgb)/d(view direction), rows = direction component (hgs_raster_args.prepare_backward)
+  unsigned long long* scan_chain;  // [(1 + kBands) * scan_chunks(nblk)] published chunk totals of the K2 scans (K1 clears it)
   static size_t bytes(int32_t P);
   static GeomWs carve_from(void* base, int32_t P);
 };
@@ -98,49 +99,74 @@ inline int tile_bits(int T) {
   return b < 1 ? 1 : b;
 }
 
+// Chunks of the workgroup-sum scans: one 1024-thread workgroup per 8192 entries (scan_chunks(n) workgroups per array).
+constexpr int kScanPer = 8;
+constexpr int kScanChunk = 1024 * kScanPer;
+__host__ __device__ inline int scan_chunks(size_t n) { return (int)((n + kScanChunk - 1) / kScanChunk) + (n == 0 ? 1 : 0); }
+
 #ifdef __HIPCC__
-// In-place exclusive scan of sums[0 .. n) by ONE 1024-thread workgroup; the total goes to sums[n] and is returned to every
-// thread.  A thread owns PER consecutive entries per round (1024 PER entries per round: 50 M hierarchy nodes / 25 M cut
-// rows give ~100-200 k workgroup sums -- with one entry per thread and round those scans cost 0.11 / 0.24 ms).
-template <int PER>
-__device__ __forceinline__ uint32_t workgroup_scan_inplace(uint32_t* __restrict__ sums, int n) {
+// In-place exclusive scan of sums[0 .. n), total to sums[n], by scan_chunks(n) workgroups of 1024 threads IN ONE LAUNCH:
+// workgroup c (= blockIdx.x) scans entries [c, c + 1) * kScanChunk locally, publishes its total in chain[c] (bit 32 = valid)
+// and adds the published totals of the workgroups before it -- which were dispatched before it and wait for nobody, so
+// the look-back cannot deadlock whatever fits on the chip.  `chain` must be ZERO when the launch starts (the kernel
+// that produces the sums clears it).  One workgroup walking the array 1024 entries per round cost 0.13 ms at the 96 k
+// sums of a 24.7 M-row view and 0.24 ms at the 195 k of a 50 M-node cut (one memory round trip + three barriers per
+// round, nothing to overlap them with); the 24 chunk workgroups take one round each.
+// Returns the grand total in the LAST chunk's threads (0 elsewhere).
+__device__ __forceinline__ uint32_t chained_scan_inplace(uint32_t* __restrict__ sums, int n,
+                                                         unsigned long long* __restrict__ chain) {
   __shared__ uint32_t scan_wave_tot[16];
-  __shared__ uint32_t scan_carry;
+  __shared__ uint32_t scan_prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) scan_carry = 0;
-  __syncthreads();
-  for (int base = 0; base < n; base += 1024 * PER) {
-    const int i0 = base + tid * PER;
-    uint32_t v[PER], mine = 0;
+  const int c = blockIdx.x, chunks = gridDim.x;
+  const int i0 = c * kScanChunk + tid * kScanPer;
+  // all loads are issued before the first is waited for (clamped index + select, no branch per load)
+  uint32_t v[kScanPer], mine = 0;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      v[k] = (i0 + k < n) ? sums[i0 + k] : 0u;
-      mine += v[k];
-    }
-    uint32_t inc = mine;
+  for (int k = 0; k < kScanPer; ++k) v[k] = sums[max(min(i0 + k, n - 1), 0)];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += t;
-    }
-    if (lane == 63) scan_wave_tot[wave] = inc;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (int w = 0; w < wave; ++w) wbase += scan_wave_tot[w];
-    const uint32_t carry = scan_carry;
-    uint32_t run = carry + wbase + inc - mine;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      if (i0 + k < n) sums[i0 + k] = run;
-      run += v[k];
-    }
-    __syncthreads();
-    if (tid == 1023) scan_carry = carry + wbase + inc;
-    __syncthreads();
+  for (int k = 0; k < kScanPer; ++k) {
+    v[k] = (i0 + k < n) ? v[k] : 0u;
+    mine += v[k];
   }
-  const uint32_t total = scan_carry;
-  if (tid == 0) sums[n] = total;
-  return total;
+  uint32_t inc = mine;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) scan_wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const uint32_t t = scan_wave_tot[w];
+    wbase += (w < wave) ? t : 0u;
+    total += t;
+  }
+  if (tid == 0) __hip_atomic_store(&chain[c], (1ull << 32) | (unsigned long long)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (wave == 0) {            // look back: lane l sums the totals of chunks l, l + 64, ... below c
+    uint32_t before = 0;
+    for (int q = lane; q < c; q += 64) {
+      unsigned long long x;
+      do { x = __hip_atomic_load(&chain[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); } while ((x >> 32) == 0ull);
+      before += (uint32_t)x;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
+    if (lane == 0) scan_prefix = before;
+  }
+  __syncthreads();
+  const uint32_t prefix = scan_prefix;
+  uint32_t run = prefix + wbase + inc - mine;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (i0 + k < n) sums[i0 + k] = run;
+    run += v[k];
+  }
+  if (c != chunks - 1) return 0u;
+  if (tid == 0) sums[n] = prefix + total;
+  return prefix + total;
 }
 #endif
 

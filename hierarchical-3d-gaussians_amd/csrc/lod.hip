@@ -71,8 +71,11 @@ __global__ __launch_bounds__(256) void lod_expand_level_kernel(const int32_t* __
 // over the N nodes instead of one launch per tree level (24 levels x ~8 us at 1 M nodes).
 __global__ __launch_bounds__(256) void lod_mark_kernel(const int32_t* __restrict__ nodes, const float* __restrict__ boxes,
                                                        int N, float tau, Vec3 vp, uint32_t* __restrict__ emit_cnt,
-                                                       uint32_t* __restrict__ block_sums) {
+                                                       uint32_t* __restrict__ block_sums,
+                                                       unsigned long long* __restrict__ chain) {
   __shared__ uint32_t wave_tot[4];
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < scan_chunks(gridDim.x); t += 256) chain[t] = 0ull;
   const int n = blockIdx.x * 256 + threadIdx.x;
   uint32_t cnt = 0;
   if (n < N) {
@@ -109,8 +112,11 @@ __global__ __launch_bounds__(256) void lod_nested_kernel(const int32_t* __restri
 
 // per-workgroup sums of emit_cnt (256 nodes per workgroup)
 __global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __restrict__ emit_cnt, int N,
-                                                             uint32_t* __restrict__ block_sums) {
+                                                             uint32_t* __restrict__ block_sums,
+                                                             unsigned long long* __restrict__ chain) {
   __shared__ uint32_t wave_tot[4];
+  if (blockIdx.x == 0)
+    for (int t = threadIdx.x; t < scan_chunks(gridDim.x); t += 256) chain[t] = 0ull;
   const int i = blockIdx.x * 256 + threadIdx.x;
   uint32_t v = (i < N) ? emit_cnt[i] : 0u;
 #pragma unroll
@@ -120,8 +126,9 @@ __global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __r
   if (threadIdx.x == 0) block_sums[blockIdx.x] = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
 }
 
-__global__ __launch_bounds__(1024) void lod_scan_sums_kernel(uint32_t* __restrict__ sums, int n) {
-  (void)workgroup_scan_inplace<8>(sums, n);
+__global__ __launch_bounds__(1024) void lod_scan_sums_kernel(uint32_t* __restrict__ sums, int n,
+                                                             unsigned long long* __restrict__ chain) {
+  (void)chained_scan_inplace(sums, n, chain);
 }
 
 __global__ __launch_bounds__(256) void lod_emit_kernel(const int32_t* __restrict__ nodes,
@@ -197,6 +204,7 @@ struct ExpandTmp {
   int32_t* frontier_b;   // [N]
   uint32_t* counts;      // [kMaxLevels + 2]
   uint32_t* block_sums;  // [nblk + 1]
+  unsigned long long* chain;  // [scan_chunks(nblk)] published chunk totals of the scan (cleared by the kernel before it)
 };
 
 inline ExpandTmp carve_expand(void* tmp, int32_t N) {
@@ -208,6 +216,7 @@ inline ExpandTmp carve_expand(void* tmp, int32_t N) {
   t.frontier_b = carve<int32_t>(p, n);
   t.counts = carve<uint32_t>(p, kMaxLevels + 2);
   t.block_sums = carve<uint32_t>(p, (n + 255) / 256 + 1);
+  t.chain = carve<unsigned long long>(p, (size_t)scan_chunks((n + 255) / 256));
   return t;
 }
 
@@ -220,14 +229,15 @@ extern "C" {
 
 size_t hgs_expand_tmp_bytes(int32_t N) {
   const size_t n = (size_t)(N > 0 ? N : 1);
-  return 3 * align_up(n * 4) + align_up((kMaxLevels + 2) * 4) + align_up(((n + 255) / 256 + 1) * 4) + kAlign;
+  return 3 * align_up(n * 4) + align_up((kMaxLevels + 2) * 4) + align_up(((n + 255) / 256 + 1) * 4) +
+         align_up((size_t)scan_chunks((n + 255) / 256) * 8) + kAlign;
 }
 
 static int expand_finish(const int32_t* nodes, const ExpandTmp& t, int32_t N, int32_t* render_indices,
                          int32_t* parent_indices, int32_t* nodes_for_render_indices, int32_t capacity,
                          int32_t* count_out_host, hipStream_t s) {
   const int nblk = (N + 255) / 256;
-  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(1), dim3(1024), 0, s, t.block_sums, nblk);
+  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(scan_chunks(nblk)), dim3(1024), 0, s, t.block_sums, nblk, t.chain);
   HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
   hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,
                      render_indices, parent_indices, nodes_for_render_indices, capacity);
@@ -286,7 +296,7 @@ int hgs_expand_to_size(const int32_t* nodes, const float* boxes, int32_t N, floa
     else if (level >= kMaxLevels) { set_error("hierarchy deeper than %d levels", kMaxLevels); return HGS_ERR_INVALID; }
   }
   const int nblk = (N + 255) / 256;
-  hipLaunchKernelGGL(lod_block_sums_kernel, dim3(nblk), dim3(256), 0, s, t.emit_cnt, N, t.block_sums);
+  hipLaunchKernelGGL(lod_block_sums_kernel, dim3(nblk), dim3(256), 0, s, t.emit_cnt, N, t.block_sums, t.chain);
   HGS_LAUNCH_CHECK("lod_block_sums", s, false);
   return expand_finish(nodes, t, N, render_indices, parent_indices, nodes_for_render_indices, capacity, count_out_host, s);
 }
@@ -308,7 +318,7 @@ int hgs_expand_to_size_nested(const int32_t* nodes, const float* boxes, int32_t 
   const ExpandTmp t = carve_expand(tmp, N);
   const Vec3 vp = {viewpoint[0], viewpoint[1], viewpoint[2]};
   hipLaunchKernelGGL(lod_mark_kernel, dim3((N + 255) / 256), dim3(256), 0, s, nodes, boxes, N, size, vp, t.emit_cnt,
-                     t.block_sums);
+                     t.block_sums, t.chain);
   HGS_LAUNCH_CHECK("lod_mark", s, false);
   return expand_finish(nodes, t, N, render_indices, parent_indices, nodes_for_render_indices, capacity, count_out_host, s);
 }

@@ -275,6 +275,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   __shared__ uint32_t band_cnt[kBands];          // this workgroup's instances per tile band (binning: band streams)
   if (threadIdx.x < kBands) band_cnt[threadIdx.x] = 0u;
+  if (blockIdx.x == 0)        // the scan launch that follows publishes its chunk totals here (common.h)
+    for (int t = threadIdx.x; t < (1 + kBands) * scan_chunks(gridDim.x); t += kPreBlock) g.scan_chain[t] = 0ull;
   __syncthreads();
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const int gx = (a.width + kTile - 1) / kTile;
@@ -506,16 +508,18 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   if (threadIdx.x < kBands) g.block_band[(size_t)threadIdx.x * (gridDim.x + 1) + blockIdx.x] = band_cnt[threadIdx.x];
 }
 
-// Exclusive scan of the per-workgroup sums (nblk = P/256): workgroup 0 scans block_sums, workgroups 1..kBands the
-// columns of block_band; every array has n + 1 entries, the total lands in entry n.
+// Exclusive scan of the per-workgroup sums (nblk = P/256): grid row 0 scans block_sums, rows 1..kBands the columns of
+// block_band (common.h: chained_scan_inplace, one workgroup per 8192 entries); every array has n + 1 entries, the total
+// lands in entry n.
 // `total_mirror` (may be null): a second home for the grand total -- mapped host memory, so that the host learns the
 // instance count without a copy command in the stream (a 4-byte D2H copy + its barriers cost the stream ~10 us).
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums0,
                                                                uint32_t* __restrict__ bands, int n,
+                                                               unsigned long long* __restrict__ chain,
                                                                uint32_t* __restrict__ total_mirror) {
-  uint32_t* __restrict__ sums = blockIdx.x == 0 ? sums0 : bands + (size_t)(blockIdx.x - 1) * (n + 1);
-  const uint32_t total = workgroup_scan_inplace<8>(sums, n);
-  if (threadIdx.x == 0 && blockIdx.x == 0 && total_mirror) *total_mirror = total;
+  uint32_t* __restrict__ sums = blockIdx.y == 0 ? sums0 : bands + (size_t)(blockIdx.y - 1) * (n + 1);
+  const uint32_t total = chained_scan_inplace(sums, n, chain + (size_t)blockIdx.y * gridDim.x);
+  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && total_mirror) *total_mirror = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -1267,8 +1271,8 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
 
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band, nblk,
-                     total_mirror);
+  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(scan_chunks(nblk), 1 + kBands), dim3(1024), 0, s, g.block_sums,
+                     g.block_band, nblk, g.scan_chain, total_mirror);
   HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
   return HGS_OK;
 }
