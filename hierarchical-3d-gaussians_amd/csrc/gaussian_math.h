@@ -259,6 +259,22 @@ __device__ __forceinline__ LodRow lod_row(const hgs_raster_args& a, int idx) {
   }
   return l;
 }
+// The row as the GATHERS see it: with weight exactly 1 the parent row is not read -- w x + 0 y = x for every finite y --
+// the node row stands in for it (same address twice: no second HBM row; the load itself stays unconditional -- a branch
+// around it serialises the row's loads and cost K1 +30 %).  82 % of the rows of the 50 M-node render loop
+// and 25-90 % of a train_post-shaped cut have weight 1 (the parent is more than twice too coarse), and a row costs
+// 236 bytes.  Differences to the Python expression t * x[r] + (1 - t) * x[p]: a -0.0 attribute stays -0.0 (the
+// expression gives +0.0 next to a positive parent value) and a non-finite parent attribute does not reach rows it has
+// no weight in.  The gradient scatter keeps using lod_row: the parent of a weight-1 row still belongs to its siblings'
+// run.
+template <bool LOD>
+__device__ __forceinline__ LodRow lod_row_gather(const hgs_raster_args& a, int idx) {
+  LodRow l = lod_row<LOD>(a, idx);
+  if constexpr (LOD) {
+    if (l.w == 1.0f) l.p = l.r;
+  }
+  return l;
+}
 // w * x + u * y with both products and the sum rounded separately (what torch's t * x[r] + (1 - t) * x[p] does)
 __device__ __forceinline__ float lod_lerp(float x, float y, float w, float u) {
 #pragma clang fp contract(off)
@@ -279,7 +295,7 @@ template <bool LOD>
 __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx, float sc[3], float q[4],
                                                double* nrm) {
   if constexpr (LOD) {                         // interpolated row (no activations in this mode)
-    const LodRow l = lod_row<true>(a, idx);
+    const LodRow l = lod_row_gather<true>(a, idx);
 #pragma unroll
     for (int k = 0; k < 3; ++k) sc[k] = lod_lerp(a.scales[l.r * 3 + k], a.scales[l.p * 3 + k], l.w, l.u);
     const float4 qa = reinterpret_cast<const float4*>(a.rotations)[l.r];
@@ -310,7 +326,7 @@ __device__ __forceinline__ void load_scale_rot(const hgs_raster_args& a, int idx
 template <bool LOD>
 __device__ __forceinline__ float load_opacity(const hgs_raster_args& a, int idx, double* dact) {
   if constexpr (LOD) {
-    const LodRow l = lod_row<true>(a, idx);
+    const LodRow l = lod_row_gather<true>(a, idx);
     if (dact) *dact = 1.0;
     return lod_lerp(a.opacities[l.r], a.opacities[l.p], l.w, l.u);
   }

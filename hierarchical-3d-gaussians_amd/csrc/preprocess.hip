@@ -249,13 +249,13 @@ __device__ __forceinline__ void coop_gather_sh(const float* __restrict__ shs, in
     const float* pad = lds + row * stride + n;
     const size_t r = (size_t)__float_as_uint(pad[0]), p = (size_t)__float_as_uint(pad[1]);
     const float w = pad[2], u = 1.0f - w;
-    const float4 x = src[r * cpr + c], y = src[p * cpr + c];
+    const float4 x = src[r * cpr + c], y = src[p * cpr + c];     // (weight 1: p = r, see lod_row_gather)
     *reinterpret_cast<float4*>(lds + row * stride + c * 4) =
         make_float4(lod_lerp(x.x, y.x, w, u), lod_lerp(x.y, y.y, w, u), lod_lerp(x.z, y.z, w, u), lod_lerp(x.w, y.w, w, u));
   }
 }
 __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, float sh[48]) {
-  const LodRow l = lod_row<true>(a, idx);
+  const LodRow l = lod_row_gather<true>(a, idx);
   const int n = a.M * 3;
   const float* x = a.shs + l.r * n;
   const float* y = a.shs + l.p * n;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   constexpr bool lod = LOD;
   const int shn = a.M * 3;
   if (idx < a.P) {
-    const LodRow lr = lod_row<LOD>(a, idx);
+    const LodRow lr = lod_row_gather<LOD>(a, idx);     // (its node / parent / weight also steer the cooperative SH gather)
     load_mean<LOD>(a, lr, p);
     if (lod && a.shs && (shn & 3) == 0) {
       // the cooperative SH gather below needs every row's (node row, parent row, weight): they ride in the four pad
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
     const uint32_t flags = g.flags[idx];
     float p[3];
-    load_mean<LOD>(a, lod_row<LOD>(a, idx), p);
+    load_mean<LOD>(a, lod_row_gather<LOD>(a, idx), p);
     float q[4] = {1.f, 0.f, 0.f, 0.f};
     float sc[3] = {1.f, 1.f, 1.f};
     double qnorm = 1.0;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       const bool vis = in_range && n != 0;
       const float wn = self ? 1.0f : l.w, u = (self || !vis) ? 0.0f : l.u;
       float sgn = 1.0f;
-      if (vis && !self) {
+      if (vis && !self && u != 0.0f) {          // (weight 1: nothing goes to the parent, its quaternion is not needed)
         const float4 qa = reinterpret_cast<const float4*>(a.rotations)[l.r];
         const float4 qb = reinterpret_cast<const float4*>(a.rotations)[l.p];
         sgn = (qa.x * qb.x + qa.y * qb.y + qa.z * qb.z + qa.w * qb.w) < 0.0f ? -1.0f : 1.0f;
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
   if (active) {
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
     float pm[3];
-    load_mean<LOD>(a, lod_row<LOD>(a, idx), pm);
+    load_mean<LOD>(a, lod_row_gather<LOD>(a, idx), pm);
     const float dx = pm[0] - a.campos[0], dy = pm[1] - a.campos[1], dz = pm[2] - a.campos[2];
     const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
     const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
