@@ -49,7 +49,7 @@ def test_viewpoint_on_the_gpu_is_cached_per_tensor_and_follows_in_place_edits(gp
     h, cam, nodes, boxes = _setup(20_000, gpu)
     G = h.xyz.shape[0]
     ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
-    tau = 0.01
+    tau = 0.06
     a, b = torch.tensor([0.0, 0.0, 0.0]), torch.tensor([1.0, 2.0, -4.0])
     want = {k: lo.expand_to_size(h.nodes.numpy(), h.boxes.numpy(), tau, v.numpy())[0] for k, v in (("a", a), ("b", b))}
     assert not np.array_equal(want["a"], want["b"])

@@ -224,3 +224,37 @@ def test_trained_like_footprints_1080p(gpu):
     cam = synth.make_camera(1920, 1080)
     scene = synth.make_scene_trained_like(400_000, cam, seed=3)
     _run_case("trained_like_400k_1080p", gpu, scene.P, 1920, 1080, 48, seed=3, prepared=(scene, None, None))
+
+
+_FRAME_DIGEST = r"""
+import hashlib, os, sys
+root = sys.argv[1]
+for p in (root, os.path.join(root, "hierarchical-3d-gaussians_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import torch
+import parity as pa
+from hgs import synth
+cam = synth.make_camera(200, 120)
+scene = synth.make_scene(3000, cam, seed=5)
+gc, gd = synth.upstream_grads(120, 200, seed=1)
+r = pa.run_hip(scene, cam, torch.zeros(3), gc, gd, "cuda:0", debug=False, grad_mask=None)
+h = hashlib.sha256()
+for t in [r["color"], r["radii"], r["invdepth"]] + [r["grads"][k] for k in sorted(r["grads"])]:
+    h.update(t.contiguous().numpy().tobytes())
+print("digest", h.hexdigest(), r["L"])
+"""
+
+
+def test_diagnostic_wait_and_count_routes_give_the_same_frame(gpu):
+    """HGS_BLOCKING_WAIT (sleeping host waits instead of polling) and HGS_COUNT_BY_COPY (the instance count by a copy
+    command instead of the scan kernel's store into mapped host memory) are read once per process: one small
+    fwd+bwd per setting in a process of its own, bit-identical outputs and gradients."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = {}
+    for name, env in (("default", {}), ("blocking", {"HGS_BLOCKING_WAIT": "1"}), ("copy", {"HGS_COUNT_BY_COPY": "1"})):
+        r = subprocess.run([sys.executable, "-c", _FRAME_DIGEST, root], env={**os.environ, **env}, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        digests[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")][-1]
+    assert digests["default"] == digests["blocking"] == digests["copy"], digests
