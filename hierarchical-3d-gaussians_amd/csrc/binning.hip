@@ -365,7 +365,7 @@ __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths,
 constexpr uint32_t kWaveCap = 1024;     // one wave, 16 keys per lane
 constexpr uint32_t kQuadCap = 4096;     // the four waves of a workgroup together
 
-// ---- 1025 .. 4096 instances: the workgroup's FOUR waves sort one tile together ------------------------------------------
+// ---- 1025 .. 4096 instances: two or four waves of the workgroup sort one tile together -------------------------------
 // Every wave sorts a block of 1024 keys in registers (the network above, blocks alternately ascending / descending: the
 // direction bits of `base` include the wave), then the remaining stages of the bitonic network over 2048 and 4096 keys
 // run: a stage whose partner distance is >= 1024 pairs keys of two WAVES and goes through LDS (write the block, barrier,
@@ -388,13 +388,24 @@ __device__ __forceinline__ void quad_cross_stage(uint64_t (&key)[16], uint64_t* 
   }
 }
 
-__device__ __forceinline__ void quad_sort_tile(uint64_t* lk, const float* __restrict__ depths,
-                                               uint32_t* __restrict__ vals, uint32_t r0, uint32_t n) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// GROUP = 4: the workgroup's four waves sort one tile of 2049 .. 4096 instances.  GROUP = 2: a PAIR of waves (`wv` = the
+// wave's number inside its pair, `lk` = the pair's half of the LDS array) sorts a tile of 1025 .. 2048 -- the two pairs of
+// a workgroup sort two such tiles at the same time (four waves on one 2048-key tile leave two of them sorting padding).
+// n == 0: the group has no tile this round and only keeps the workgroup's barriers company.
+template <int GROUP>
+__device__ __forceinline__ void coop_sort_tile(uint64_t* lk, const float* __restrict__ depths,
+                                               uint32_t* __restrict__ vals, uint32_t r0, uint32_t n, int wv) {
+  static_assert(GROUP == 2 || GROUP == 4, "pair or quad");
+  const int lane = threadIdx.x & 63;
+  if (GROUP == 2 && n == 0) {                   // (uniform per pair) the one cross stage's two barriers
+    __syncthreads();
+    __syncthreads();
+    return;
+  }
   uint64_t key[16];
 #pragma unroll
   for (int e = 0; e < 16; ++e) {                // coalesced load: any permutation inside the wave's block will do
-    const uint32_t i = (uint32_t)(wave * 1024 + e * 64 + lane);
+    const uint32_t i = (uint32_t)(wv * 1024 + e * 64 + lane);
     uint64_t k = ~0ull;
     if (i < n) {
       const uint32_t gid = vals[r0 + i];
@@ -402,11 +413,11 @@ __device__ __forceinline__ void quad_sort_tile(uint64_t* lk, const float* __rest
     }
     key[e] = k;
   }
-  const uint32_t base = (uint32_t)(wave * 1024 + lane * 16);
+  const uint32_t base = (uint32_t)(wv * 1024 + lane * 16);
   wave_sort_network<16, 2>(key, lane, base);                  // blocks of 1024, directions by bit 10 of the index
   quad_cross_stage<2048>(key, lk, base, 1024);
   wave_sort_block<16, 2048, 512>(key, lane, base);
-  if (n > 2048) {                                             // uniform
+  if constexpr (GROUP == 4) {
     quad_cross_stage<4096>(key, lk, base, 2048);
     quad_cross_stage<4096>(key, lk, base, 1024);
     wave_sort_block<16, 4096, 512>(key, lane, base);
@@ -456,11 +467,31 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_
   }
   if constexpr (QUAD) {
     __syncthreads();
-    for (int w = 0; w < 4; ++w) {                 // uniform: the four tiles of this workgroup, one after the other
+    // the workgroup's tiles of 1025 .. 2048 (two at a time, one per pair of waves) and of 2049 .. 4096 (one after the
+    // other, all four waves): uniform control flow, every wave meets every barrier
+    uint32_t pair_mask = 0, quad_mask = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
       const uint32_t qn = quad_n[w];
-      if (qn == 0) continue;
-      const int t = blockIdx.x * 4 + w;
-      quad_sort_tile(lk, depths, vals, ranges[t * 2 + 0], qn);
+      if (qn > 2048u) quad_mask |= 1u << w;
+      else if (qn != 0u) pair_mask |= 1u << w;
+    }
+    while (pair_mask) {
+      const int w0 = __builtin_ctz(pair_mask);
+      pair_mask &= pair_mask - 1u;
+      int w1 = -1;
+      if (pair_mask) { w1 = __builtin_ctz(pair_mask); pair_mask &= pair_mask - 1u; }
+      const int pair = wave >> 1;
+      const int wsel = pair ? w1 : w0;
+      uint32_t pr0 = 0, pn = 0;
+      if (wsel >= 0) { pr0 = ranges[(blockIdx.x * 4 + wsel) * 2 + 0]; pn = quad_n[wsel]; }
+      coop_sort_tile<2>(lk + pair * 2048, depths, vals, pr0, pn, wave & 1);
+      __syncthreads();
+    }
+    while (quad_mask) {
+      const int w = __builtin_ctz(quad_mask);
+      quad_mask &= quad_mask - 1u;
+      coop_sort_tile<4>(lk, depths, vals, ranges[(blockIdx.x * 4 + w) * 2 + 0], quad_n[w], wave);
       __syncthreads();
     }
   }
