@@ -1,7 +1,9 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_raster_gpu.py tests/test_scale_parity_gpu.py -m gpu -x -q -p no:cacheprovider -k "crowded or 4k or config3" 2>&1 | tail -3
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --extras config5_50m_4k_render,heavy_1m 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k,v in d['extra'].items(): print(k, round(v['value'],1), v['unit'], {a:round(b,3) for a,b in v['stages_ms'].items()})
-print('headline', round(d['value'],1), d['stages_ms']['tile_depth_sort'])"
+L=hierarchical-3d-gaussians_amd/lib/libhgs.so; cp $L /tmp/prod.so
+for v in product k8pad product; do
+  if [ $v != product ]; then cp ab_variants/libhgs_$v.so $L; else cp /tmp/prod.so $L; fi
+  echo "== $v"; rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o r -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary > /dev/null 2>&1
+  python scripts/rocprof_summary.py $(ls /tmp/prof_$v/*.db | head -1) 2>/dev/null | grep "preprocess_bwd\|sh_bwd"
+  rm -rf /tmp/prof_$v
+done
+cp /tmp/prod.so $L
