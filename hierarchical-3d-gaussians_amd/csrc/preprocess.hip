@@ -571,11 +571,6 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
                                                                    hgs_raster_grads out) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const bool in_range = idx < a.P;
-#ifdef HGS_K8A_LDS_PAD      // experiment: K8a at the occupancy a fusion with K8b's 52 KB output stage would leave it
-  __shared__ float occupancy_pad[HGS_K8A_LDS_PAD / 4];
-  if (a.P < 0) occupancy_pad[threadIdx.x] = 1.0f;
-  if (a.P < -1) out.dL_dopacity[0] = occupancy_pad[threadIdx.x ^ 1];
-#endif
   if constexpr (!LOD) {
     if (!in_range) return;
   }
