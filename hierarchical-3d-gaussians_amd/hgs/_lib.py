@@ -56,6 +56,10 @@ class HierHost(C.Structure):
                 ("boxes", C.c_void_p)]
 
 
+class ResidRows(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("means3D", "shs", "opacities", "scales", "rotations")]
+
+
 class ShBwdView(C.Structure):
     _fields_ = [("geom_ws", C.c_void_p), ("bwd_ws", C.c_void_p), ("campos", C.c_void_p), ("L", C.c_uint32),
                 ("reserved", C.c_uint32)]
@@ -131,8 +135,18 @@ SIGNATURES = {
     "hgs_p2p_close": (C.c_int, [_P, C.c_int]),
     "hgs_p2p_allreduce_sum": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(_P), C.c_size_t, C.c_size_t,
                                         C.c_uint32, _P, C.c_int]),
+    "hgs_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "hgs_host_free": (None, [_P]),
+    "hgs_resid_mark": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P, _P,
+                                 C.POINTER(C.c_uint32), _P, C.c_int]),
+    "hgs_resid_evict": (C.c_int, [_P, _P, _P, C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), _P,
+                                  C.c_int]),
+    "hgs_resid_fetch": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint32, C.POINTER(ResidRows),
+                                  C.POINTER(ResidRows), C.c_int32, _P, C.c_int]),
+    "hgs_resid_remap": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int]),
 }
 P2P_MAX_WORLD, P2P_HANDLE_BYTES, P2P_FLAG_BYTES = 8, 64, 256
+RESID_COUNTER_WORDS = 68
 
 _lib = None
 

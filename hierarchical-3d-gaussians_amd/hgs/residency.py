@@ -1,0 +1,186 @@
+"""VRAM-budgeted residency of a hierarchy's attribute rows ("VRAM-budgeted streaming LOD", BASELINE configs[4]; the
+``--budget <MB>`` of the reference's hierarchy viewer, README.md:233-235, whose implementation is in the un-vendored
+SIBR viewer).  Opt-in, beside the drop-in path: ``render_hierarchy.py`` itself loads the whole hierarchy onto the GPU
+(scene/gaussian_model.py:329,376-399) and so does ``bench.py``'s configs[4] loop -- 15 GB of 288 GB.
+
+The full attribute arrays (means, SH, opacity, scales, rotations: 4 (3 M + 11) bytes per Gaussian) live in pinned host
+memory that the GPU can read directly; the GPU holds ``budget`` rows in slot arrays plus one int32 per Gaussian (its
+slot, or "absent").  Per view::
+
+    sel = bh.select(nodes, boxes, tau, viewpoint_gpu, viewpoint_cpu)   # cut, weights, residency; raises tau if needed
+    rs  = GaussianRasterizationSettings(..., render_indices=sel.render_indices, parent_indices=sel.parent_indices,
+                                        interpolation_weights=sel.weights, num_node_kids=sel.kids)
+    GaussianRasterizer(rs)(means3D=bh.means3D, shs=bh.shs, opacities=bh.opacities, scales=bh.scales,
+                           rotations=bh.rotations, means2D=...)
+
+``select`` runs the reference's two LOD calls (``expand_to_size`` / ``get_interpolation_weights``), marks the rows the
+cut needs (node and parent row of every entry), fetches the missing ones over PCIe with ONE kernel that reads the host
+arrays itself (no host-side gather, no staging buffer), recycles the slots that have gone unused for the longest when the
+free list runs out, and returns the cut's indices translated to slots.  A view whose rows do not fit the budget is cut
+again at a coarser granularity (tau x 1.5 per attempt), as the reference's viewer "auto-regulates and raises the
+granularity until the scene can fit inside the defined VRAM budget".  The rasterizer's in-op LOD path runs on the slot
+arrays unchanged: rows are rows."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _host_array(shape, dtype=np.float32):
+    """A numpy array over pinned, device-mapped host memory (hgs_host_alloc) and the owner that frees it."""
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = _lib.lib().hgs_host_alloc(n)
+    if not p:
+        raise RuntimeError(f"cannot allocate {n} bytes of pinned host memory")
+    buf = (C.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return arr, p
+
+
+@dataclass
+class Selection:
+    n: int                              # entries of the cut
+    tau: float                          # the granularity that was rendered (>= the requested one)
+    render_indices: torch.Tensor        # int32 [n]: SLOT of the node row
+    parent_indices: torch.Tensor        # int32 [n]: SLOT of the parent row
+    weights: torch.Tensor               # f32 [>= n]
+    kids: torch.Tensor                  # int32 [>= n]
+    misses: int                         # rows fetched for this view
+    attempts: int                       # cuts tried (1 = the requested granularity fitted)
+
+
+class BudgetedHierarchy:
+    def __init__(self, means3D, shs, opacities, scales, rotations, device, budget_mb: Optional[float] = None,
+                 budget_rows: Optional[int] = None, index_capacity: Optional[int] = None):
+        """The five attribute arrays as CPU tensors ([G,3], [G,M,3], [G] or [G,1], [G,3], [G,4], float32, already in the
+        form the rasterizer takes: activated).  They are COPIED into pinned host memory.  ``budget_mb``: megabytes of
+        GPU memory for the attribute rows (the reference's ``--budget``); or ``budget_rows`` directly."""
+        self.dev = torch.device(device)
+        self.lib = _lib.lib()
+        G = int(means3D.shape[0])
+        M = int(shs.shape[1])
+        self.G, self.M = G, M
+        self.row_bytes = 4 * (3 * M + 11)
+        if budget_rows is None:
+            if budget_mb is None:
+                raise ValueError("budget_mb or budget_rows")
+            budget_rows = int(budget_mb * 1e6 // self.row_bytes)
+        self.B = B = max(1, min(int(budget_rows), G))
+        srcs = dict(means3D=(means3D, (G, 3)), shs=(shs, (G, M, 3)), opacities=(opacities, (G,)), scales=(scales, (G, 3)),
+                    rotations=(rotations, (G, 4)))
+        self._host, self._host_ptrs = {}, {}
+        for k, (t, shape) in srcs.items():
+            arr, p = _host_array(shape)
+            arr[...] = t.detach().to("cpu", torch.float32).reshape(shape).numpy()
+            self._host[k], self._host_ptrs[k] = arr, p
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.means3D = torch.zeros(B, 3, **f32)
+        self.shs = torch.zeros(B, M, 3, **f32)
+        self.opacities = torch.zeros(B, 1, **f32)
+        self.scales = torch.ones(B, 3, **f32)
+        self.rotations = torch.zeros(B, 4, **f32)
+        self.rotations[:, 0] = 1.0
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        self.slot_of = torch.full((G,), -1, **i32)
+        self.id_of_slot = torch.full((B,), -1, **i32)
+        self.stamp = torch.zeros(B, **i32)
+        self.free_list = torch.arange(B - 1, -1, -1, **i32)
+        self.free_top = B
+        self.counters = torch.zeros(_lib.RESID_COUNTER_WORDS, **i32)
+        cap = int(index_capacity or G)
+        self.ri = torch.zeros(cap, **i32); self.pi = torch.zeros(cap, **i32); self.ni = torch.zeros(cap, **i32)
+        self.ro = torch.zeros(cap, **i32); self.po = torch.zeros(cap, **i32)
+        self.miss_ids = torch.zeros(2 * cap, **i32)
+        self.w = torch.zeros(cap, dtype=torch.float32, device=self.dev)
+        self.ns = torch.zeros(cap, **i32)
+        self.frame = 0
+        self.stats = dict(views=0, rows_fetched=0, bytes_fetched=0, evictions=0, retries=0)
+        self._host_rows = _lib.ResidRows(*[C.c_void_p(self._host_ptrs[k]) for k in
+                                           ("means3D", "shs", "opacities", "scales", "rotations")])
+        self._slot_rows = _lib.ResidRows(*[C.c_void_p(t.data_ptr()) for t in
+                                           (self.means3D, self.shs, self.opacities, self.scales, self.rotations)])
+
+    def __del__(self):
+        try:
+            for p in getattr(self, "_host_ptrs", {}).values():
+                self.lib.hgs_host_free(C.c_void_p(p))
+        except Exception:
+            pass
+
+    # ---------------------------------------------------------------------------------------------------------------
+    @property
+    def budget_bytes(self):
+        return self.B * self.row_bytes
+
+    @property
+    def resident_rows(self):
+        return self.B - self.free_top
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def make_resident(self, render_indices: torch.Tensor, parent_indices: torch.Tensor):
+        """Rows of a cut (int32 GPU tensors of Gaussian rows, equal length) -> (slots of the node rows, slots of the
+        parent rows, rows fetched).  Raises RuntimeError (code 5) when the rows do not fit the budget."""
+        n = int(render_indices.numel())
+        assert parent_indices.numel() >= n and n <= self.ro.numel()
+        p, dev_i, s = _lib.ptr, self.dev.index or 0, self._stream()
+        self.frame += 1
+        miss = C.c_uint32(0)
+        _lib.check(self.lib.hgs_resid_mark(p(render_indices), p(parent_indices), n, self.G, p(self.slot_of), p(self.stamp),
+                                           self.frame, p(self.miss_ids), p(self.counters), p(self.ro), p(self.po),
+                                           C.byref(miss), s, dev_i), "hgs_resid_mark")
+        m = int(miss.value)
+        if m:
+            try:
+                if m > self.free_top:
+                    top = C.c_uint32(self.free_top)
+                    _lib.check(self.lib.hgs_resid_evict(p(self.stamp), p(self.id_of_slot), p(self.slot_of), self.B,
+                                                        self.frame, m, p(self.free_list), p(self.counters), C.byref(top),
+                                                        s, dev_i), "hgs_resid_evict")
+                    self.stats["evictions"] += int(top.value) - self.free_top
+                    self.free_top = int(top.value)
+                _lib.check(self.lib.hgs_resid_fetch(p(self.miss_ids), m, p(self.free_list), self.free_top, p(self.slot_of),
+                                                    p(self.id_of_slot), p(self.stamp), self.frame,
+                                                    C.byref(self._host_rows), C.byref(self._slot_rows), self.M, s, dev_i),
+                           "hgs_resid_fetch")
+            except RuntimeError:
+                # the rows queued by the mark pass (slot_of = -2) go back to "absent"
+                ids = self.miss_ids[:m].long()
+                self.slot_of[ids] = torch.where(self.slot_of[ids] == -2, torch.full_like(self.slot_of[ids], -1),
+                                                self.slot_of[ids])
+                raise
+            self.free_top -= m
+            _lib.check(self.lib.hgs_resid_remap(p(render_indices), p(parent_indices), n, p(self.slot_of), p(self.ro),
+                                                p(self.po), s, dev_i), "hgs_resid_remap")
+            self.stats["rows_fetched"] += m
+            self.stats["bytes_fetched"] += m * self.row_bytes
+        return self.ro[:n], self.po[:n], m
+
+    def select(self, nodes, boxes, tau, viewpoint_gpu, viewpoint_cpu, max_attempts: int = 48, growth: float = 1.5) -> Selection:
+        """expand_to_size + get_interpolation_weights at ``tau`` (train_post.py:91-113, render_hierarchy.py:58-80), the
+        cut's rows made resident; a cut that does not fit the budget is repeated at ``growth`` x tau (from 1e-4 when the
+        request was tau = 0: every leaf)."""
+        from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+        zero3 = torch.zeros(3)
+        t = float(tau)
+        for attempt in range(1, max_attempts + 1):
+            n = expand_to_size(nodes, boxes, t, viewpoint_gpu, zero3, self.ri, self.pi, self.ni)
+            try:
+                ro, po, m = self.make_resident(self.ri[:n], self.pi[:n])
+            except RuntimeError as e:
+                if "code 5" not in str(e):
+                    raise
+                self.stats["retries"] += 1
+                t = t * growth if t > 0 else 1e-4
+                continue
+            get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
+            self.stats["views"] += 1
+            return Selection(n, t, ro, po, self.w, self.ns, m, attempt)
+        raise RuntimeError(f"no granularity up to tau = {t:g} fits a budget of {self.B} rows")

@@ -409,6 +409,51 @@ int hgs_p2p_close(void* ptr, int device);
 int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* const* flag_blocks, size_t offset,
                           size_t n, uint32_t epoch, hgs_stream_t stream, int device);
 
+/* ---------------------------------------------------------------------------
+ * Budgeted residency of a hierarchy's attribute rows ("VRAM-budgeted streaming LOD": the `--budget <MB>` of the
+ * reference's hierarchy viewer, README.md:233-235 -- "this only defines the budget for the SCENE representation" --
+ * whose implementation lives in the un-vendored SIBR viewer; BASELINE configs[4] names it).  Opt-in layer BESIDE the
+ * drop-in path (hgs/residency.py): the full attribute arrays stay in pinned, device-mapped HOST memory
+ * (hgs_host_alloc); the GPU holds `B` rows in slot arrays.  Per view, after the LOD cut:
+ *   hgs_resid_mark    every row the cut needs (node row and parent row of each entry): resident -> stamped with the
+ *                     frame number; absent -> appended ONCE to the miss list (slot_of: >= 0 slot, -1 absent, -2 queued
+ *                     this frame); ro / po receive the slots of the resident rows.  Waits; *miss_count_host.
+ *   hgs_resid_evict   when the free list is shorter than the miss list: frees the slots that have gone unused for
+ *                     the longest (age histogram on the device, threshold chosen on the host; rows stamped this frame
+ *                     are never evicted).  HGS_ERR_CAPACITY if even that is not enough: the working set of the view
+ *                     exceeds the budget -- the caller raises tau, as the reference's viewer "auto-regulates".
+ *   hgs_resid_fetch   assigns free slots to the missing rows and copies their attributes from the host arrays into
+ *                     the slot arrays: ONE kernel reading host memory directly (zero copy over PCIe), no staging
+ *                     buffer, no host-side gather.
+ *   hgs_resid_remap   render_indices / parent_indices (Gaussian rows) -> slot indices, for the in-op LOD path of the
+ *                     rasterizer (hgs_raster_args.lod_*) running on the slot arrays.
+ * slot_of int32 [G] (initialised to -1), stamp uint32 [B], id_of_slot int32 [B] (initialised to -1), free_list int32
+ * [B] (initialised to B-1 .. 0: slot 0 is handed out first), counters uint32 [HGS_RESID_COUNTER_WORDS] (device
+ * scratch), miss_ids int32
+ * [2 x capacity of the index arrays].  All calls are ordered on `stream`.
+ * ------------------------------------------------------------------------- */
+#define HGS_RESID_COUNTER_WORDS 68
+typedef struct hgs_resid_rows {
+  float* means3D;    /* [rows, 3]    */
+  float* shs;        /* [rows, M, 3] */
+  float* opacities;  /* [rows]       */
+  float* scales;     /* [rows, 3]    */
+  float* rotations;  /* [rows, 4]    */
+} hgs_resid_rows;
+void* hgs_host_alloc(size_t bytes);      /* pinned host memory mapped into every device's address space; NULL on failure */
+void hgs_host_free(void* p);
+int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, int32_t G,
+                   int32_t* slot_of, uint32_t* stamp, uint32_t frame, int32_t* miss_ids, uint32_t* counters,
+                   int32_t* ro, int32_t* po, uint32_t* miss_count_host, hgs_stream_t stream, int device);
+int hgs_resid_evict(uint32_t* stamp, int32_t* id_of_slot, int32_t* slot_of, int32_t B, uint32_t frame, uint32_t need,
+                    int32_t* free_list, uint32_t* counters, uint32_t* free_top_inout_host, hgs_stream_t stream,
+                    int device);
+int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_list, uint32_t free_top, int32_t* slot_of,
+                    int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const hgs_resid_rows* host_rows,
+                    const hgs_resid_rows* slot_rows, int32_t M, hgs_stream_t stream, int device);
+int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, const int32_t* slot_of,
+                    int32_t* ro, int32_t* po, hgs_stream_t stream, int device);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,121 @@
+"""VRAM-budgeted residency of a hierarchy's attribute rows (hgs/residency.py, csrc/residency.hip; BASELINE configs[4]
+"VRAM-budgeted streaming LOD", the reference viewer's --budget, README.md:233-235).  The property: rendering through the
+slot arrays gives the SAME BITS as rendering the fully resident hierarchy through the same in-op LOD path -- whatever
+was fetched, evicted or already there -- and a view that does not fit is rendered at a coarser granularity."""
+import numpy as np
+import pytest
+import torch
+
+import parity as pa
+from hgs import hierarchy, synth
+
+pytestmark = pytest.mark.gpu
+W, H = 320, 200
+
+
+def _scene(gpu, leaves=20_000, seed=4):
+    cam = synth.make_camera(W, H)
+    h = hierarchy.build_hierarchy(synth.make_scene(leaves, cam, seed=seed))
+    attrs = dict(means3D=h.xyz, shs=h.shs, opacities=h.alpha.abs().reshape(-1, 1), scales=torch.exp(h.log_scales),
+                 rotations=torch.nn.functional.normalize(h.rots))
+    return h, attrs, h.nodes.to(gpu), h.boxes.to(gpu)
+
+
+def _render(gpu, cam, arrays, ri, pi, w, ns):
+    import diff_gaussian_rasterization as dgr
+    kw = pa.settings_kwargs(cam, torch.zeros(3), 3, do_depth=False, device=gpu, interpolation_weights=w, num_node_kids=ns)
+    kw.update(render_indices=ri, parent_indices=pi)
+    rs = dgr.GaussianRasterizationSettings(**kw)
+    G = arrays["means3D"].shape[0]
+    with torch.no_grad():
+        color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=arrays["means3D"], means2D=torch.zeros(G, 3, device=gpu),
+                                                     shs=arrays["shs"], opacities=arrays["opacities"],
+                                                     scales=arrays["scales"], rotations=arrays["rotations"])
+    return color, radii
+
+
+def _reference(gpu, cam, full, nodes, boxes, tau):
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
+    G = full["means3D"].shape[0]
+    ri = torch.zeros(G, dtype=torch.int32, device=gpu); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+    w = torch.zeros(G, device=gpu); ns = torch.zeros(G, dtype=torch.int32, device=gpu)
+    n = expand_to_size(nodes, boxes, tau, cam.camera_center.to(gpu), torch.zeros(3), ri, pi, ni)
+    get_interpolation_weights(ni[:n], tau, nodes, boxes, cam.camera_center.cpu(), torch.zeros(3), w, ns)
+    color, radii = _render(gpu, cam, full, ri[:n], pi, w, ns)
+    rows = int(torch.unique(torch.cat([ri[:n], pi[:n]])).numel())
+    return color, radii, n, rows
+
+
+def _views():
+    return [(synth.orbit_camera(W, H, j, 6, radius=0.4, tilt=0.05), tau) for j, tau in
+            enumerate((0.02, 0.004, 0.05, 0.01, 0.1, 0.004))]
+
+
+def test_budgeted_rendering_is_bit_identical_and_recycles_slots(gpu):
+    from hgs.residency import BudgetedHierarchy
+    h, attrs, nodes, boxes = _scene(gpu)
+    full = {k: v.to(gpu).contiguous() for k, v in attrs.items()}
+    G = full["means3D"].shape[0]
+    refs = [_reference(gpu, cam, full, nodes, boxes, tau) for cam, tau in _views()]
+    need = max(r[3] for r in refs)
+    assert need < 0.9 * G                                     # the views leave room below the full hierarchy
+    bh = BudgetedHierarchy(attrs["means3D"], attrs["shs"], attrs["opacities"], attrs["scales"], attrs["rotations"], gpu,
+                           budget_rows=int(need * 1.05))     # every view fits, the union of all views does not
+    assert bh.B < G
+    for rnd in range(2):
+        for (cam, tau), (color_ref, radii_ref, n_ref, rows_ref) in zip(_views(), refs):
+            sel = bh.select(nodes, boxes, tau, cam.camera_center.to(gpu), cam.camera_center.cpu())
+            assert sel.attempts == 1 and sel.tau == tau and sel.n == n_ref
+            assert int(sel.render_indices.min()) >= 0 and int(sel.parent_indices.min()) >= 0
+            assert int(sel.render_indices.max()) < bh.B
+            arrays = dict(means3D=bh.means3D, shs=bh.shs, opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
+            color, radii = _render(gpu, cam, arrays, sel.render_indices, sel.parent_indices, sel.weights, sel.kids)
+            assert torch.equal(color, color_ref) and torch.equal(radii, radii_ref)
+            assert bh.resident_rows <= bh.B
+    st = bh.stats
+    print(st, "budget rows", bh.B, "of", G)
+    assert st["evictions"] > 0 and st["retries"] == 0
+    assert st["rows_fetched"] > bh.B                           # more rows went through the slots than there are slots
+    # bookkeeping is consistent: every occupied slot is the slot of its row, the free list holds the rest
+    ids = bh.id_of_slot.long()
+    occ = ids >= 0
+    assert int(occ.sum()) == bh.resident_rows
+    assert torch.equal(bh.slot_of[ids[occ]].long(), torch.nonzero(occ).reshape(-1))
+    assert int((bh.slot_of >= 0).sum()) == bh.resident_rows and int((bh.slot_of == -2).sum()) == 0
+    free = bh.free_list[:bh.free_top].long()
+    assert free.unique().numel() == bh.free_top and not bool(occ[free].any())
+
+
+def test_view_that_does_not_fit_is_rendered_coarser(gpu):
+    """The reference viewer "auto-regulates and raises the granularity until the scene can fit inside the defined VRAM
+    budget" (README.md:235): tau = 0 asks for every leaf; with a quarter of the rows as budget the cut is repeated at
+    1.5 x tau until it fits, and what is rendered equals the fully resident render at THAT tau."""
+    from hgs.residency import BudgetedHierarchy
+    h, attrs, nodes, boxes = _scene(gpu, leaves=8_000, seed=6)
+    full = {k: v.to(gpu).contiguous() for k, v in attrs.items()}
+    G = full["means3D"].shape[0]
+    cam = synth.make_camera(W, H)
+    bh = BudgetedHierarchy(attrs["means3D"], attrs["shs"], attrs["opacities"], attrs["scales"], attrs["rotations"], gpu,
+                           budget_mb=(G // 4) * 4 * (3 * 16 + 11) / 1e6)
+    assert bh.B == G // 4
+    sel = bh.select(nodes, boxes, 0.0, cam.camera_center.to(gpu), cam.camera_center.cpu())
+    assert sel.attempts > 1 and sel.tau > 0.0 and bh.stats["retries"] == sel.attempts - 1
+    color_ref, radii_ref, n_ref, rows_ref = _reference(gpu, cam, full, nodes, boxes, sel.tau)
+    assert sel.n == n_ref and rows_ref <= bh.B
+    arrays = dict(means3D=bh.means3D, shs=bh.shs, opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
+    color, radii = _render(gpu, cam, arrays, sel.render_indices, sel.parent_indices, sel.weights, sel.kids)
+    assert torch.equal(color, color_ref) and torch.equal(radii, radii_ref)
+    assert int((bh.slot_of == -2).sum()) == 0                  # nothing is left queued by the attempts that failed
+    # a second, finer request after the coarse one: the rows of the failed attempts did not leak slots
+    sel2 = bh.select(nodes, boxes, sel.tau, cam.camera_center.to(gpu), cam.camera_center.cpu())
+    assert sel2.attempts == 1 and sel2.misses == 0
+
+
+def test_index_outside_the_hierarchy_is_refused(gpu):
+    from hgs.residency import BudgetedHierarchy
+    h, attrs, nodes, boxes = _scene(gpu, leaves=500, seed=1)
+    bh = BudgetedHierarchy(attrs["means3D"], attrs["shs"], attrs["opacities"], attrs["scales"], attrs["rotations"], gpu,
+                           budget_rows=100)
+    bad = torch.tensor([0, 1, bh.G], dtype=torch.int32, device=gpu)
+    with pytest.raises(RuntimeError):
+        bh.make_resident(bad, bad)
