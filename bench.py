@@ -442,6 +442,77 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     return out
 
 
+def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, budget_mb=6000.0):
+    """BASELINE configs[4] with its "VRAM-budgeted streaming LOD": the same 50 M-node hierarchy, but the attribute rows
+    (11.8 GB) live in pinned HOST memory and the GPU holds `budget_mb` of them (hgs/residency.py; the reference viewer's
+    --budget, README.md:233-235).  Per frame: cut + weights, the cut's rows made resident (misses fetched over PCIe by a
+    kernel that reads the host arrays), 3840x2160 render through the in-op LOD path on the slot arrays.  The requested
+    granularity does not fit the budget: the loop settles at the finest one that does, as the reference's viewer."""
+    import diff_gaussian_rasterization as dgr
+    from diff_gaussian_rasterization import _C as dgrC
+    from hgs import hierarchy, synth
+    from hgs.residency import BudgetedHierarchy
+    W, H = 3840, 2160
+    cam = synth.make_camera(W, H)
+    h = hierarchy.build_hierarchy_on_device(leaves, cam, dev, seed=0)
+    G = h.nodes.shape[0]
+    t0 = time.perf_counter()
+    bh = BudgetedHierarchy(h.xyz.cpu(), h.shs.cpu(), h.alpha.cpu(), torch.exp(h.log_scales).cpu(), h.rots.cpu(), dev,
+                           budget_mb=budget_mb)
+    t_host = time.perf_counter() - t0
+    nodes, boxes = h.nodes, h.boxes
+    del h
+    torch.cuda.empty_cache()
+    cams = [synth.orbit_camera(W, H, j, 8, radius=0.05, tilt=0.004) for j in range(8)]
+    vps = [(c.camera_center.to(dev), c.camera_center.cpu()) for c in cams]
+    tau = (2 * tau_px + 1) * cam.tanfovx / (0.5 * W)
+    m2 = torch.zeros(bh.B, 3, device=dev)
+    st = {"i": 0, "sel": []}
+
+    def frame():
+        j = st["i"] % len(cams); st["i"] += 1
+        sel = bh.select(nodes, boxes, tau, vps[j][0], vps[j][1])
+        rs = _settings(dgr, cams[j], dev, do_depth=False, interpolation_weights=sel.weights, num_node_kids=sel.kids,
+                       render_indices=sel.render_indices, parent_indices=sel.parent_indices)
+        with torch.no_grad():
+            color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=bh.means3D, means2D=m2, shs=bh.shs,
+                                                         opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
+        st["sel"].append((sel.n, sel.tau, sel.misses, sel.attempts))
+        return color
+
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    frame()                                                     # cold start: the whole working set crosses PCIe
+    torch.cuda.synchronize(); t_cold = time.perf_counter() - t0
+    cold = dict(bh.stats)
+    for _ in range(max(warmup - 1, 0)):
+        frame()
+    torch.cuda.synchronize()
+    st["sel"].clear()
+    f0 = bh.stats["rows_fetched"]
+    miss0 = dgrC.stats["capacity_misses"]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    sels = st["sel"]
+    return {"what": "BASELINE configs[4] with VRAM-budgeted streaming LOD: the 50 M-node hierarchy's attribute rows in pinned "
+                    "host memory, a budget of them on the GPU (hgs/residency.py), per frame cut + weights + residency + "
+                    "3840x2160 render on the slot arrays (forward only)",
+            "metric": "rendered frames/s @ 3840x2160", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "config": {"hierarchy_nodes": G, "attribute_bytes_on_host": int(G * bh.row_bytes), "budget_mb": budget_mb,
+                       "budget_rows": bh.B, "requested_tau_px": tau_px,
+                       "rendered_tau_px": (sum(s[1] for s in sels) / len(sels) * (0.5 * W) / cam.tanfovx - 1) / 2,
+                       "mean_cut": sum(s[0] for s in sels) / len(sels),
+                       "cuts_per_frame": sum(s[3] for s in sels) / len(sels),
+                       "rows_fetched_per_frame": (bh.stats["rows_fetched"] - f0) / steps,
+                       "cold_start": {"seconds": t_cold, "rows": cold["rows_fetched"],
+                                      "pcie_GBps": cold["bytes_fetched"] / t_cold / 1e9},
+                       "host_copy_s": t_host, "evictions": bh.stats["evictions"],
+                       "capacity_misses": dgrC.stats["capacity_misses"] - miss0, "width": W, "height": H}}
+
+
 C5_STEPS = (10, 3)      # (steps, warmup) of the configs[4] extra
 
 
@@ -459,6 +530,7 @@ def run_extras(args, dev, measure):
                                          "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
         "config3_train_post": lambda: extra_train_post(dev, measure, 20, 5),
         "config5_50m_4k_render": lambda: extra_config5(dev, *C5_STEPS),
+        "config5_budgeted_6gb": lambda: extra_config5_budgeted(dev, 16, 8),
     }
     for name in wanted:
         if name not in jobs:
@@ -508,7 +580,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` objects (BASELINE configs 2 / 3 / 5 and the heavy 1 M variant)")
-    ap.add_argument("--extras", default="config2_300k,heavy_1m,config3_train_post,config5_50m_4k_render")
+    ap.add_argument("--extras", default="config2_300k,heavy_1m,config3_train_post,config5_50m_4k_render,config5_budgeted_6gb")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="L",
                     help="internal: time the CPU oracle for a frame with L tile instances, print JSON, exit")

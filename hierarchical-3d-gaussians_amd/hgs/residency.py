@@ -17,7 +17,7 @@ slot, or "absent").  Per view::
 cut needs (node and parent row of every entry), fetches the missing ones over PCIe with ONE kernel that reads the host
 arrays itself (no host-side gather, no staging buffer), recycles the slots that have gone unused for the longest when the
 free list runs out, and returns the cut's indices translated to slots.  A view whose rows do not fit the budget is cut
-again at a coarser granularity (tau x 1.5 per attempt), as the reference's viewer "auto-regulates and raises the
+again at a coarser granularity (tau x 1.2 per attempt), as the reference's viewer "auto-regulates and raises the
 granularity until the scene can fit inside the defined VRAM budget".  The rasterizer's in-op LOD path runs on the slot
 arrays unchanged: rows are rows."""
 from __future__ import annotations
@@ -100,6 +100,8 @@ class BudgetedHierarchy:
         self.w = torch.zeros(cap, dtype=torch.float32, device=self.dev)
         self.ns = torch.zeros(cap, **i32)
         self.frame = 0
+        self._regulated = None          # granularity the previous view was coarsened to (None: the request fitted)
+        self._since_probe, self.probe_every = 0, 16
         self.stats = dict(views=0, rows_fetched=0, bytes_fetched=0, evictions=0, retries=0)
         self._host_rows = _lib.ResidRows(*[C.c_void_p(self._host_ptrs[k]) for k in
                                            ("means3D", "shs", "opacities", "scales", "rotations")])
@@ -138,6 +140,10 @@ class BudgetedHierarchy:
                                            C.byref(miss), s, dev_i), "hgs_resid_mark")
         m = int(miss.value)
         if m:
+            if m > 4096:
+                # slots are handed out in miss-list order: sorted by row, a bulk fetch (cold start, a jump of the camera)
+                # lays the rows out in the hierarchy's own order and K1's gathers stay as local as on the full arrays
+                self.miss_ids[:m] = torch.sort(self.miss_ids[:m]).values
             try:
                 if m > self.free_top:
                     top = C.c_uint32(self.free_top)
@@ -163,13 +169,21 @@ class BudgetedHierarchy:
             self.stats["bytes_fetched"] += m * self.row_bytes
         return self.ro[:n], self.po[:n], m
 
-    def select(self, nodes, boxes, tau, viewpoint_gpu, viewpoint_cpu, max_attempts: int = 48, growth: float = 1.5) -> Selection:
+    def select(self, nodes, boxes, tau, viewpoint_gpu, viewpoint_cpu, max_attempts: int = 96, growth: float = 1.2) -> Selection:
         """expand_to_size + get_interpolation_weights at ``tau`` (train_post.py:91-113, render_hierarchy.py:58-80), the
         cut's rows made resident; a cut that does not fit the budget is repeated at ``growth`` x tau (from 1e-4 when the
         request was tau = 0: every leaf)."""
         from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
         zero3 = torch.zeros(3)
         t = float(tau)
+        if self._regulated is not None and self._regulated > t:
+            # the previous view had to be coarsened: start from what fitted then, and only every `probe_every`-th view
+            # one step finer (a cut that does not fit costs a cut and a pass over its rows)
+            self._since_probe += 1
+            probe = self._since_probe >= self.probe_every
+            if probe:
+                self._since_probe = 0
+            t = max(t, self._regulated / growth if probe else self._regulated)
         for attempt in range(1, max_attempts + 1):
             n = expand_to_size(nodes, boxes, t, viewpoint_gpu, zero3, self.ri, self.pi, self.ni)
             try:
@@ -182,5 +196,6 @@ class BudgetedHierarchy:
                 continue
             get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
             self.stats["views"] += 1
+            self._regulated = t if t > float(tau) else None
             return Selection(n, t, ro, po, self.w, self.ns, m, attempt)
         raise RuntimeError(f"no granularity up to tau = {t:g} fits a budget of {self.B} rows")

@@ -1,9 +1,8 @@
 cd $GRAFT_REPO_ROOT
-L=hierarchical-3d-gaussians_amd/lib/libhgs.so; cp $L /tmp/prod.so
-for v in product k8pad product; do
-  if [ $v != product ]; then cp ab_variants/libhgs_$v.so $L; else cp /tmp/prod.so $L; fi
-  echo "== $v"; rocprofv3 --kernel-trace --stats -d /tmp/prof_$v -o r -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary > /dev/null 2>&1
-  python scripts/rocprof_summary.py $(ls /tmp/prof_$v/*.db | head -1) 2>/dev/null | grep "preprocess_bwd\|sh_bwd"
-  rm -rf /tmp/prof_$v
-done
-cp /tmp/prod.so $L
+timeout 600 python -m pytest tests/test_residency_gpu.py -m gpu -x -q -p no:cacheprovider 2>&1 | tail -2
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-stage-timing --extras config5_budgeted_6gb 2>&1 | grep -v amdgpu | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print(json.dumps(d['extra'],indent=1))
+    else: print(l.rstrip()[:300])"

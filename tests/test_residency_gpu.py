@@ -89,7 +89,7 @@ def test_budgeted_rendering_is_bit_identical_and_recycles_slots(gpu):
 def test_view_that_does_not_fit_is_rendered_coarser(gpu):
     """The reference viewer "auto-regulates and raises the granularity until the scene can fit inside the defined VRAM
     budget" (README.md:235): tau = 0 asks for every leaf; with a quarter of the rows as budget the cut is repeated at
-    1.5 x tau until it fits, and what is rendered equals the fully resident render at THAT tau."""
+    1.2 x tau until it fits, and what is rendered equals the fully resident render at THAT tau."""
     from hgs.residency import BudgetedHierarchy
     h, attrs, nodes, boxes = _scene(gpu, leaves=8_000, seed=6)
     full = {k: v.to(gpu).contiguous() for k, v in attrs.items()}
