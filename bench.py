@@ -523,12 +523,12 @@ def run_extras(args, dev, measure):
     W, H = 1920, 1080
     cam = synth.make_camera(W, H)
     jobs = {
-        "config2_300k": lambda: extra_dropin("config2_300k", synth.make_scene(300_000, cam, seed=0), W, H, dev, measure, 20, 5,
+        "config2_300k": lambda: extra_dropin("config2_300k", synth.make_scene(300_000, cam, seed=0), W, H, dev, measure, 60, 10,
                                              "BASELINE configs[1]: ~300 k Gaussians, 1080p, train_single.py fwd+bwd call shape"),
         "heavy_1m": lambda: extra_dropin("heavy_1m", synth.make_scene(1_000_000, cam, seed=0, s_px=(1.0, 8.0)), W, H, dev,
-                                         measure, 20, 5, "the metric configuration with heavier footprints: 1 M Gaussians, "
+                                         measure, 40, 8, "the metric configuration with heavier footprints: 1 M Gaussians, "
                                          "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
-        "config3_train_post": lambda: extra_train_post(dev, measure, 20, 5),
+        "config3_train_post": lambda: extra_train_post(dev, measure, 40, 8),
         "config5_50m_4k_render": lambda: extra_config5(dev, *C5_STEPS),
         "config5_budgeted_6gb": lambda: extra_config5_budgeted(dev, 16, 8),
     }
