@@ -45,6 +45,8 @@ def _host_array(shape, dtype=np.float32):
 
 @dataclass
 class Selection:
+    """What one view renders.  The index / weight tensors are views of buffers the BudgetedHierarchy owns: valid until
+    its next ``select`` / ``make_resident`` (enqueue the render first -- stream order does the rest)."""
     n: int                              # entries of the cut
     tau: float                          # the granularity that was rendered (>= the requested one)
     render_indices: torch.Tensor        # int32 [n]: SLOT of the node row
