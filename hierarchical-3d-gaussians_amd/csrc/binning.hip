@@ -227,45 +227,10 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t kLargeCap = 16384;   // 1024-thread workgroup, 128 KiB LDS
 
-template <int THREADS>
-__device__ __forceinline__ void bitonic_sort_lds(uint64_t* keys, uint32_t m) {
-  for (uint32_t k = 2; k <= m; k <<= 1) {
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < (m >> 1); t += THREADS) {
-        // t-th compare-exchange of this stage: i has bit j clear
-        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const uint32_t ixj = i | j;
-        const uint64_t a = keys[i], b = keys[ixj];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { keys[i] = b; keys[ixj] = a; }
-      }
-      __syncthreads();
-    }
-  }
-}
-
-template <int THREADS>
-__device__ __forceinline__ void sort_tile_in_lds(uint64_t* keys, const float* __restrict__ depths,
-                                                 uint32_t* __restrict__ vals, uint32_t r0, uint32_t n) {
-  uint32_t m = 2;
-  while (m < n) m <<= 1;
-  for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
-    uint64_t k = ~0ull;
-    if (i < n) {
-      const uint32_t gid = vals[r0 + i];
-      k = ((uint64_t)__float_as_uint(depths[gid]) << 32) | gid;
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
-  bitonic_sort_lds<THREADS>(keys, m);
-  for (uint32_t i = threadIdx.x; i < n; i += THREADS) vals[r0 + i] = (uint32_t)keys[i];
-}
-
 // ---- register-resident bitonic sort: one WAVE per tile, E keys per lane, no LDS, no barriers ----------------
 // Logical element index i = lane * E + e.  Compare-exchange partners at distance j < E sit in the same lane
 // (pure VALU); at distance j >= E they sit in lane ^ (j / E) and are fetched with a 64-bit lane shuffle.  The
-// LDS version above pays a workgroup barrier per stage (45 stages for 512 keys) and is latency-bound; here the
+// A network kept in LDS pays a workgroup barrier per stage (45 stages for 512 keys) and is latency-bound; here the
 // stages of a wave simply follow each other.  Keys are unique ((depth bits << 32) | id), so the unstable network
 // yields the stable (depth, id) order.
 __device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
@@ -388,14 +353,35 @@ __device__ __forceinline__ void quad_cross_stage(uint64_t (&key)[16], uint64_t* 
   }
 }
 
-// GROUP = 4: the workgroup's four waves sort one tile of 2049 .. 4096 instances.  GROUP = 2: a PAIR of waves (`wv` = the
-// wave's number inside its pair, `lk` = the pair's half of the LDS array) sorts a tile of 1025 .. 2048 -- the two pairs of
-// a workgroup sort two such tiles at the same time (four waves on one 2048-key tile leave two of them sorting padding).
-// n == 0: the group has no tile this round and only keeps the workgroup's barriers company.
+// The merge levels above the waves' own 1024-key blocks: level K pairs keys of different waves at the distances K / 2 ..
+// 1024 (one LDS round trip each) and finishes inside the waves (distances 512 .. 1).  Levels up to `kmax` run (uniform).
+template <int K, int J>
+__device__ __forceinline__ void coop_cross_stages(uint64_t (&key)[16], uint64_t* lk, uint32_t base) {
+  quad_cross_stage<K>(key, lk, base, J);
+  if constexpr (J > 1024) coop_cross_stages<K, J / 2>(key, lk, base);
+}
+template <int K, int KMAX>
+__device__ __forceinline__ void coop_merge_levels(uint64_t (&key)[16], uint64_t* lk, uint32_t base, int lane, uint32_t kmax) {
+  if ((uint32_t)K > kmax) return;
+  coop_cross_stages<K, K / 2>(key, lk, base);
+  wave_sort_block<16, K, 512>(key, lane, base);
+  if constexpr (K < KMAX) coop_merge_levels<K * 2, KMAX>(key, lk, base, lane, kmax);
+}
+
+// GROUP waves sort one tile of up to 1024 GROUP instances together (`wv` = the wave's number inside its group, `lk` = the
+// group's part of the LDS array, 1024 GROUP keys):
+//   GROUP = 4   the workgroup's four waves, 2049 .. 4096 instances;
+//   GROUP = 2   a PAIR of waves, 1025 .. 2048 -- the two pairs of a workgroup sort two such tiles at the same time (four
+//               waves on one 2048-key tile leave two of them sorting padding); n == 0: the pair has no tile this round
+//               and only keeps the workgroup's barriers company;
+//   GROUP = 8 / 16  the 512 / 1024 lanes of the oversized-classes launches, up to 8192 / 16384 instances; only the merge
+//               levels up to the next power of two above n run (the waves above it hold padding and merge it among
+//               themselves).  The LDS-only network this replaces pays a workgroup barrier and a pass over all keys in
+//               LDS for each of its 105 stages at 16 Ki keys; here 10 stages cross waves.
 template <int GROUP>
 __device__ __forceinline__ void coop_sort_tile(uint64_t* lk, const float* __restrict__ depths,
                                                uint32_t* __restrict__ vals, uint32_t r0, uint32_t n, int wv) {
-  static_assert(GROUP == 2 || GROUP == 4, "pair or quad");
+  static_assert(GROUP == 2 || GROUP == 4 || GROUP == 8 || GROUP == 16, "pair, quad, 512 or 1024 lanes");
   const int lane = threadIdx.x & 63;
   if (GROUP == 2 && n == 0) {                   // (uniform per pair) the one cross stage's two barriers
     __syncthreads();
@@ -414,14 +400,13 @@ __device__ __forceinline__ void coop_sort_tile(uint64_t* lk, const float* __rest
     key[e] = k;
   }
   const uint32_t base = (uint32_t)(wv * 1024 + lane * 16);
-  wave_sort_network<16, 2>(key, lane, base);                  // blocks of 1024, directions by bit 10 of the index
-  quad_cross_stage<2048>(key, lk, base, 1024);
-  wave_sort_block<16, 2048, 512>(key, lane, base);
-  if constexpr (GROUP == 4) {
-    quad_cross_stage<4096>(key, lk, base, 2048);
-    quad_cross_stage<4096>(key, lk, base, 1024);
-    wave_sort_block<16, 4096, 512>(key, lane, base);
+  uint32_t kmax = 1024u * GROUP;
+  if constexpr (GROUP >= 8) {
+    kmax = 2048u;
+    while (kmax < n) kmax <<= 1;
   }
+  wave_sort_network<16, 2>(key, lane, base);                  // blocks of 1024, directions by bit 10 of the index
+  coop_merge_levels<2048, 1024 * GROUP>(key, lk, base, lane, kmax);
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const uint32_t i = base + (uint32_t)e;
@@ -497,8 +482,9 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_
   }
 }
 
-// Medium class without QUAD (kWaveCap < n <= kSmallCap): bitonic sort in LDS, one workgroup per listed tile (same launch
-// as the two larger classes: a launch of their own costs more than the work when the lists are short)
+// Medium class without QUAD (kWaveCap < n <= kSmallCap) and the large class (.. kLargeCap): one workgroup of 64 GROUP
+// lanes per listed tile, the register-block sort above.  Large tiles outside (lo, hi] are left to the other launch.
+template <int GROUP>
 __device__ __forceinline__ void sort_medium_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
                                                   const float* __restrict__ depths, uint32_t* __restrict__ vals,
                                                   const uint32_t* __restrict__ big, int T) {
@@ -507,19 +493,21 @@ __device__ __forceinline__ void sort_medium_tiles(unsigned char* smem, const uin
     const uint32_t tile = big[3 + 2 * T + e];
     const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
     __syncthreads();
-    sort_tile_in_lds<1024>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
+    coop_sort_tile<GROUP>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0, (int)(threadIdx.x >> 6));
   }
 }
 
+template <int GROUP>
 __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
                                                  const float* __restrict__ depths, uint32_t* __restrict__ vals,
-                                                 const uint32_t* __restrict__ big, int T) {
+                                                 const uint32_t* __restrict__ big, int T, uint32_t lo, uint32_t hi) {
   const uint32_t count = big[0];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
     const uint32_t tile = big[3 + e];
     const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+    if (r1 - r0 <= lo || r1 - r0 > hi) continue;          // (uniform)
     __syncthreads();
-    sort_tile_in_lds<1024>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0);
+    coop_sort_tile<GROUP>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0, (int)(threadIdx.x >> 6));
   }
 }
 
@@ -602,19 +590,37 @@ __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ran
   }   // tile loop
 }
 
-// One launch for the oversized classes (their lists are almost always empty: a launch each would cost more than the
-// work).  128 KiB of dynamic LDS for the large class + 18 KiB static for the huge class.
+// The oversized classes.  A light frame (their lists are almost always empty: a launch each would cost more than the
+// work) takes ONE launch of the 1024-lane kernel for all of them: 128 KiB of dynamic LDS for the large class + 18 KiB
+// static for the huge class.  A heavy frame (mean list above 1024: thousands of tiles of 4 .. 16 Ki instances -- coarse
+// LOD cuts, big footprints) adds the 512-lane kernel in front for the medium tiles and the large tiles up to 8192: 64
+// KiB of LDS, so TWO tiles per CU are in flight (a tile's sort is a chain of barriers and cross-lane stages: latency,
+// not throughput), and the 1024-lane kernel keeps the tiles above 8192 and the huge class.
+constexpr uint32_t kMidCap = 8192;
+__global__ __launch_bounds__(512) void tile_depth_sort_mid_kernel(const uint32_t* __restrict__ ranges,
+                                                                  const float* __restrict__ depths,
+                                                                  uint32_t* __restrict__ vals,
+                                                                  const uint32_t* __restrict__ big, int T) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  sort_medium_tiles<8>(smem, ranges, depths, vals, big, T);
+  __syncthreads();
+  sort_large_tiles<8>(smem, ranges, depths, vals, big, T, 0u, kMidCap);
+}
+
 __global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
                                                                    uint32_t* __restrict__ vals,
                                                                    uint32_t* __restrict__ scratch_k,
                                                                    uint32_t* __restrict__ scratch_v,
                                                                    uint32_t* __restrict__ scratch_k2,
-                                                                   const uint32_t* __restrict__ big, int T) {
+                                                                   const uint32_t* __restrict__ big, int T,
+                                                                   uint32_t large_lo) {     // 0: also the medium class
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  sort_medium_tiles(smem, ranges, depths, vals, big, T);
-  __syncthreads();
-  sort_large_tiles(smem, ranges, depths, vals, big, T);
+  if (large_lo == 0u) {
+    sort_medium_tiles<16>(smem, ranges, depths, vals, big, T);
+    __syncthreads();
+  }
+  sort_large_tiles<16>(smem, ranges, depths, vals, big, T, large_lo, kLargeCap);
   __syncthreads();
   sort_huge_tiles(ranges, depths, vals, scratch_k, scratch_v, scratch_k2, big, T);
 }
@@ -676,6 +682,8 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   if (!attr_set) {   // 128 KiB of dynamic LDS needs an explicit opt-in
     HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_big_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kLargeCap * 8)));
+    HGS_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_depth_sort_mid_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMidCap * 8)));
     attr_set = true;
   }
   // lists of more than 1024 instances are common when the mean list is long: then the four-wave variant
@@ -685,9 +693,16 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                      fill_tile_ids ? b.keys_out : nullptr);
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
   const int big_grid = T < 256 ? T : 256;
+  const bool heavy = (uint64_t)L > (uint64_t)T * 1024u;
+  if (heavy) {
+    hipLaunchKernelGGL(tile_depth_sort_mid_kernel, dim3(T < 512 ? T : 512), dim3(512), kMidCap * 8, s, b.ranges, g.depths,
+                       b.vals_out, b.big_tiles, T);
+    HGS_LAUNCH_CHECK("tile_depth_sort_mid", s, a.debug);
+  }
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   hipLaunchKernelGGL(tile_depth_sort_big_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,
-                     b.vals_out, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T);
+                     b.vals_out, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T,
+                     heavy ? kMidCap : 0u);
   HGS_LAUNCH_CHECK("tile_depth_sort_big", s, a.debug);
   return HGS_OK;
 }

@@ -298,12 +298,13 @@ def test_4k_8m_gaussians_forward_backward(gpu):
 
 @pytest.mark.parametrize("P,W,H,lo,hi", [(6_000, 64, 48, 512, 1024), (12_000, 64, 48, 1024, 2048),
                                          (18_000, 64, 48, 2048, 4096), (22_000, 64, 48, 2048, 4096),
-                                         (130_000, 64, 64, 4096, 16384), (1_500_000, 64, 48, 16384, 1 << 30)])
+                                         (45_000, 64, 48, 4096, 8192), (130_000, 64, 64, 8192, 16384),
+                                         (1_500_000, 64, 48, 16384, 1 << 30)])
 def test_crowded_tiles_sort_paths(gpu, P, W, H, lo, hi):
     """Every class of the per-tile depth sort: one wave with 16 keys per lane (513 .. 1024 instances), two waves per
     tile and two tiles at a time (.. 2048: the 12 k case), a workgroup holding both pair-class and four-wave tiles (the
-    18 k case: 1 886 .. 2 767 per tile), four waves (.. 4096: the 22 k case), the LDS sort (.. 16 Ki, 1024 lanes) and the
-    global radix fallback (> 16 Ki): the sorted instance list must still be bit-exact.  Forward only; oracle = geometry +
+    18 k case: 1 886 .. 2 767 per tile), four waves (.. 4096: the 22 k case), 512 lanes (.. 8192, two tiles per CU: the 45 k
+    case), 1024 lanes (.. 16 Ki) and the global radix fallback (> 16 Ki): the sorted instance list must still be bit-exact.  Forward only; oracle = geometry +
     binning spec."""
     import diff_gaussian_rasterization as dgr
     from oracle import raster_oracle as ro
