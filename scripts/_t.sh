@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_raster_gpu.py tests/test_scale_parity_gpu.py tests/test_product_paths_gpu.py -m gpu -x -q -p no:cacheprovider -k "crowded or 4k or heavy or trained" 2>&1 | tail -3
-python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-secondary --extras config5_budgeted_6gb,heavy_1m 2>/dev/null | python -c "
+timeout 600 python -m pytest tests/test_residency_gpu.py -m gpu -x -q -s -p no:cacheprovider 2>&1 | tail -4
+python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-stage-timing --extras config5_budgeted_6gb 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-for k,v in d['extra'].items(): print(k, round(v['value'],1), v['unit'], {a:round(b,3) for a,b in v.get('stages_ms',{}).items()})
-print('headline', round(d['value'],1), d['stages_ms']['tile_depth_sort'])"
+for k,v in d['extra'].items(): print(k, round(v['value'],1), v['unit'], v['config']['rendered_tau_px'], v['config']['cuts_per_frame'])"
