@@ -160,9 +160,24 @@ def kernel_source_sha():
                                                                     os.path.join(ROOT, "include", "hgs.h")])
     for f in files:
         h.update(os.path.basename(f).encode())
-        with open(f, "rb") as fh:
-            h.update(fh.read())
+        with open(f, "r", errors="replace") as fh:
+            h.update(_code_only(fh.read()).encode())
     return h.hexdigest()[:16]
+
+
+def _code_only(src):
+    """The source without comments and blank lines (a reworded comment is not another build).  String literals are kept
+    as they are; a comment marker inside one is rare enough in these sources that the simple scan is left alone: it
+    could only make the hash change too often, never too rarely."""
+    import re
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = []
+    for line in src.splitlines():
+        line = re.sub(r"(?<!:)//.*$", "", line) if "#" not in line[:1] else line
+        line = line.rstrip()
+        if line.strip():
+            out.append(line)
+    return "\n".join(out)
 
 
 def _profile_json(name):
