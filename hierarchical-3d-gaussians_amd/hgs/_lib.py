@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
 ABI_VERSION = 5
-INST_GRAD_STRIDE = 12
+INST_GRAD_STRIDE = 10          # floats per (tile, Gaussian) record of the backward scratch (HGS_INST_GRAD_STRIDE)
 ERR_CAPACITY = 5
 
 
