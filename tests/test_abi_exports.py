@@ -55,3 +55,18 @@ def test_workspace_size_queries_need_no_gpu():
     assert w.value >= 2_667_604 * 48
     assert lib.hgs_raster_ws_sizes(-1, 10, 10, 0, None, None, None, None) != 0
     assert b"bad sizes" in lib.hgs_last_error()
+
+
+def test_python_constants_match_the_header_macros():
+    """The numbers the ctypes layer repeats (it cannot include the header) against include/hgs.h."""
+    import ctypes as C
+    src = open(os.path.join(ROOT, "include", "hgs.h")).read()
+    macro = lambda name: int(re.search(rf"#define\s+{name}\s+(\d+)", src).group(1))
+    assert macro("HGS_ABI_VERSION") == _lib.ABI_VERSION
+    assert macro("HGS_INST_GRAD_STRIDE") == _lib.INST_GRAD_STRIDE
+    assert macro("HGS_P2P_MAX_WORLD") == _lib.P2P_MAX_WORLD
+    assert macro("HGS_P2P_HANDLE_BYTES") == _lib.P2P_HANDLE_BYTES
+    assert macro("HGS_P2P_FLAG_BYTES") == _lib.P2P_FLAG_BYTES
+    assert macro("HGS_RESID_COUNTER_WORDS") == _lib.RESID_COUNTER_WORDS
+    assert int(re.search(r"HGS_ERR_CAPACITY\s*=\s*(\d+)", src).group(1)) == _lib.ERR_CAPACITY
+    assert C.sizeof(_lib.ResidRows) == 5 * 8
