@@ -6,6 +6,8 @@ specification of a scene (test infrastructure; imports oracle/):
   quad     one wave per tile, the four 16-lane rows of the wave own the four 8x8 QUADRANTS and walk their OWN lists of
            the 64-instance batch: an iteration serves up to four (instance, quadrant) pairs; iterations per batch =
            the longest of the four lists
+Also reported: the iterations 128-instance batches would need (quad_iterations_b128) and the bound without any batch
+boundary (quad_iterations_unbatched: the longest of a tile's four lists) -- what a record ring could win at most.
 Early termination is ignored.   python tests/tools/quad_stats.py [heavy]"""
 import json
 import os
