@@ -186,3 +186,23 @@ def test_bench_byte_model_is_consistent():
     both = bench.algorithmic_bytes(P, P, L, N, T, M, k=k, deferred_sh=True, sh_forward=True)
     assert frame(both) < frame(deferred) < frame(base)
     assert both["preprocess_fwd"] < base["preprocess_fwd"] and "sh_colors_batched" in both
+
+
+def test_source_stamp_ignores_comments_but_not_code():
+    """bench.kernel_source_sha(): the stamp that ties committed PMC summaries to a build hashes the sources without
+    comments and blank lines -- rewording a comment is not another build, touching code is."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        bench = importlib.import_module("bench")
+    finally:
+        sys.argv = argv
+    a = "int f(int x) {\n  // doubles x\n  return 2 * x;   /* really */\n}\n\n#define URL \"http://a//b\"\n"
+    b = "int f(int x) {\n  return 2 * x;\n}\n#define URL \"http://a//b\"\n"
+    c = "int f(int x) {\n  return 3 * x;\n}\n#define URL \"http://a//b\"\n"
+    assert bench._code_only(a) == bench._code_only(b) != bench._code_only(c)
+    assert "http://a//b" in bench._code_only(a)                  # '//' behind a ':' is not a comment
+    assert len(bench.kernel_source_sha()) == 16
