@@ -170,10 +170,19 @@ def lib():
     return _lib
 
 
+class HgsError(RuntimeError):
+    """A non-zero return code of the C ABI (``.code``: HGS_ERR_*, include/hgs.h); a RuntimeError, as the reference's
+    extensions raise."""
+
+    def __init__(self, message: str, code: int):
+        super().__init__(message)
+        self.code = code
+
+
 def check(rc: int, what: str):
     if rc != 0:
         msg = lib().hgs_last_error()
-        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}")
+        raise HgsError(f"{what} failed (code {rc}): {msg.decode() if msg else '?'}", rc)
 
 
 def ptr(t):

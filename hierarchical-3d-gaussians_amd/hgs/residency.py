@@ -131,7 +131,7 @@ class BudgetedHierarchy:
 
     def make_resident(self, render_indices: torch.Tensor, parent_indices: torch.Tensor):
         """Rows of a cut (int32 GPU tensors of Gaussian rows, equal length) -> (slots of the node rows, slots of the
-        parent rows, rows fetched).  Raises RuntimeError (code 5) when the rows do not fit the budget."""
+        parent rows, rows fetched).  Raises _lib.HgsError with code HGS_ERR_CAPACITY when the rows do not fit the budget."""
         n = int(render_indices.numel())
         assert parent_indices.numel() >= n and n <= self.ro.numel()
         p, dev_i, s = _lib.ptr, self.dev.index or 0, self._stream()
@@ -158,7 +158,7 @@ class BudgetedHierarchy:
                                                     p(self.id_of_slot), p(self.stamp), self.frame,
                                                     C.byref(self._host_rows), C.byref(self._slot_rows), self.M, s, dev_i),
                            "hgs_resid_fetch")
-            except RuntimeError:
+            except _lib.HgsError:
                 # the rows queued by the mark pass (slot_of = -2) go back to "absent"
                 ids = self.miss_ids[:m].long()
                 self.slot_of[ids] = torch.where(self.slot_of[ids] == -2, torch.full_like(self.slot_of[ids], -1),
@@ -190,8 +190,8 @@ class BudgetedHierarchy:
             n = expand_to_size(nodes, boxes, t, viewpoint_gpu, zero3, self.ri, self.pi, self.ni)
             try:
                 ro, po, m = self.make_resident(self.ri[:n], self.pi[:n])
-            except RuntimeError as e:
-                if "code 5" not in str(e):
+            except _lib.HgsError as e:
+                if e.code != _lib.ERR_CAPACITY:
                     raise
                 self.stats["retries"] += 1
                 t = t * growth if t > 0 else 1e-4
