@@ -110,6 +110,18 @@ class BudgetedHierarchy:
         self._slot_rows = _lib.ResidRows(*[C.c_void_p(t.data_ptr()) for t in
                                            (self.means3D, self.shs, self.opacities, self.scales, self.rotations)])
 
+    @classmethod
+    def from_hier_file(cls, path: str, device, budget_mb: Optional[float] = None, budget_rows: Optional[int] = None):
+        """A ``.hier`` file (gaussian_hierarchy._C.load_hierarchy, scene/gaussian_model.py:329) straight into the
+        budgeted form, with the activations the reference applies to a loaded hierarchy: opacity = |alpha|
+        (scene/gaussian_model.py:393), scales = exp(log-scales), rotations normalised (scene/gaussian_model.py:108-116).
+        Returns (BudgetedHierarchy, nodes, boxes) with nodes / boxes on ``device`` (they stay resident: 60 B per node)."""
+        from gaussian_hierarchy._C import load_hierarchy
+        xyz, shs, alpha, log_scales, rots, nodes, boxes = load_hierarchy(path)
+        bh = cls(xyz, shs, alpha.abs(), torch.exp(log_scales), torch.nn.functional.normalize(rots), device,
+                 budget_mb=budget_mb, budget_rows=budget_rows)
+        return bh, nodes.to(device), boxes.to(device)
+
     def __del__(self):
         try:
             for p in getattr(self, "_host_ptrs", {}).values():

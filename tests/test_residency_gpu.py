@@ -119,3 +119,23 @@ def test_index_outside_the_hierarchy_is_refused(gpu):
     bad = torch.tensor([0, 1, bh.G], dtype=torch.int32, device=gpu)
     with pytest.raises(RuntimeError):
         bh.make_resident(bad, bad)
+
+
+def test_hier_file_to_budgeted_render(gpu, tmp_path):
+    """The viewer's chain: a .hier file on disk -> pinned host arrays -> a budget of rows on the GPU -> the same bits as
+    the resident render of the loaded hierarchy (activations as scene/gaussian_model.py applies them to a hierarchy)."""
+    from gaussian_hierarchy._C import write_hierarchy
+    from hgs.residency import BudgetedHierarchy
+    h, attrs, nodes, boxes = _scene(gpu, leaves=3_000, seed=9)
+    path = str(tmp_path / "scene.hier")
+    write_hierarchy(path, h.xyz, h.shs, h.alpha, h.log_scales, h.rots, h.nodes, h.boxes)
+    bh, nodes_f, boxes_f = BudgetedHierarchy.from_hier_file(path, gpu, budget_rows=int(0.8 * h.xyz.shape[0]))
+    assert torch.equal(nodes_f, nodes) and torch.equal(boxes_f, boxes)
+    full = {k: v.to(gpu).contiguous() for k, v in attrs.items()}
+    cam, tau = synth.make_camera(W, H), 0.02
+    sel = bh.select(nodes_f, boxes_f, tau, cam.camera_center.to(gpu), cam.camera_center.cpu())
+    color_ref, radii_ref, n_ref, rows_ref = _reference(gpu, cam, full, nodes, boxes, sel.tau)   # (tau may have been raised)
+    assert sel.n == n_ref and sel.misses == rows_ref <= bh.B
+    arrays = dict(means3D=bh.means3D, shs=bh.shs, opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
+    color, radii = _render(gpu, cam, arrays, sel.render_indices, sel.parent_indices, sel.weights, sel.kids)
+    assert torch.equal(color, color_ref) and torch.equal(radii, radii_ref)
