@@ -344,7 +344,10 @@ __device__ __forceinline__ float load_opacity(const hgs_raster_args& a, int idx,
   return raw;
 }
 
-// Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity'; oracle: raster_oracle.lod_opacity).
+// Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity'; oracle: raster_oracle.lod_opacity): a per-GAUSSIAN remap of
+// the opacity.  k stacked copies of 1 - (1 - o)^(1/k) match one copy of o only where the falloff is 1 (the centre);
+// off-centre the children are more opaque than the parent (measured: profiles/r04_lod_remap_kat.txt).  Whether upstream
+// remaps o or the per-pixel alpha is what the pin kit's upstream_raster_post.npz decides; this stays one function.
 __device__ __forceinline__ float lod_opacity(float o, float w, int kids, float* dout_do) {
   if (kids < 2) {
     if (dout_do) *dout_do = 1.0f;

@@ -279,16 +279,35 @@ def lod_opacity(opacity, interp_w, kids):
     """Hierarchy-mode opacity remap (DESIGN.md 'LOD opacity').
 
     A node in transition stands in for one of ``k`` siblings that at w=0 all
-    coincide with their parent; ``k`` stacked copies of opacity
-    ``1-(1-o)^(1/k)`` composite exactly like one copy of opacity ``o``:
+    coincide with their parent:
         o' = w*o + (1-w) * (1 - (1 - min(o, 0.99))^(1/k))      for k >= 2
     and o' = o for k < 2.  Identity when the LOD tensors are empty.
+
+    What the remap does and does not guarantee: ``k`` stacked copies of opacity ``1-(1-o)^(1/k)`` leave the
+    transmittance of ONE copy of opacity ``o`` only where the Gaussian's falloff G is 1 (its centre).  The blended
+    quantity is alpha = o*G, and off-centre ``1-(1-o'G)^k != o*G`` (o = 0.9, k = 2, G = 0.5: 0.567 against 0.45) --
+    the k children are MORE opaque than their parent there.  The exact invariant belongs to a per-PIXEL remap of
+    alpha (``lod_alpha`` below, ``rasterize(..., lod_mode="alpha")``, oracle only).  Which of the two the upstream
+    kernel applies cannot be seen from /root/reference (gaussian_renderer/__init__.py:258-265 only passes the two
+    tensors on); tests/test_oracle_kat.py::test_lod_remap_parent_vs_children measures both against the rationale, and
+    the pin kit's ``upstream_raster_post.npz`` discriminates between them on arrival.
     """
     k = kids.to(opacity.dtype).clamp_min(1.0)
     oc = opacity.clamp(max=ALPHA_MAX)
     stacked = 1.0 - torch.pow(1.0 - oc, 1.0 / k)
     out = interp_w * opacity + (1.0 - interp_w) * stacked
     return torch.where(kids >= 2, out, opacity)
+
+
+def lod_alpha(alpha_raw, interp_w, kids):
+    """ORACLE-ONLY alternative reading of the two hierarchy tensors (``lod_mode="alpha"``): the remap of
+    ``lod_opacity`` applied per pixel to alpha = o*G instead of per Gaussian to o.  With it k coincident children at
+    w = 0 composite EXACTLY like their parent at every pixel ((1 - a')^k = 1 - a).  No kernel implements it."""
+    k = kids.to(alpha_raw.dtype).clamp_min(1.0)
+    ac = alpha_raw.clamp(max=ALPHA_MAX)
+    stacked = 1.0 - torch.pow(1.0 - ac, 1.0 / k)
+    out = interp_w * alpha_raw + (1.0 - interp_w) * stacked
+    return torch.where(kids >= 2, out, alpha_raw)
 
 
 def _cov3d_torch(scales, rotations, scale_modifier):
@@ -317,13 +336,17 @@ class OracleOut:
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
               *, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
               projmatrix, sh_degree, campos, interpolation_weights=None, num_node_kids=None,
-              dtype=torch.float64, tiles=None, fragile_tol=1e-5, geom_dtype=None) -> OracleOut:
+              dtype=torch.float64, tiles=None, fragile_tol=1e-5, geom_dtype=None, lod_mode="opacity") -> OracleOut:
     """Dense per-tile oracle.  All tensor arguments are CPU torch tensors; the
     differentiable ones may require grad.  ``tiles``: optional iterable of tile
     ids to restrict the blend to (bench cpu_baseline sampling); other pixels
     are left at zero.  ``geom_dtype`` (default: ``dtype``): precision of the per-Gaussian
     continuous stage (projection, conic, colour); the blend runs in ``dtype`` on tile-relative
-    coordinates -- ``dtype=float32, geom_dtype=float64`` mirrors the HIP kernels' precision split."""
+    coordinates -- ``dtype=float32, geom_dtype=float64`` mirrors the HIP kernels' precision split.
+    ``lod_mode``: "opacity" = ``lod_opacity`` per Gaussian (what the kernels do); "alpha" = ``lod_alpha`` per pixel
+    (oracle-only alternative, see ``lod_opacity``)."""
+    if lod_mode not in ("opacity", "alpha"):
+        raise ValueError(f"lod_mode {lod_mode!r}")
     H, W = int(image_height), int(image_width)
     # the op receives tanfov / scale_modifier as C floats (GaussianRasterizationSettings -> float32)
     tanfovx, tanfovy = float(np.float32(tanfovx)), float(np.float32(tanfovy))
@@ -397,9 +420,13 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
         d = d / d.norm(dim=1, keepdim=True)
         rgb = torch.clamp_min(eval_sh_torch(int(sh_degree), sel(shs), d) + 0.5, 0.0)
     opac = sel(opacities).reshape(-1)
+    lod_w = lod_k = None
     if interpolation_weights is not None and interpolation_weights.numel() > 0:
-        opac = lod_opacity(opac, cv(interpolation_weights.detach()).reshape(-1)[:P][vidx],
-                           num_node_kids.detach().reshape(-1)[:P][vidx])
+        lod_w = cv(interpolation_weights.detach()).reshape(-1)[:P][vidx]
+        lod_k = num_node_kids.detach().reshape(-1)[:P][vidx]
+        if lod_mode == "opacity":
+            opac = lod_opacity(opac, lod_w, lod_k)
+            lod_w = lod_k = None
     invz = 1.0 / tz
     # hand the per-Gaussian values to the blend precision (pixel centres stay in geom precision
     # until they have been made tile-relative)
@@ -432,6 +459,8 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
             power = -0.5 * (A[ids][None] * dx * dx + C[ids][None] * dy * dy) - B[ids][None] * dx * dy
             G = torch.exp(power)
             araw = opac[ids][None] * G
+            if lod_w is not None:
+                araw = lod_alpha(araw, lod_w[ids][None].to(dtype), lod_k[ids][None])
             alpha = araw + (torch.clamp(araw, max=ALPHA_MAX) - araw).detach()   # straight-through cap
             live = (power <= 0) & (alpha >= ALPHA_MIN)
             a_eff = torch.where(live, alpha, torch.zeros_like(alpha))

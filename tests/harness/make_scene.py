@@ -31,7 +31,10 @@ def rotmat2qvec(R):
     return -q if q[0] < 0 else q
 
 
-def make(path, n_points=240, n_views=6, W=64, H=48, seed=0, hier=True):
+def make(path, n_points=240, n_views=6, W=64, H=48, seed=0, hier=True, radius=None, look_at_depth=None):
+    """radius / look_at_depth: cameras on an ellipse (radius, 0.75 radius) around the origin, turned towards the point
+    (0, 0, look_at_depth) -- a scene extent of a sane size for the densification rules of train_single.py (default: the
+    small 0.4 x 0.3 circle with a 0.04 rad wobble of the short chain test)."""
     from PIL import Image
     from plyfile import PlyData, PlyElement
     from hgs import hierarchy, synth
@@ -49,8 +52,13 @@ def make(path, n_points=240, n_views=6, W=64, H=48, seed=0, hier=True):
     bg = torch.zeros(3)
     for k in range(n_views):
         ang = 2 * math.pi * k / n_views
-        c = np.array([0.4 * math.cos(ang), 0.3 * math.sin(ang), 0.0])
-        yaw, pitch = 0.04 * math.cos(ang), 0.04 * math.sin(ang)
+        if radius is None:
+            c = np.array([0.4 * math.cos(ang), 0.3 * math.sin(ang), 0.0])
+            yaw, pitch = 0.04 * math.cos(ang), 0.04 * math.sin(ang)
+        else:
+            c = np.array([radius * math.cos(ang), 0.75 * radius * math.sin(ang), 0.0])
+            yaw = math.atan2(-c[0], look_at_depth)
+            pitch = math.atan2(c[1], math.hypot(c[0], look_at_depth))
         Ry = np.array([[math.cos(yaw), 0, math.sin(yaw)], [0, 1, 0], [-math.sin(yaw), 0, math.cos(yaw)]])
         Rx = np.array([[1, 0, 0], [0, math.cos(pitch), -math.sin(pitch)], [0, math.sin(pitch), math.cos(pitch)]])
         Rc2w = Ry @ Rx

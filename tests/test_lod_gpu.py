@@ -431,3 +431,36 @@ def test_config5_scale_50m_node_hierarchy_4k(gpu):
             f.write(json.dumps(log) + "\n")
     except OSError:
         pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("o", [0.3, 0.9, 1.3])
+def test_lod_remap_parent_vs_children_on_the_device(gpu, k, o):
+    """The KAT of tests/test_oracle_kat.py::test_lod_remap_parent_vs_children through the HIP op: one parent against
+    its k coincident children at w = 0.  The device must reproduce the ORACLE's images (both follow the per-Gaussian
+    remap ``lod_opacity``), and therefore also its distance from the remap's own rationale -- zero only at the
+    centre, up to 0.29 in alpha for o = 1.3, k = 8 (profiles/r04_lod_remap_kat.txt)."""
+    import json, os
+    import parity as pa
+    import test_oracle_kat as kat
+    bg = torch.zeros(3)
+
+    def hip_render(scene, cam, weights, kids):
+        z = torch.zeros(cam.image_height, cam.image_width)
+        return pa.run_hip(scene, cam, bg, z[None].expand(3, -1, -1), z[None], gpu, interpolation_weights=weights,
+                          num_node_kids=kids, grad_mask=None)["color"].double()
+
+    e_hip, parent_hip = kat.lod_parent_vs_children(hip_render, k, o)
+    e_or, parent_or = kat.lod_parent_vs_children(kat._oracle_lod_render("opacity"), k, o)
+    assert (parent_hip - parent_or).abs().max() <= 1e-5
+    assert abs(e_hip - e_or) <= 2e-5
+    exp = kat.lod_remap_expected(k, o)
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_log.jsonl"), "a") as f:
+            f.write(json.dumps({"case": "lod_remap_kat", "k": k, "o": o, "device_children_vs_parent": e_hip,
+                                "oracle_children_vs_parent": e_or, "predicted": exp}) + "\n")
+    except OSError:
+        pass

@@ -3,6 +3,7 @@ vectorised blend == literal per-pixel loop; float32 geometry spec == float64 tor
 import math
 
 import numpy as np
+import pytest
 import torch
 
 from hgs import synth
@@ -149,6 +150,67 @@ def test_lod_opacity_identity_and_stacking():
     r = ro.lod_opacity(o, torch.zeros(4, dtype=torch.float64), kids)
     assert torch.allclose(1 - (1 - r[:3]) ** 3, o[:3])            # k stacked copies composite like the parent
     assert torch.allclose(ro.lod_opacity(o, torch.ones(4, dtype=torch.float64), kids), o)
+
+
+def lod_parent_vs_children(render, k, o, w=0.0):
+    """One parent Gaussian of opacity ``o`` against its ``k`` coincident children drawn with interpolation weight ``w``
+    and ``num_node_kids = k`` (at w = 0 a child "looks like its parent", gaussian_renderer/__init__.py:204-218).
+    ``render(scene, cam, weights, kids) -> color [3,H,W]``.  Returns (max |children - parent| over the pixels, the
+    parent's image).  Shared by the oracle KAT below and the device KAT in tests/test_lod_gpu.py."""
+    cam = synth.make_camera(64, 64)
+    z, s = 4.0, 0.45                                  # sigma' = sqrt((fy s / z)^2 + 0.3) = 6.3 px
+    sh = torch.zeros(1, 16, 3, dtype=torch.float32)
+    sh[:, 0] = (1.0 - 0.5) / ro.SH_C0                 # DC colour 1: the image IS the accumulated alpha
+    one = synth.Scene(torch.tensor([[0.0, 0.0, z]]), torch.full((1, 3), s), torch.tensor([[1.0, 0.0, 0.0, 0.0]]),
+                      torch.tensor([[o]], dtype=torch.float32), sh, 3)
+    rep = lambda t: t.repeat((k,) + (1,) * (t.dim() - 1)).contiguous()
+    kids_scene = synth.Scene(rep(one.means3D), rep(one.scales), rep(one.rotations), rep(one.opacities), rep(one.shs), 3)
+    parent = render(one, cam, None, None)
+    children = render(kids_scene, cam, torch.full((k,), w, dtype=torch.float32), torch.full((k,), k, dtype=torch.int32))
+    return float((children - parent).abs().max()), parent
+
+
+def _oracle_lod_render(mode):
+    def render(scene, cam, weights, kids):
+        with torch.no_grad():
+            return ro.rasterize(scene.means3D, None, scene.shs, None, scene.opacities, scene.scales, scene.rotations,
+                                None, image_height=cam.image_height, image_width=cam.image_width, tanfovx=cam.tanfovx,
+                                tanfovy=cam.tanfovy, bg=torch.zeros(3), scale_modifier=1.0,
+                                viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+                                campos=cam.camera_center, interpolation_weights=weights, num_node_kids=kids,
+                                lod_mode=mode).color
+    return render
+
+
+def lod_remap_expected(k, o):
+    """sup over the falloff G in (0, 1] of |1 - (1 - o' G)^k - min(0.99, o G)| with o' = lod_opacity(o, w=0, k): what the
+    per-Gaussian remap costs against its own rationale (zero only at G = 1), alpha caps included, the 1/255 skip not."""
+    G = np.linspace(1e-4, 1.0, 20001)
+    op = 1.0 - (1.0 - min(o, 0.99)) ** (1.0 / k)
+    return float(np.abs(1.0 - (1.0 - np.minimum(0.99, op * G)) ** k - np.minimum(0.99, o * G)).max())
+
+
+@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("o", [0.3, 0.9, 1.3])
+def test_lod_remap_parent_vs_children(k, o):
+    """does the hierarchy-mode remap do what its rationale says -- k coincident children at w = 0
+    composite like their parent?  Per-Gaussian remap of o (``lod_opacity``, what the kernels implement): only at the
+    centre; the worst pixel is off by what ``lod_remap_expected`` predicts (up to 0.24 in alpha for o = 1.3, k = 8).
+    Per-pixel remap of alpha (``lod_alpha``, oracle only): exact wherever the children pass the alpha >= 1/255 test
+    (each child carries ~alpha / k, so the parent's alpha below ~k / 255 is lost to the skip rule in BOTH modes: the
+    floor of this comparison).  Numbers: profiles/r04_lod_remap_kat.txt."""
+    e_op, parent = lod_parent_vs_children(_oracle_lod_render("opacity"), k, o)
+    e_al, _ = lod_parent_vs_children(_oracle_lod_render("alpha"), k, o)
+    centre = float(parent[0, 32, 32])
+    assert abs(centre - min(0.99, o * np.exp(-0.5 * (2 * 0.5 ** 2) / ((0.5 * 64 / np.tan(np.pi / 6) * 0.45 / 4.0) ** 2 + 0.3)))) < 1e-6
+    exp = lod_remap_expected(k, o)
+    floor = k / 255.0
+    assert e_al <= floor * 1.01
+    assert abs(e_op - max(exp, min(floor, e_al))) <= 0.02 * exp + floor, (e_op, exp)   # pixel sampling of G + the skip
+    if exp > 4 * floor:
+        assert e_op > 2 * e_al
+    print(f"lod remap KAT k={k} o={o}: per-Gaussian remap max|children - parent| = {e_op:.5f} (predicted {exp:.5f}); "
+          f"per-pixel remap = {e_al:.2e}")
 
 
 def test_saturation_stop_rule_and_last_contributor():

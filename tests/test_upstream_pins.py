@@ -68,8 +68,16 @@ def check_raster_oracle(G, what):
     if "interpolation_weights" in G.files:
         kw = dict(interpolation_weights=torch.from_numpy(G["interpolation_weights"]),
                   num_node_kids=torch.from_numpy(G["num_node_kids"]))
-    oo, og = pa.run_oracle(scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]),
-                           do_depth=bool(G["do_depth"]), mask_fragile=False, **kw)   # the golden's loss covers every pixel
+    args = (scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]))
+    if kw:
+        # the two readings of interpolation_weights / num_node_kids (oracle/raster_oracle.py: lod_opacity per Gaussian --
+        # what the kernels implement -- vs lod_alpha per pixel): say which one upstream's pixels follow before asserting
+        fit = {m: _rel(pa.run_oracle(*args, do_depth=bool(G["do_depth"]), mask_fragile=False, lod_mode=m, **kw)[0]
+                       .color.detach().numpy(), G["out_color"]) for m in ("opacity", "alpha")}
+        print(f"{what}: colour error vs upstream by LOD remap reading: {fit}")
+        assert fit["opacity"] <= REL_TOL or fit["alpha"] > REL_TOL, \
+            f"upstream follows the per-PIXEL alpha remap ({fit}): move lod_opacity() from K1 into the compositing kernels"
+    oo, og = pa.run_oracle(*args, do_depth=bool(G["do_depth"]), mask_fragile=False, **kw)   # the golden's loss covers every pixel
     _compare_raster(oo.color.detach().numpy(), oo.radii.numpy(), oo.invdepth.detach().numpy(),
                     {k: v.numpy() for k, v in og.items()}, G, f"oracle, {what}")
 
