@@ -22,6 +22,11 @@ from oracle import raster_oracle as ro
 
 REL_TOL = 1e-5
 FRAGILE_FRAC = 1e-3
+# element-wise bound: |hip - oracle| <= MIXED_REL * |oracle| + MIXED_ABS * max|oracle| for EVERY
+# entry of every compared tensor -- a relative bound on the entries that matter plus an absolute floor (in units of the
+# tensor's largest entry) for entries that are small sums of large cancelling terms
+MIXED_REL = 1e-5
+MIXED_ABS = 1e-6
 _PAIRED = {}     # fragile-pixel mask of the last run_oracle, consumed by the next run_hip of the same image size
 
 
@@ -115,12 +120,52 @@ def run_hip(scene, cam, bg, gc, gd, device, *, colors_precomp=None, cov3D_precom
 
 
 def err_stats(hip, ref):
+    """Norm-wise (``maxrel`` = max|d| / max|ref|, ``l2``) AND element-wise figures of one tensor pair:
+    ``p999_rel``  99.9th percentile of |d| / |ref| over the entries with |ref| >= 1e-3 max|ref|;
+    ``mixed``     max over ALL entries of |d| / (MIXED_REL |ref| + MIXED_ABS max|ref|)  (<= 1 passes ``assert_stats``)."""
     a, b = hip.double().reshape(-1), ref.double().reshape(-1)
-    scale = b.abs().max().item()
+    scale = b.abs().max().item() if b.numel() else 0.0
     if scale == 0:
-        return dict(maxrel=a.abs().max().item(), l2=a.norm().item(), scale=0.0)
-    return dict(maxrel=((a - b).abs().max() / scale).item(),
-                l2=((a - b).norm() / b.norm()).item(), scale=scale)
+        return dict(maxrel=a.abs().max().item() if a.numel() else 0.0, l2=a.norm().item(), scale=0.0, p999_rel=0.0,
+                    mixed=0.0 if not a.numel() or a.abs().max().item() == 0 else float("inf"))
+    d = (a - b).abs()
+    big = b.abs() >= 1e-3 * scale
+    rel = (d[big] / b.abs()[big])
+    p999 = torch.quantile(rel, 0.999).item() if rel.numel() <= 16_000_000 else \
+        rel.kthvalue(max(1, int(0.999 * rel.numel()))).values.item()
+    return dict(maxrel=(d.max() / scale).item(), l2=((a - b).norm() / b.norm()).item(), scale=scale, p999_rel=p999,
+                mixed=(d / (MIXED_REL * b.abs() + MIXED_ABS * scale)).max().item())
+
+
+def assert_stats(name, stats, rel_tol=REL_TOL, mixed_tol=1.0):
+    """Every tensor of a ``compare`` result within tolerance: norm-wise (maxrel, relative L2 <= rel_tol) and
+    element-wise (``mixed`` <= mixed_tol, see MIXED_REL / MIXED_ABS)."""
+    for k, v in stats.items():
+        if not isinstance(v, dict):
+            continue
+        assert v["maxrel"] <= rel_tol, f"{name}: {k} max error {v['maxrel']:.3e} (rel. to max) > {rel_tol}"
+        assert v["l2"] <= rel_tol, f"{name}: {k} rel-L2 error {v['l2']:.3e} > {rel_tol}"
+        assert v["mixed"] <= mixed_tol, (f"{name}: {k} element-wise error {v['mixed']:.3f} x the bound "
+                                         f"{MIXED_REL}|ref| + {MIXED_ABS} max|ref|")
+
+
+def rows_touching_fragile(oracle_out):
+    """How many Gaussians (gradient rows) have a fragile pixel inside their footprint rectangle -- an upper bound on
+    the rows whose gradients lost a term to the fragile-pixel mask."""
+    fr = oracle_out.fragile
+    if not fr.any():
+        return 0
+    g = oracle_out.geom
+    H, W = fr.shape
+    ii = np.zeros((H + 1, W + 1), dtype=np.int64)
+    ii[1:, 1:] = fr.astype(np.int64).cumsum(0).cumsum(1)
+    vis = g.visible
+    x0 = np.clip(np.floor(g.px[vis] - g.radii[vis]).astype(np.int64), 0, W)
+    x1 = np.clip(np.ceil(g.px[vis] + g.radii[vis]).astype(np.int64) + 1, 0, W)
+    y0 = np.clip(np.floor(g.py[vis] - g.radii[vis]).astype(np.int64), 0, H)
+    y1 = np.clip(np.ceil(g.py[vis] + g.radii[vis]).astype(np.int64) + 1, 0, H)
+    cnt = ii[y1, x1] - ii[y0, x1] - ii[y1, x0] + ii[y0, x0]
+    return int((cnt > 0).sum())
 
 
 def check_indices(hip, oracle_out):
@@ -151,7 +196,7 @@ def check_indices(hip, oracle_out):
 
 def compare(hip, oracle_out, oracle_grads, do_depth=True):
     ok = torch.from_numpy(~oracle_out.fragile)
-    stats = {"fragile_frac": float(oracle_out.fragile.mean())}
+    stats = {"fragile_frac": float(oracle_out.fragile.mean()), "rows_touching_fragile": rows_touching_fragile(oracle_out)}
     c_h, c_o = hip["color"][:, ok], oracle_out.color.detach()[:, ok]
     stats["color"] = err_stats(c_h, c_o)
     if do_depth:

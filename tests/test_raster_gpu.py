@@ -35,11 +35,7 @@ def _assert_case(name, hip, oo, og, do_depth=True):
         print("   ", k, v)
     assert all(v == 0 for v in idx.values()), f"{name}: integer mismatch {idx}"
     assert st["fragile_frac"] <= pa.FRAGILE_FRAC
-    for k, v in st.items():
-        if k == "fragile_frac":
-            continue
-        assert v["maxrel"] <= pa.REL_TOL, f"{name}: {k} max error {v['maxrel']:.3e} (rel. to max) > {pa.REL_TOL}"
-        assert v["l2"] <= pa.REL_TOL, f"{name}: {k} rel-L2 error {v['l2']:.3e} > {pa.REL_TOL}"
+    pa.assert_stats(name, st)
 
 
 def test_config1_1k_128(gpu):

@@ -65,7 +65,7 @@ def _compare(hip, oo, og):
     st = pa.compare(hip, oo, og)
     assert st["fragile_frac"] <= pa.FRAGILE_FRAC
     for k, v in st.items():
-        if k != "fragile_frac":
+        if isinstance(v, dict):
             assert v["maxrel"] <= pa.REL_TOL and v["l2"] <= pa.REL_TOL, (k, v)
 
 
