@@ -372,6 +372,8 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
     sc, zero3 = torch.exp(h.log_scales), torch.zeros(3)
     st = {"i": 0, "n": [], "L": [], "cut_s": 0.0}
     from diff_gaussian_rasterization import _C as dgrC
+    from gaussian_hierarchy import _C as ghC
+    ghC.set_viewpoint_cache(True)       # a viewer loop that keeps its Camera objects (restored by run_extras)
 
     def frame():
         j = st["i"] % len(cams); st["i"] += 1
@@ -461,70 +463,131 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
     """BASELINE configs[4] with its "VRAM-budgeted streaming LOD": the same 50 M-node hierarchy, but the attribute rows
     (11.8 GB) live in pinned HOST memory and the GPU holds `budget_mb` of them (hgs/residency.py; the reference viewer's
     --budget, README.md:233-235).  Per frame: cut + weights, the cut's rows made resident (misses fetched over PCIe by a
-    kernel that reads the host arrays), 3840x2160 render through the in-op LOD path on the slot arrays.  The requested
-    granularity does not fit the budget: the loop settles at the finest one that does, as the reference's viewer."""
+    kernel that reads the host arrays), 3840x2160 render through the in-op LOD path on the slot arrays.
+
+    The camera FLIES: forward through the scene by 0.08 units per frame (the cut changes on every frame: rows are
+    fetched and slots recycled continuously), with one jump sideways halfway (a burst).  A requested granularity that does
+    not fit the budget settles at the finest one that does, as the reference's viewer.  For comparison the SAME path is
+    then rendered from the fully resident hierarchy at the granularity each budgeted frame settled at
+    (``resident_same_path``), and the last frame of both is compared bit for bit."""
+    import numpy as np
     import diff_gaussian_rasterization as dgr
     from diff_gaussian_rasterization import _C as dgrC
+    from gaussian_hierarchy import _C as ghC
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
     from hgs import hierarchy, synth
     from hgs.residency import BudgetedHierarchy
     W, H = 3840, 2160
     cam = synth.make_camera(W, H)
     h = hierarchy.build_hierarchy_on_device(leaves, cam, dev, seed=0)
     G = h.nodes.shape[0]
+    full = dict(means3D=h.xyz, shs=h.shs, opacities=h.alpha, scales=torch.exp(h.log_scales), rotations=h.rots)
     t0 = time.perf_counter()
-    bh = BudgetedHierarchy(h.xyz.cpu(), h.shs.cpu(), h.alpha.cpu(), torch.exp(h.log_scales).cpu(), h.rots.cpu(), dev,
-                           budget_mb=budget_mb)
+    bh = BudgetedHierarchy(full["means3D"].cpu(), full["shs"].cpu(), full["opacities"].cpu(), full["scales"].cpu(),
+                           full["rotations"].cpu(), dev, budget_mb=budget_mb)
     t_host = time.perf_counter() - t0
     nodes, boxes = h.nodes, h.boxes
-    del h
-    torch.cuda.empty_cache()
-    cams = [synth.orbit_camera(W, H, j, 8, radius=0.05, tilt=0.004) for j in range(8)]
+    total = warmup + steps
+    jump = warmup + steps // 2
+
+    def pose(k):            # world-to-camera translation of frame k: forward 0.08 per frame, 2 units sideways at the jump
+        return np.array([-(2.0 if k >= jump else 0.0), 0.0, -0.08 * k])
+    cams = [synth.make_camera(W, H, T=pose(k)) for k in range(total)]
+    for c in cams:
+        _settings(dgr, c, dev)                                  # camera tensors onto the GPU before the clock runs
     vps = [(c.camera_center.to(dev), c.camera_center.cpu()) for c in cams]
     tau = (2 * tau_px + 1) * cam.tanfovx / (0.5 * W)
-    m2 = torch.zeros(bh.B, 3, device=dev)
-    st = {"i": 0, "sel": []}
+    m2 = torch.zeros(max(bh.B, G), 3, device=dev)
+    st = {"sel": []}
 
-    def frame():
-        j = st["i"] % len(cams); st["i"] += 1
-        sel = bh.select(nodes, boxes, tau, vps[j][0], vps[j][1])
-        rs = _settings(dgr, cams[j], dev, do_depth=False, interpolation_weights=sel.weights, num_node_kids=sel.kids,
+    def frame(k):
+        sel = bh.select(nodes, boxes, tau, vps[k][0], vps[k][1])
+        rs = _settings(dgr, cams[k], dev, do_depth=False, interpolation_weights=sel.weights, num_node_kids=sel.kids,
                        render_indices=sel.render_indices, parent_indices=sel.parent_indices)
         with torch.no_grad():
-            color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=bh.means3D, means2D=m2, shs=bh.shs,
+            color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=bh.means3D, means2D=m2[:bh.B], shs=bh.shs,
                                                          opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
         st["sel"].append((sel.n, sel.tau, sel.misses, sel.attempts))
         return color
 
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    frame()                                                     # cold start: the whole working set crosses PCIe
-    torch.cuda.synchronize(); t_cold = time.perf_counter() - t0
-    cold = dict(bh.stats)
-    for _ in range(max(warmup - 1, 0)):
-        frame()
-    torch.cuda.synchronize()
-    st["sel"].clear()
-    f0 = bh.stats["rows_fetched"]
-    miss0 = dgrC.stats["capacity_misses"]
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        frame()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    sels = st["sel"]
+    prev_cache = ghC.set_viewpoint_cache(True)
+    try:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        frame(0)                                                # cold start: the whole working set crosses PCIe
+        torch.cuda.synchronize(); t_cold = time.perf_counter() - t0
+        cold = dict(bh.stats)
+        for k in range(1, warmup):
+            frame(k)
+        torch.cuda.synchronize()
+        st["sel"].clear()
+        f0, e0 = bh.stats["rows_fetched"], bh.stats["evictions"]
+        miss0 = dgrC.stats["capacity_misses"]
+        bh.profile_fetch, bh.fetch_events = True, []
+        ends = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        ends[0].record()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            color_b = frame(warmup + i)
+            ends[i + 1].record()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        bh.profile_fetch = False
+        sels = list(st["sel"])
+        frame_ms = sorted(ends[i].elapsed_time(ends[i + 1]) for i in range(steps))
+        fetch_rows = sum(m for m, _, _ in bh.fetch_events)
+        fetch_ms = sum(a.elapsed_time(b) for _, a, b in bh.fetch_events)
+        # ---- the same path from the fully resident hierarchy, at the granularity each budgeted frame settled at ----------
+        ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+        w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+
+        def resident(k, t):
+            n = expand_to_size(nodes, boxes, t, vps[k][0], torch.zeros(3), ri, pi, ni)
+            get_interpolation_weights(ni[:n], t, nodes, boxes, vps[k][1], torch.zeros(3), w, ns)
+            rs = _settings(dgr, cams[k], dev, do_depth=False, interpolation_weights=w, num_node_kids=ns,
+                           render_indices=ri[:n], parent_indices=pi)
+            with torch.no_grad():
+                return dgr.GaussianRasterizer(rs)(means3D=full["means3D"], means2D=m2[:G], shs=full["shs"],
+                                                  opacities=full["opacities"], scales=full["scales"],
+                                                  rotations=full["rotations"])[0]
+        for i in range(min(3, steps)):
+            resident(warmup + i, sels[i][1])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(steps):
+            color_r = resident(warmup + i, sels[i][1])
+        torch.cuda.synchronize()
+        elapsed_res = time.perf_counter() - t0
+        same_bits = bool(torch.equal(color_b, color_r))
+    finally:
+        ghC.set_viewpoint_cache(prev_cache)
+    px = lambda t: (t * (0.5 * W) / cam.tanfovx - 1) / 2
+    rows = [s[2] for s in sels]
     return {"what": "BASELINE configs[4] with VRAM-budgeted streaming LOD: the 50 M-node hierarchy's attribute rows in pinned "
                     "host memory, a budget of them on the GPU (hgs/residency.py), per frame cut + weights + residency + "
-                    "3840x2160 render on the slot arrays (forward only)",
+                    "3840x2160 render on the slot arrays (forward only); camera flying forward 0.08 units per frame with one "
+                    "2-unit jump sideways halfway",
             "metric": "rendered frames/s @ 3840x2160", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
             "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+            "frame_ms": {"p50": frame_ms[len(frame_ms) // 2], "p99": frame_ms[min(len(frame_ms) - 1, int(0.99 * len(frame_ms)))],
+                         "max": frame_ms[-1], "min": frame_ms[0]},
+            "resident_same_path": {"ms_per_step": elapsed_res / steps * 1e3, "value": steps / elapsed_res,
+                                   "last_frame_bit_identical": same_bits,
+                                   "what": "the same camera path from the fully resident hierarchy at the granularity "
+                                           "each budgeted frame settled at"},
             "config": {"hierarchy_nodes": G, "attribute_bytes_on_host": int(G * bh.row_bytes), "budget_mb": budget_mb,
                        "budget_rows": bh.B, "requested_tau_px": tau_px,
-                       "rendered_tau_px": (sum(s[1] for s in sels) / len(sels) * (0.5 * W) / cam.tanfovx - 1) / 2,
+                       "rendered_tau_px": sum(px(s[1]) for s in sels) / len(sels),
+                       "rendered_tau_px_range": [px(min(s[1] for s in sels)), px(max(s[1] for s in sels))],
                        "mean_cut": sum(s[0] for s in sels) / len(sels),
                        "cuts_per_frame": sum(s[3] for s in sels) / len(sels),
                        "rows_fetched_per_frame": (bh.stats["rows_fetched"] - f0) / steps,
+                       "rows_fetched_per_frame_min_median_max": [min(rows), sorted(rows)[len(rows) // 2], max(rows)],
+                       "rows_fetched_share_of_cut_median": sorted(r / max(s[0], 1) for r, s in zip(rows, sels))[len(rows) // 2],
+                       "fetch_kernel": {"launches": len(bh.fetch_events), "rows": fetch_rows, "ms": fetch_ms,
+                                        "pcie_GBps": fetch_rows * bh.row_bytes / max(fetch_ms, 1e-9) / 1e6},
+                       "evictions": bh.stats["evictions"] - e0,
                        "cold_start": {"seconds": t_cold, "rows": cold["rows_fetched"],
                                       "pcie_GBps": cold["bytes_fetched"] / t_cold / 1e9},
-                       "host_copy_s": t_host, "evictions": bh.stats["evictions"],
+                       "host_copy_s": t_host,
                        "capacity_misses": dgrC.stats["capacity_misses"] - miss0, "width": W, "height": H}}
 
 
@@ -545,7 +608,7 @@ def run_extras(args, dev, measure):
                                          "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
         "config3_train_post": lambda: extra_train_post(dev, measure, 40, 8),
         "config5_50m_4k_render": lambda: extra_config5(dev, *C5_STEPS),
-        "config5_budgeted_6gb": lambda: extra_config5_budgeted(dev, 16, 8),
+        "config5_budgeted_6gb": lambda: extra_config5_budgeted(dev, 32, 8),
     }
     for name in wanted:
         if name not in jobs:
@@ -556,6 +619,8 @@ def run_extras(args, dev, measure):
         except Exception as e:          # an extra must never take the headline line down with it
             out[name] = {"error": repr(e)}
         out[name]["wall_s"] = time.perf_counter() - t0
+        from gaussian_hierarchy import _C as ghC
+        ghC.set_viewpoint_cache(False)
         torch.cuda.empty_cache()
     return out
 

@@ -3,6 +3,7 @@
 #include "common.h"
 
 #include <pthread.h>
+#include <sched.h>
 #include <stdlib.h>
 #include <time.h>
 #include <string.h>
@@ -93,6 +94,15 @@ static bool blocking_waits() {
   static const bool b = getenv("HGS_BLOCKING_WAIT") != nullptr;
   return b;
 }
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  __asm__ __volatile__("yield");
+#else
+  sched_yield();
+#endif
+}
 template <typename Query>
 static bool poll_done(Query query, hipError_t* result) {
   if (blocking_waits()) return false;
@@ -102,7 +112,7 @@ static bool poll_done(Query query, hipError_t* result) {
     const hipError_t q = query();
     if (q != hipErrorNotReady) { *result = q; return true; }
     (void)hipGetLastError();                       // "not ready" is not an error to keep
-    __builtin_ia32_pause();
+    cpu_relax();
     if ((i & 255u) == 255u) {
       timespec t;
       clock_gettime(CLOCK_MONOTONIC, &t);

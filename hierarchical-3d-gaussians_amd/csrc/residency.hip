@@ -13,19 +13,25 @@ namespace {
 
 constexpr int kAges = 64;
 
+// `weights` (nullable): interpolation weight of every entry of the cut.  The rasterizer's in-op LOD gather does not read
+// the parent row of an entry whose weight is exactly 1 (gaussian_math.h: lod_row_gather -- 82 % of the entries of the
+// 50 M-node render loop), so that parent need not be resident for this entry: its slot is reported as the node's own.
 __global__ __launch_bounds__(256) void resid_mark_kernel(const int32_t* __restrict__ ri, const int32_t* __restrict__ pi,
-                                                         int n, int G, int32_t* __restrict__ slot_of,
-                                                         uint32_t* __restrict__ stamp, uint32_t frame,
-                                                         int32_t* __restrict__ miss_ids, uint32_t* __restrict__ counters,
-                                                         int32_t* __restrict__ ro, int32_t* __restrict__ po) {
+                                                         const float* __restrict__ weights, int n, int G,
+                                                         int32_t* __restrict__ slot_of, uint32_t* __restrict__ stamp,
+                                                         uint32_t frame, int32_t* __restrict__ miss_ids,
+                                                         uint32_t* __restrict__ counters, int32_t* __restrict__ ro,
+                                                         int32_t* __restrict__ po) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
+  const bool need_parent = !weights || weights[i] != 1.0f;
   const int32_t ids[2] = {ri[i], pi[i]};
   int32_t out[2];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int32_t id = ids[k];
     if (id < 0 || id >= G) { counters[2] = 1u; out[k] = -1; continue; }     // (benign race: every writer stores 1)
+    if (k == 1 && !need_parent) { out[1] = out[0]; continue; }
     int32_t s = slot_of[id];
     if (s == -1) {                               // absent: exactly one lane of the launch queues it
       const int32_t old = atomicCAS(&slot_of[id], -1, -2);
@@ -40,12 +46,14 @@ __global__ __launch_bounds__(256) void resid_mark_kernel(const int32_t* __restri
 }
 
 __global__ __launch_bounds__(256) void resid_remap_kernel(const int32_t* __restrict__ ri, const int32_t* __restrict__ pi,
-                                                          int n, const int32_t* __restrict__ slot_of,
+                                                          const float* __restrict__ weights, int n,
+                                                          const int32_t* __restrict__ slot_of,
                                                           int32_t* __restrict__ ro, int32_t* __restrict__ po) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  ro[i] = slot_of[ri[i]];
-  po[i] = slot_of[pi[i]];
+  const int32_t r = slot_of[ri[i]];
+  ro[i] = r;
+  po[i] = (!weights || weights[i] != 1.0f) ? slot_of[pi[i]] : r;
 }
 
 // occupied slots by age = min(frame - stamp, kAges - 1)
@@ -75,28 +83,43 @@ __global__ __launch_bounds__(256) void resid_evict_kernel(const uint32_t* __rest
   free_list[atomicAdd(&counters[1], 1u)] = s;
 }
 
-// one wave per missing row: slot from the top of the free stack, 3 M + 11 floats from the host arrays into the slot arrays
+// Sixteen lanes per missing row, four rows per wave: slot from the top of the free stack, 3 M + 11 floats from the host
+// arrays into the slot arrays.  The SH block (3 M floats; 192 B at M = 16, rows 16-byte aligned whenever 3 M % 4 == 0) and
+// the quaternion move as 16-byte loads -- a quarter of the PCIe read requests of a float-per-lane copy -- and the miss
+// list is sorted for bulk fetches (hgs/residency.py), so the four rows of a wave are usually neighbours in the host
+// arrays and their requests fall into the same pages.
+template <bool kVec>
 __global__ __launch_bounds__(256) void resid_fetch_kernel(const int32_t* __restrict__ miss_ids, uint32_t m,
                                                           const int32_t* __restrict__ free_list, uint32_t free_top,
                                                           int32_t* __restrict__ slot_of, int32_t* __restrict__ id_of_slot,
                                                           uint32_t* __restrict__ stamp, uint32_t frame,
                                                           hgs_resid_rows src, hgs_resid_rows dst, int nsh) {
-  const uint32_t j = blockIdx.x * 4u + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const uint32_t j = blockIdx.x * 16u + (threadIdx.x >> 4);
+  const int sub = threadIdx.x & 15;
   if (j >= m) return;
   const size_t id = (size_t)miss_ids[j];
   const size_t s = (size_t)free_list[free_top - 1u - j];
-  if (lane == 0) {
+  if (kVec) {                                      // nsh % 4 == 0, nsh <= 48: lanes 0..11 one float4 of the SH block each
+    if (sub * 4 < nsh)
+      reinterpret_cast<float4*>(dst.shs + s * nsh)[sub] = reinterpret_cast<const float4*>(src.shs + id * nsh)[sub];
+  } else {
+    for (int c = sub; c < nsh; c += 12)
+      if (sub < 12) dst.shs[s * nsh + c] = src.shs[id * nsh + c];
+  }
+  if (sub == 12) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dst.means3D[s * 3 + t] = src.means3D[id * 3 + t];
+  } else if (sub == 13) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t) dst.scales[s * 3 + t] = src.scales[id * 3 + t];
+  } else if (sub == 14) {
+    reinterpret_cast<float4*>(dst.rotations)[s] = reinterpret_cast<const float4*>(src.rotations)[id];
+  } else if (sub == 15) {
+    dst.opacities[s] = src.opacities[id];
     slot_of[id] = (int32_t)s;
     id_of_slot[s] = (int32_t)id;
     stamp[s] = frame;
   }
-  if (lane < nsh) dst.shs[s * nsh + lane] = src.shs[id * nsh + lane];           // nsh <= 48
-  const int t = lane - 48;                       // lanes 48..58: mean (3), scale (3), rotation (4), opacity (1)
-  if (t >= 0 && t < 3) dst.means3D[s * 3 + t] = src.means3D[id * 3 + t];
-  else if (t >= 3 && t < 6) dst.scales[s * 3 + (t - 3)] = src.scales[id * 3 + (t - 3)];
-  else if (t >= 6 && t < 10) dst.rotations[s * 4 + (t - 6)] = src.rotations[id * 4 + (t - 6)];
-  else if (t == 10) dst.opacities[s] = src.opacities[id];
 }
 
 }  // namespace
@@ -125,7 +148,7 @@ static int read_words(uint32_t* dst_host, const uint32_t* src_dev, int words, hi
   return HGS_OK;
 }
 
-int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, int32_t G,
+int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n, int32_t G,
                    int32_t* slot_of, uint32_t* stamp, uint32_t frame, int32_t* miss_ids, uint32_t* counters,
                    int32_t* ro, int32_t* po, uint32_t* miss_count_host, hgs_stream_t stream, int device) {
   if (!miss_count_host) { set_error("null miss_count_host"); return HGS_ERR_INVALID; }
@@ -138,14 +161,15 @@ int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices,
   HGS_HIP(hipSetDevice(device));
   hipStream_t s = static_cast<hipStream_t>(stream);
   HGS_HIP(hipMemsetAsync(counters, 0, 4 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(resid_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, n, G,
+  hipLaunchKernelGGL(resid_mark_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, weights, n, G,
                      slot_of, stamp, frame, miss_ids, counters, ro, po);
   HGS_LAUNCH_CHECK("resid_mark", s, false);
   uint32_t w[4] = {0, 0, 0, 0};
   int rc = read_words(w, counters, 4, s);
   if (rc) return rc;
-  if (w[2]) { set_error("a render / parent index lies outside [0, %d)", G); return HGS_ERR_INVALID; }
+  // the misses queued so far are reported on the error path too: the caller has to take them back out of the queue
   *miss_count_host = w[0];
+  if (w[2]) { set_error("a render / parent index lies outside [0, %d)", G); return HGS_ERR_INVALID; }
   return HGS_OK;
 }
 
@@ -214,20 +238,30 @@ int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_lis
     }
     *pp = static_cast<float*>(d);
   }
-  hipLaunchKernelGGL(resid_fetch_kernel, dim3((m + 3) / 4), dim3(256), 0, s, miss_ids, m, free_list, free_top, slot_of,
-                     id_of_slot, stamp, frame, src, *slot_rows, M * 3);
+  // 16-byte moves need every row of the SH blocks and of the quaternions on a 16-byte boundary
+  const bool vec = ((M * 3) & 3) == 0 && ((((uintptr_t)src.shs | (uintptr_t)slot_rows->shs) & 15u) == 0);
+  if ((((uintptr_t)src.rotations | (uintptr_t)slot_rows->rotations) & 15u) != 0) {
+    set_error("rotation arrays must be 16-byte aligned");
+    return HGS_ERR_INVALID;
+  }
+  if (vec)
+    hipLaunchKernelGGL(resid_fetch_kernel<true>, dim3((m + 15) / 16), dim3(256), 0, s, miss_ids, m, free_list, free_top,
+                       slot_of, id_of_slot, stamp, frame, src, *slot_rows, M * 3);
+  else
+    hipLaunchKernelGGL(resid_fetch_kernel<false>, dim3((m + 15) / 16), dim3(256), 0, s, miss_ids, m, free_list, free_top,
+                       slot_of, id_of_slot, stamp, frame, src, *slot_rows, M * 3);
   HGS_LAUNCH_CHECK("resid_fetch", s, false);
   return HGS_OK;
 }
 
-int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, const int32_t* slot_of,
-                    int32_t* ro, int32_t* po, hgs_stream_t stream, int device) {
+int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n,
+                    const int32_t* slot_of, int32_t* ro, int32_t* po, hgs_stream_t stream, int device) {
   if (n <= 0) return HGS_OK;
   if (!render_indices || !parent_indices || !slot_of || !ro || !po) { set_error("null argument"); return HGS_ERR_INVALID; }
   HGS_HIP(hipSetDevice(device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(resid_remap_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, n,
-                     slot_of, ro, po);
+  hipLaunchKernelGGL(resid_remap_kernel, dim3((n + 255) / 256), dim3(256), 0, s, render_indices, parent_indices, weights,
+                     n, slot_of, ro, po);
   HGS_LAUNCH_CHECK("resid_remap", s, false);
   return HGS_OK;
 }

@@ -12,16 +12,32 @@ import torch
 from hgs import _lib
 
 
+# Opt-in (``set_viewpoint_cache(True)``): remember the host copy of a GPU viewpoint ON the tensor object.  A viewer loop
+# that keeps its Camera objects then pays no device-to-host read per frame.  Off by default because the key --
+# (data_ptr, version counter) -- cannot see writes that bypass the version counter (``t.data.copy_()``, ``set_()``,
+# writes from external kernels or through DLPack): a caller that opts in promises not to make those.
+_viewpoint_cache = False
+
+
+def set_viewpoint_cache(on: bool) -> bool:
+    """Enable / disable the per-tensor host copy of GPU viewpoints (see above); returns the previous setting."""
+    global _viewpoint_cache
+    prev, _viewpoint_cache = _viewpoint_cache, bool(on)
+    return prev
+
+
 def _vec3(t) -> "C.Array":
     """The C-ABI takes viewpoints as host floats; the reference passes ``camera_center`` as a GPU tensor
     (train_post.py:96, render_hierarchy.py:63).  Reading it back waits for everything enqueued before it -- the previous
-    frame's render in a viewer loop -- so (a) the host copy is remembered ON the tensor object (keyed by its version
-    counter: an in-place edit re-reads it), and (b) the wait polls the stream instead of sleeping in the blocking copy
-    (the wake-up of a sleeping wait was measured at milliseconds on virtualised hosts)."""
-    if torch.is_tensor(t) and t.is_cuda:
-        cached = getattr(t, "_hgs_vec3", None)
-        if cached is not None and cached[0] == t._version:
-            return cached[1]
+    frame's render in a viewer loop -- so the wait polls the stream instead of sleeping in the blocking copy (the
+    wake-up of a sleeping wait was measured at milliseconds on virtualised hosts); with ``set_viewpoint_cache(True)``
+    the host copy is also remembered on the tensor object (an in-place edit through torch re-reads it)."""
+    on_gpu = torch.is_tensor(t) and t.is_cuda
+    if on_gpu:
+        if _viewpoint_cache:
+            cached = getattr(t, "_hgs_vec3", None)
+            if cached is not None and cached[0] == (t.data_ptr(), t._version):
+                return cached[1]
         stream = torch.cuda.current_stream(t.device)
         deadline = time.perf_counter() + 0.2
         while not stream.query() and time.perf_counter() < deadline:
@@ -30,9 +46,9 @@ def _vec3(t) -> "C.Array":
     if v.numel() != 3:
         raise RuntimeError("expected a 3-vector")
     out = (C.c_float * 3)(*[float(x) for x in v])
-    if torch.is_tensor(t) and t.is_cuda:
+    if on_gpu and _viewpoint_cache:
         try:
-            t._hgs_vec3 = (t._version, out)
+            t._hgs_vec3 = ((t.data_ptr(), t._version), out)
         except Exception:       # (a tensor subclass without a __dict__)
             pass
     return out

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 INST_GRAD_STRIDE = 10          # floats per (tile, Gaussian) record of the backward scratch (HGS_INST_GRAD_STRIDE)
 ERR_CAPACITY = 5
 
@@ -137,13 +137,13 @@ SIGNATURES = {
                                         C.c_uint32, _P, C.c_int]),
     "hgs_host_alloc": (C.c_void_p, [C.c_size_t]),
     "hgs_host_free": (None, [_P]),
-    "hgs_resid_mark": (C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P, _P,
+    "hgs_resid_mark": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, _P, _P, C.c_uint32, _P, _P, _P, _P,
                                  C.POINTER(C.c_uint32), _P, C.c_int]),
     "hgs_resid_evict": (C.c_int, [_P, _P, _P, C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), _P,
                                   C.c_int]),
     "hgs_resid_fetch": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint32, C.POINTER(ResidRows),
                                   C.POINTER(ResidRows), C.c_int32, _P, C.c_int]),
-    "hgs_resid_remap": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int]),
+    "hgs_resid_remap": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int]),
 }
 P2P_MAX_WORLD, P2P_HANDLE_BYTES, P2P_FLAG_BYTES = 8, 64, 256
 RESID_COUNTER_WORDS = 68

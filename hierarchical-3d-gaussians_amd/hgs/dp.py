@@ -208,7 +208,7 @@ class DirectAllReduce:
         lib = _lib.lib()
         own_buf, own_flag = C.c_void_p(), C.c_void_p()
         fine = 2 if os.environ.get("HGS_P2P_FINEGRAINED", "") == "1" else 0
-        self._own, self._opened = None, []
+        self._own, self._opened = [], []          # every pointer is recorded right after its own allocation
         # Every step that can fail for ONE rank only (allocation, hipIpc export, opening a peer) is followed by an
         # exchange of the outcome, so that all ranks raise DirectRouteUnavailable together instead of one raising
         # while the others wait in a collective.
@@ -217,8 +217,9 @@ class DirectAllReduce:
             if os.environ.get("HGS_P2P_INJECT_FAILURE", "") == str(self.rank):     # tests: one rank cannot export
                 raise RuntimeError("injected failure (HGS_P2P_INJECT_FAILURE)")
             _lib.check(lib.hgs_p2p_alloc(padded * 4, fine, C.byref(own_buf), self.dev_index), "hgs_p2p_alloc")
+            self._own.append(own_buf.value)       # (a failing flag-block allocation must not leak the bucket)
             _lib.check(lib.hgs_p2p_alloc(_lib.P2P_FLAG_BYTES, 1, C.byref(own_flag), self.dev_index), "hgs_p2p_alloc")
-            self._own = (own_buf.value, own_flag.value)
+            self._own.append(own_flag.value)
             hb, hf = C.create_string_buffer(_lib.P2P_HANDLE_BYTES), C.create_string_buffer(_lib.P2P_HANDLE_BYTES)
             _lib.check(lib.hgs_p2p_export(own_buf, hb, self.dev_index), "hgs_p2p_export")
             _lib.check(lib.hgs_p2p_export(own_flag, hf, self.dev_index), "hgs_p2p_export")

@@ -14,7 +14,8 @@ slot, or "absent").  Per view::
                            rotations=bh.rotations, means2D=...)
 
 ``select`` runs the reference's two LOD calls (``expand_to_size`` / ``get_interpolation_weights``), marks the rows the
-cut needs (node and parent row of every entry), fetches the missing ones over PCIe with ONE kernel that reads the host
+cut needs (the node row of every entry, and its parent row unless the entry's weight is exactly 1 -- the in-op LOD gather
+does not read that parent), fetches the missing ones over PCIe with ONE kernel that reads the host
 arrays itself (no host-side gather, no staging buffer), recycles the slots that have gone unused for the longest when the
 free list runs out, and returns the cut's indices translated to slots.  A view whose rows do not fit the budget is cut
 again at a coarser granularity (tau x 1.2 per attempt), as the reference's viewer "auto-regulates and raises the
@@ -105,6 +106,8 @@ class BudgetedHierarchy:
         self._regulated = None          # granularity the previous view was coarsened to (None: the request fitted)
         self._since_probe, self.probe_every = 0, 16
         self.stats = dict(views=0, rows_fetched=0, bytes_fetched=0, evictions=0, retries=0)
+        self.profile_fetch = False      # True: (rows, start event, end event) of every fetch launch -> self.fetch_events
+        self.fetch_events = []
         self._host_rows = _lib.ResidRows(*[C.c_void_p(self._host_ptrs[k]) for k in
                                            ("means3D", "shs", "opacities", "scales", "rotations")])
         self._slot_rows = _lib.ResidRows(*[C.c_void_p(t.data_ptr()) for t in
@@ -141,17 +144,36 @@ class BudgetedHierarchy:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def make_resident(self, render_indices: torch.Tensor, parent_indices: torch.Tensor):
+    def make_resident(self, render_indices: torch.Tensor, parent_indices: torch.Tensor,
+                      weights: Optional[torch.Tensor] = None):
         """Rows of a cut (int32 GPU tensors of Gaussian rows, equal length) -> (slots of the node rows, slots of the
-        parent rows, rows fetched).  Raises _lib.HgsError with code HGS_ERR_CAPACITY when the rows do not fit the budget."""
+        parent rows, rows fetched).  ``weights`` (float32 GPU tensor, one interpolation weight per entry, optional): the
+        parent row of an entry of weight exactly 1 is not read by the rasterizer's in-op LOD gather and is therefore
+        neither fetched nor stamped -- its slot is reported as the node's own.  Raises _lib.HgsError with code
+        HGS_ERR_CAPACITY when the rows do not fit the budget."""
         n = int(render_indices.numel())
         assert parent_indices.numel() >= n and n <= self.ro.numel()
+        if weights is not None:
+            assert weights.is_cuda and weights.dtype == torch.float32 and weights.is_contiguous() and weights.numel() >= n
         p, dev_i, s = _lib.ptr, self.dev.index or 0, self._stream()
         self.frame += 1
         miss = C.c_uint32(0)
-        _lib.check(self.lib.hgs_resid_mark(p(render_indices), p(parent_indices), n, self.G, p(self.slot_of), p(self.stamp),
-                                           self.frame, p(self.miss_ids), p(self.counters), p(self.ro), p(self.po),
-                                           C.byref(miss), s, dev_i), "hgs_resid_mark")
+
+        def unqueue():
+            # the rows queued by the mark pass (slot_of = -2) go back to "absent"
+            k = int(miss.value)
+            if k:
+                ids = self.miss_ids[:k].long()
+                self.slot_of[ids] = torch.where(self.slot_of[ids] == -2, torch.full_like(self.slot_of[ids], -1),
+                                                self.slot_of[ids])
+
+        try:
+            _lib.check(self.lib.hgs_resid_mark(p(render_indices), p(parent_indices), p(weights), n, self.G, p(self.slot_of),
+                                               p(self.stamp), self.frame, p(self.miss_ids), p(self.counters), p(self.ro),
+                                               p(self.po), C.byref(miss), s, dev_i), "hgs_resid_mark")
+        except _lib.HgsError:
+            unqueue()                   # a bad index is reported after the valid rows of the cut were queued
+            raise
         m = int(miss.value)
         if m:
             if m > 4096:
@@ -166,19 +188,22 @@ class BudgetedHierarchy:
                                                         s, dev_i), "hgs_resid_evict")
                     self.stats["evictions"] += int(top.value) - self.free_top
                     self.free_top = int(top.value)
+                if self.profile_fetch:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 _lib.check(self.lib.hgs_resid_fetch(p(self.miss_ids), m, p(self.free_list), self.free_top, p(self.slot_of),
                                                     p(self.id_of_slot), p(self.stamp), self.frame,
                                                     C.byref(self._host_rows), C.byref(self._slot_rows), self.M, s, dev_i),
                            "hgs_resid_fetch")
+                if self.profile_fetch:
+                    e1.record()
+                    self.fetch_events.append((m, e0, e1))
             except _lib.HgsError:
-                # the rows queued by the mark pass (slot_of = -2) go back to "absent"
-                ids = self.miss_ids[:m].long()
-                self.slot_of[ids] = torch.where(self.slot_of[ids] == -2, torch.full_like(self.slot_of[ids], -1),
-                                                self.slot_of[ids])
+                unqueue()
                 raise
             self.free_top -= m
-            _lib.check(self.lib.hgs_resid_remap(p(render_indices), p(parent_indices), n, p(self.slot_of), p(self.ro),
-                                                p(self.po), s, dev_i), "hgs_resid_remap")
+            _lib.check(self.lib.hgs_resid_remap(p(render_indices), p(parent_indices), p(weights), n, p(self.slot_of),
+                                                p(self.ro), p(self.po), s, dev_i), "hgs_resid_remap")
             self.stats["rows_fetched"] += m
             self.stats["bytes_fetched"] += m * self.row_bytes
         return self.ro[:n], self.po[:n], m
@@ -200,15 +225,16 @@ class BudgetedHierarchy:
             t = max(t, self._regulated / growth if probe else self._regulated)
         for attempt in range(1, max_attempts + 1):
             n = expand_to_size(nodes, boxes, t, viewpoint_gpu, zero3, self.ri, self.pi, self.ni)
+            # the weights first: an entry of weight 1 does not need its parent row (make_resident)
+            get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
             try:
-                ro, po, m = self.make_resident(self.ri[:n], self.pi[:n])
+                ro, po, m = self.make_resident(self.ri[:n], self.pi[:n], self.w)
             except _lib.HgsError as e:
                 if e.code != _lib.ERR_CAPACITY:
                     raise
                 self.stats["retries"] += 1
                 t = t * growth if t > 0 else 1e-4
                 continue
-            get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
             self.stats["views"] += 1
             self._regulated = t if t > float(tau) else None
             return Selection(n, t, ro, po, self.w, self.ns, m, attempt)

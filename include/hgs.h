@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 5
+#define HGS_ABI_VERSION 6
 #define HGS_TILE 16
 #define HGS_INST_GRAD_STRIDE 10 /* floats per (tile, Gaussian) instance in the backward scratch (40 bytes: the ten sums) */
 
@@ -417,7 +417,9 @@ int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* 
  * whose implementation lives in the un-vendored SIBR viewer; BASELINE configs[4] names it).  Opt-in layer BESIDE the
  * drop-in path (hgs/residency.py): the full attribute arrays stay in pinned, device-mapped HOST memory
  * (hgs_host_alloc); the GPU holds `B` rows in slot arrays.  Per view, after the LOD cut:
- *   hgs_resid_mark    every row the cut needs (node row and parent row of each entry): resident -> stamped with the
+ *   hgs_resid_mark    every row the cut needs (node row of each entry, and its parent row unless `weights` -- nullable,
+ *                     the entries' interpolation weights -- says the weight is exactly 1: the in-op LOD gather does
+ *                     not read that parent, and po then repeats the node's slot): resident -> stamped with the
  *                     frame number; absent -> appended ONCE to the miss list (slot_of: >= 0 slot, -1 absent, -2 queued
  *                     this frame); ro / po receive the slots of the resident rows.  Waits; *miss_count_host.
  *   hgs_resid_evict   when the free list is shorter than the miss list: frees the slots that have gone unused for
@@ -444,7 +446,7 @@ typedef struct hgs_resid_rows {
 } hgs_resid_rows;
 void* hgs_host_alloc(size_t bytes);      /* pinned host memory mapped into every device's address space; NULL on failure */
 void hgs_host_free(void* p);
-int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, int32_t G,
+int hgs_resid_mark(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n, int32_t G,
                    int32_t* slot_of, uint32_t* stamp, uint32_t frame, int32_t* miss_ids, uint32_t* counters,
                    int32_t* ro, int32_t* po, uint32_t* miss_count_host, hgs_stream_t stream, int device);
 int hgs_resid_evict(uint32_t* stamp, int32_t* id_of_slot, int32_t* slot_of, int32_t B, uint32_t frame, uint32_t need,
@@ -453,8 +455,8 @@ int hgs_resid_evict(uint32_t* stamp, int32_t* id_of_slot, int32_t* slot_of, int3
 int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_list, uint32_t free_top, int32_t* slot_of,
                     int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const hgs_resid_rows* host_rows,
                     const hgs_resid_rows* slot_rows, int32_t M, hgs_stream_t stream, int device);
-int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, int32_t n, const int32_t* slot_of,
-                    int32_t* ro, int32_t* po, hgs_stream_t stream, int device);
+int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n,
+                    const int32_t* slot_of, int32_t* ro, int32_t* po, hgs_stream_t stream, int device);
 
 #ifdef __cplusplus
 }

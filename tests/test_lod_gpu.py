@@ -42,9 +42,11 @@ def test_expand_to_size_and_weights_match_oracle(gpu, P):
 
 
 def test_viewpoint_on_the_gpu_is_cached_per_tensor_and_follows_in_place_edits(gpu):
-    """expand_to_size takes the viewpoint as a GPU tensor (train_post.py:96); the wrapper remembers its host copy on the
-    tensor object, keyed by the version counter: the same tensor again costs no device-to-host read, an in-place edit
-    is seen, another tensor with other values is another viewpoint."""
+    """expand_to_size takes the viewpoint as a GPU tensor (train_post.py:96); with set_viewpoint_cache(True) the wrapper
+    remembers its host copy on the tensor object, keyed by (data_ptr, version counter): the same tensor again costs no
+    device-to-host read, an in-place edit is seen, another tensor with other values is another viewpoint.  Off (the
+    default): nothing is remembered."""
+    from gaussian_hierarchy import _C as gh
     from gaussian_hierarchy._C import expand_to_size
     h, cam, nodes, boxes = _setup(20_000, gpu)
     G = h.xyz.shape[0]
@@ -54,15 +56,25 @@ def test_viewpoint_on_the_gpu_is_cached_per_tensor_and_follows_in_place_edits(gp
     want = {k: lo.expand_to_size(h.nodes.numpy(), h.boxes.numpy(), tau, v.numpy())[0] for k, v in (("a", a), ("b", b))}
     assert not np.array_equal(want["a"], want["b"])
     vp = a.to(gpu)
-    for _ in range(2):                                   # second call: served from the tensor's cached host copy
-        n = expand_to_size(nodes, boxes, tau, vp, torch.zeros(3), ri, pi, ni)
-        assert np.array_equal(ri[:n].cpu().numpy(), want["a"])
-    assert getattr(vp, "_hgs_vec3")[0] == vp._version
-    vp.copy_(b)                                          # in place: the version counter moves, the cache is stale
+    n = expand_to_size(nodes, boxes, tau, vp, torch.zeros(3), ri, pi, ni)
+    assert not hasattr(vp, "_hgs_vec3")                  # default: no cache; a write that bypasses the version counter
+    vp.data.copy_(b)                                     # is therefore seen
     n = expand_to_size(nodes, boxes, tau, vp, torch.zeros(3), ri, pi, ni)
     assert np.array_equal(ri[:n].cpu().numpy(), want["b"])
-    n = expand_to_size(nodes, boxes, tau, a.to(gpu), torch.zeros(3), ri, pi, ni)      # a fresh tensor
-    assert np.array_equal(ri[:n].cpu().numpy(), want["a"])
+    prev = gh.set_viewpoint_cache(True)
+    try:
+        vp = a.to(gpu)
+        for _ in range(2):                               # second call: served from the tensor's cached host copy
+            n = expand_to_size(nodes, boxes, tau, vp, torch.zeros(3), ri, pi, ni)
+            assert np.array_equal(ri[:n].cpu().numpy(), want["a"])
+        assert getattr(vp, "_hgs_vec3")[0] == (vp.data_ptr(), vp._version)
+        vp.copy_(b)                                      # in place: the version counter moves, the cache is stale
+        n = expand_to_size(nodes, boxes, tau, vp, torch.zeros(3), ri, pi, ni)
+        assert np.array_equal(ri[:n].cpu().numpy(), want["b"])
+        n = expand_to_size(nodes, boxes, tau, a.to(gpu), torch.zeros(3), ri, pi, ni)      # a fresh tensor
+        assert np.array_equal(ri[:n].cpu().numpy(), want["a"])
+    finally:
+        gh.set_viewpoint_cache(prev)
 
 
 def test_single_pass_and_level_by_level_cuts_agree(gpu):
