@@ -573,7 +573,7 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
                                    "last_frame_bit_identical": same_bits,
                                    "what": "the same camera path from the fully resident hierarchy at the granularity "
                                            "each budgeted frame settled at"},
-            "config": {"hierarchy_nodes": G, "attribute_bytes_on_host": int(G * bh.row_bytes), "budget_mb": budget_mb,
+            "config": {"hierarchy_nodes": G, "attribute_bytes_on_host": int(G * bh.row_bytes), "host_row_bytes": 256, "budget_mb": budget_mb,
                        "budget_rows": bh.B, "requested_tau_px": tau_px,
                        "rendered_tau_px": sum(px(s[1]) for s in sels) / len(sels),
                        "rendered_tau_px_range": [px(min(s[1] for s in sels)), px(max(s[1] for s in sels))],
@@ -591,7 +591,7 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
                        "capacity_misses": dgrC.stats["capacity_misses"] - miss0, "width": W, "height": H}}
 
 
-C5_STEPS = (10, 3)      # (steps, warmup) of the configs[4] extra
+C5_STEPS = (16, 8)      # (steps, warmup) of the configs[4] extra: the warm-up sees each of the 8 cameras once
 
 
 def run_extras(args, dev, measure):

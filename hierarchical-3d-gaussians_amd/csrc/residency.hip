@@ -83,39 +83,44 @@ __global__ __launch_bounds__(256) void resid_evict_kernel(const uint32_t* __rest
   free_list[atomicAdd(&counters[1], 1u)] = s;
 }
 
-// Sixteen lanes per missing row, four rows per wave: slot from the top of the free stack, 3 M + 11 floats from the host
-// arrays into the slot arrays.  The SH block (3 M floats; 192 B at M = 16, rows 16-byte aligned whenever 3 M % 4 == 0) and
-// the quaternion move as 16-byte loads -- a quarter of the PCIe read requests of a float-per-lane copy -- and the miss
-// list is sorted for bulk fetches (hgs/residency.py), so the four rows of a wave are usually neighbours in the host
-// arrays and their requests fall into the same pages.
+// Host layout: ONE PACKED ROW of HGS_RESID_HOST_ROW_FLOATS = 64 floats (256 B, four PCIe read requests of 64 B) per
+// Gaussian --
+//   [0, 3 M) SH coefficients   [48, 52) rotation   [52, 55) mean   [55, 58) scale   [58] opacity   rest: padding
+// -- instead of the five attribute arrays: a row fetched from five arrays costs seven 64-byte requests for 236 useful
+// bytes (measured: 21 GB/s of rows over a link that moves twice that in requests).  Sixteen lanes per missing row, four
+// rows per wave: every lane loads ONE float4 of the packed row (one fully coalesced 256-byte read per row), lanes 0..11
+// store the SH block, lane 12 the quaternion, lanes 13 / 14 mean, scale and opacity; the slot comes from the top of the
+// free stack.  The miss list is sorted for bulk fetches (hgs/residency.py), so a wave's four rows are usually
+// neighbours in host memory.
 template <bool kVec>
 __global__ __launch_bounds__(256) void resid_fetch_kernel(const int32_t* __restrict__ miss_ids, uint32_t m,
                                                           const int32_t* __restrict__ free_list, uint32_t free_top,
                                                           int32_t* __restrict__ slot_of, int32_t* __restrict__ id_of_slot,
                                                           uint32_t* __restrict__ stamp, uint32_t frame,
-                                                          hgs_resid_rows src, hgs_resid_rows dst, int nsh) {
+                                                          const float4* __restrict__ src, hgs_resid_rows dst, int nsh) {
   const uint32_t j = blockIdx.x * 16u + (threadIdx.x >> 4);
   const int sub = threadIdx.x & 15;
   if (j >= m) return;
   const size_t id = (size_t)miss_ids[j];
   const size_t s = (size_t)free_list[free_top - 1u - j];
-  if (kVec) {                                      // nsh % 4 == 0, nsh <= 48: lanes 0..11 one float4 of the SH block each
-    if (sub * 4 < nsh)
-      reinterpret_cast<float4*>(dst.shs + s * nsh)[sub] = reinterpret_cast<const float4*>(src.shs + id * nsh)[sub];
-  } else {
-    for (int c = sub; c < nsh; c += 12)
-      if (sub < 12) dst.shs[s * nsh + c] = src.shs[id * nsh + c];
-  }
-  if (sub == 12) {
+  const float4 v = src[id * (HGS_RESID_HOST_ROW_FLOATS / 4) + sub];
+  if (sub < 12) {
+    if (kVec) {                                    // nsh % 4 == 0: slot rows of the SH array are 16-byte aligned
+      if (sub * 4 < nsh) reinterpret_cast<float4*>(dst.shs + s * nsh)[sub] = v;
+    } else {
+      const float c[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-    for (int t = 0; t < 3; ++t) dst.means3D[s * 3 + t] = src.means3D[id * 3 + t];
-  } else if (sub == 13) {
-#pragma unroll
-    for (int t = 0; t < 3; ++t) dst.scales[s * 3 + t] = src.scales[id * 3 + t];
-  } else if (sub == 14) {
-    reinterpret_cast<float4*>(dst.rotations)[s] = reinterpret_cast<const float4*>(src.rotations)[id];
-  } else if (sub == 15) {
-    dst.opacities[s] = src.opacities[id];
+      for (int t = 0; t < 4; ++t)
+        if (sub * 4 + t < nsh) dst.shs[s * nsh + sub * 4 + t] = c[t];
+    }
+  } else if (sub == 12) {
+    reinterpret_cast<float4*>(dst.rotations)[s] = v;
+  } else if (sub == 13) {                          // floats 52..55: mean, scale.x
+    dst.means3D[s * 3 + 0] = v.x; dst.means3D[s * 3 + 1] = v.y; dst.means3D[s * 3 + 2] = v.z;
+    dst.scales[s * 3 + 0] = v.w;
+  } else if (sub == 14) {                          // floats 56..59: scale.y, scale.z, opacity, pad
+    dst.scales[s * 3 + 1] = v.x; dst.scales[s * 3 + 2] = v.y;
+    dst.opacities[s] = v.z;
     slot_of[id] = (int32_t)s;
     id_of_slot[s] = (int32_t)id;
     stamp[s] = frame;
@@ -215,10 +220,10 @@ int hgs_resid_evict(uint32_t* stamp, int32_t* id_of_slot, int32_t* slot_of, int3
 }
 
 int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_list, uint32_t free_top, int32_t* slot_of,
-                    int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const hgs_resid_rows* host_rows,
+                    int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const float* host_rows_packed,
                     const hgs_resid_rows* slot_rows, int32_t M, hgs_stream_t stream, int device) {
   if (m == 0) return HGS_OK;
-  if (!miss_ids || !free_list || !slot_of || !id_of_slot || !stamp || !host_rows || !slot_rows) {
+  if (!miss_ids || !free_list || !slot_of || !id_of_slot || !stamp || !host_rows_packed || !slot_rows) {
     set_error("null argument");
     return HGS_ERR_INVALID;
   }
@@ -226,24 +231,19 @@ int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_lis
   if (free_top < m) { set_error("%u free slots for %u missing rows", free_top, m); return HGS_ERR_CAPACITY; }
   HGS_HIP(hipSetDevice(device));
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hgs_resid_rows src = *host_rows;
-  // the host arrays by their device-side addresses
-  float** ptrs[5] = {&src.means3D, &src.shs, &src.opacities, &src.scales, &src.rotations};
-  for (float** pp : ptrs) {
-    void* d = nullptr;
-    if (!*pp || hipHostGetDevicePointer(&d, *pp, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      set_error("host attribute arrays must come from hgs_host_alloc (pinned, device-mapped)");
-      return HGS_ERR_INVALID;
-    }
-    *pp = static_cast<float*>(d);
-  }
-  // 16-byte moves need every row of the SH blocks and of the quaternions on a 16-byte boundary
-  const bool vec = ((M * 3) & 3) == 0 && ((((uintptr_t)src.shs | (uintptr_t)slot_rows->shs) & 15u) == 0);
-  if ((((uintptr_t)src.rotations | (uintptr_t)slot_rows->rotations) & 15u) != 0) {
-    set_error("rotation arrays must be 16-byte aligned");
+  // the packed host rows by their device-side address
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, const_cast<float*>(host_rows_packed), 0) != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("the packed host rows must come from hgs_host_alloc (pinned, device-mapped)");
     return HGS_ERR_INVALID;
   }
+  if (((uintptr_t)d | (uintptr_t)slot_rows->rotations) & 15u) {
+    set_error("packed host rows / slot rotations must be 16-byte aligned");
+    return HGS_ERR_INVALID;
+  }
+  const float4* src = static_cast<const float4*>(d);
+  const bool vec = ((M * 3) & 3) == 0 && (((uintptr_t)slot_rows->shs & 15u) == 0);
   if (vec)
     hipLaunchKernelGGL(resid_fetch_kernel<true>, dim3((m + 15) / 16), dim3(256), 0, s, miss_ids, m, free_list, free_top,
                        slot_of, id_of_slot, stamp, frame, src, *slot_rows, M * 3);

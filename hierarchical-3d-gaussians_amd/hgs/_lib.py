@@ -141,12 +141,13 @@ SIGNATURES = {
                                  C.POINTER(C.c_uint32), _P, C.c_int]),
     "hgs_resid_evict": (C.c_int, [_P, _P, _P, C.c_int32, C.c_uint32, C.c_uint32, _P, _P, C.POINTER(C.c_uint32), _P,
                                   C.c_int]),
-    "hgs_resid_fetch": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint32, C.POINTER(ResidRows),
+    "hgs_resid_fetch": (C.c_int, [_P, C.c_uint32, _P, C.c_uint32, _P, _P, _P, C.c_uint32, _P,
                                   C.POINTER(ResidRows), C.c_int32, _P, C.c_int]),
     "hgs_resid_remap": (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_int]),
 }
 P2P_MAX_WORLD, P2P_HANDLE_BYTES, P2P_FLAG_BYTES = 8, 64, 256
 RESID_COUNTER_WORDS = 68
+RESID_HOST_ROW_FLOATS = 64     # packed host row: [0, 3M) SH, [48, 52) rotation, [52, 55) mean, [55, 58) scale, [58] opacity
 
 _lib = None
 

@@ -3,8 +3,9 @@
 SIBR viewer).  Opt-in, beside the drop-in path: ``render_hierarchy.py`` itself loads the whole hierarchy onto the GPU
 (scene/gaussian_model.py:329,376-399) and so does ``bench.py``'s configs[4] loop -- 15 GB of 288 GB.
 
-The full attribute arrays (means, SH, opacity, scales, rotations: 4 (3 M + 11) bytes per Gaussian) live in pinned host
-memory that the GPU can read directly; the GPU holds ``budget`` rows in slot arrays plus one int32 per Gaussian (its
+The full attributes live in pinned host memory that the GPU can read directly, as ONE PACKED ROW of 64 floats per
+Gaussian (SH, rotation, mean, scale, opacity: 4 (3 M + 11) useful bytes in 256 -- four 64-byte PCIe reads per row instead
+of seven from five separate arrays); the GPU holds ``budget`` rows in slot arrays plus one int32 per Gaussian (its
 slot, or "absent").  Per view::
 
     sel = bh.select(nodes, boxes, tau, viewpoint_gpu, viewpoint_cpu)   # cut, weights, residency; raises tau if needed
@@ -75,13 +76,18 @@ class BudgetedHierarchy:
                 raise ValueError("budget_mb or budget_rows")
             budget_rows = int(budget_mb * 1e6 // self.row_bytes)
         self.B = B = max(1, min(int(budget_rows), G))
-        srcs = dict(means3D=(means3D, (G, 3)), shs=(shs, (G, M, 3)), opacities=(opacities, (G,)), scales=(scales, (G, 3)),
-                    rotations=(rotations, (G, 4)))
-        self._host, self._host_ptrs = {}, {}
-        for k, (t, shape) in srcs.items():
-            arr, p = _host_array(shape)
-            arr[...] = t.detach().to("cpu", torch.float32).reshape(shape).numpy()
-            self._host[k], self._host_ptrs[k] = arr, p
+        R = _lib.RESID_HOST_ROW_FLOATS
+        assert 3 * M <= 48
+        self._rows, self._rows_ptr = _host_array((G, R))           # the packed host rows (include/hgs.h)
+        f = lambda t, shape: t.detach().to("cpu", torch.float32).reshape(shape).numpy()
+        rows = self._rows
+        rows[:, :3 * M] = f(shs, (G, 3 * M))
+        rows[:, 3 * M:48] = 0.0
+        rows[:, 48:52] = f(rotations, (G, 4))
+        rows[:, 52:55] = f(means3D, (G, 3))
+        rows[:, 55:58] = f(scales, (G, 3))
+        rows[:, 58] = f(opacities, (G,))
+        rows[:, 59:] = 0.0
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.means3D = torch.zeros(B, 3, **f32)
         self.shs = torch.zeros(B, M, 3, **f32)
@@ -108,8 +114,6 @@ class BudgetedHierarchy:
         self.stats = dict(views=0, rows_fetched=0, bytes_fetched=0, evictions=0, retries=0)
         self.profile_fetch = False      # True: (rows, start event, end event) of every fetch launch -> self.fetch_events
         self.fetch_events = []
-        self._host_rows = _lib.ResidRows(*[C.c_void_p(self._host_ptrs[k]) for k in
-                                           ("means3D", "shs", "opacities", "scales", "rotations")])
         self._slot_rows = _lib.ResidRows(*[C.c_void_p(t.data_ptr()) for t in
                                            (self.means3D, self.shs, self.opacities, self.scales, self.rotations)])
 
@@ -127,8 +131,11 @@ class BudgetedHierarchy:
 
     def __del__(self):
         try:
-            for p in getattr(self, "_host_ptrs", {}).values():
+            p = getattr(self, "_rows_ptr", None)
+            if p:
+                self._rows = None
                 self.lib.hgs_host_free(C.c_void_p(p))
+                self._rows_ptr = None
         except Exception:
             pass
 
@@ -193,7 +200,7 @@ class BudgetedHierarchy:
                     e0.record()
                 _lib.check(self.lib.hgs_resid_fetch(p(self.miss_ids), m, p(self.free_list), self.free_top, p(self.slot_of),
                                                     p(self.id_of_slot), p(self.stamp), self.frame,
-                                                    C.byref(self._host_rows), C.byref(self._slot_rows), self.M, s, dev_i),
+                                                    C.c_void_p(self._rows_ptr), C.byref(self._slot_rows), self.M, s, dev_i),
                            "hgs_resid_fetch")
                 if self.profile_fetch:
                     e1.record()

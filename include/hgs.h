@@ -426,9 +426,9 @@ int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* 
  *                     the longest (age histogram on the device, threshold chosen on the host; rows stamped this frame
  *                     are never evicted).  HGS_ERR_CAPACITY if even that is not enough: the working set of the view
  *                     exceeds the budget -- the caller raises tau, as the reference's viewer "auto-regulates".
- *   hgs_resid_fetch   assigns free slots to the missing rows and copies their attributes from the host arrays into
- *                     the slot arrays: ONE kernel reading host memory directly (zero copy over PCIe), no staging
- *                     buffer, no host-side gather.
+ *   hgs_resid_fetch   assigns free slots to the missing rows and copies their attributes from the packed host rows
+ *                     (HGS_RESID_HOST_ROW_FLOATS) into the slot arrays: ONE kernel reading host memory directly (zero
+ *                     copy over PCIe, one coalesced 256-byte read per row), no staging buffer, no host-side gather.
  *   hgs_resid_remap   render_indices / parent_indices (Gaussian rows) -> slot indices, for the in-op LOD path of the
  *                     rasterizer (hgs_raster_args.lod_*) running on the slot arrays.
  * slot_of int32 [G] (initialised to -1), stamp uint32 [B], id_of_slot int32 [B] (initialised to -1), free_list int32
@@ -437,6 +437,9 @@ int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* 
  * [2 x capacity of the index arrays].  All calls are ordered on `stream`.
  * ------------------------------------------------------------------------- */
 #define HGS_RESID_COUNTER_WORDS 68
+/* host side of the budgeted residency: one packed row of 64 floats (256 B = four 64-byte PCIe reads) per Gaussian, in
+ * memory from hgs_host_alloc:  [0, 3 M) SH coefficients, [48, 52) rotation, [52, 55) mean, [55, 58) scale, [58] opacity */
+#define HGS_RESID_HOST_ROW_FLOATS 64
 typedef struct hgs_resid_rows {
   float* means3D;    /* [rows, 3]    */
   float* shs;        /* [rows, M, 3] */
@@ -453,7 +456,7 @@ int hgs_resid_evict(uint32_t* stamp, int32_t* id_of_slot, int32_t* slot_of, int3
                     int32_t* free_list, uint32_t* counters, uint32_t* free_top_inout_host, hgs_stream_t stream,
                     int device);
 int hgs_resid_fetch(const int32_t* miss_ids, uint32_t m, const int32_t* free_list, uint32_t free_top, int32_t* slot_of,
-                    int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const hgs_resid_rows* host_rows,
+                    int32_t* id_of_slot, uint32_t* stamp, uint32_t frame, const float* host_rows_packed,
                     const hgs_resid_rows* slot_rows, int32_t M, hgs_stream_t stream, int device);
 int hgs_resid_remap(const int32_t* render_indices, const int32_t* parent_indices, const float* weights, int32_t n,
                     const int32_t* slot_of, int32_t* ro, int32_t* po, hgs_stream_t stream, int device);

@@ -68,5 +68,6 @@ def test_python_constants_match_the_header_macros():
     assert macro("HGS_P2P_HANDLE_BYTES") == _lib.P2P_HANDLE_BYTES
     assert macro("HGS_P2P_FLAG_BYTES") == _lib.P2P_FLAG_BYTES
     assert macro("HGS_RESID_COUNTER_WORDS") == _lib.RESID_COUNTER_WORDS
+    assert macro("HGS_RESID_HOST_ROW_FLOATS") == _lib.RESID_HOST_ROW_FLOATS
     assert int(re.search(r"HGS_ERR_CAPACITY\s*=\s*(\d+)", src).group(1)) == _lib.ERR_CAPACITY
     assert C.sizeof(_lib.ResidRows) == 5 * 8
