@@ -156,8 +156,17 @@ __device__ __forceinline__ void project_gaussian(const float p[3], const float* 
 // error of the pixel centre at 1080p+ (ulp of 1900.x is 1.2e-4), which otherwise dominates the
 // gradient error of sub-pixel Gaussians.  K1/K8 are HBM-bound; the extra flops are free.
 // ---------------------------------------------------------------------------------------------
+// 1 / d for the double-precision chain: the float reciprocal (v_rcp_f32, 1 ulp) refined by ONE Newton step in double --
+// relative error ~1e-14, five instructions where an IEEE double division expands to a dozen (v_div_scale, v_rcp_f64,
+// three refinement FMAs, v_div_fmas, v_div_fixup) at half rate.  The chain's divisors (w + 1e-7, z > 0.2, the dilated
+// determinant >= 0.09) are far inside float range; a result of 1e-14 relative accuracy moves the pixel centre by 3e-11 px.
+__device__ __forceinline__ double rcp_d(double d) {
+  const double r = (double)__builtin_amdgcn_rcpf((float)d);
+  return fma(fma(-d, r, 1.0), r, r);
+}
+
 struct ProjD {
-  double tx, ty, tz, hx, hy, hw, pw;
+  double tx, ty, tz, hx, hy, hw, pw, itz, di;      // itz = 1 / tz, di = 1 / det
   double txc, tyc, fx, fy;
   double T0[3], T1[3], U0[3], U1[3];
   double c3[6];
@@ -199,7 +208,7 @@ __device__ __forceinline__ void project_gaussian_d(const float p[3], const float
   o.hx = (double)pm[0] * x + (double)pm[4] * y + (double)pm[8] * z + (double)pm[12];
   o.hy = (double)pm[1] * x + (double)pm[5] * y + (double)pm[9] * z + (double)pm[13];
   o.hw = (double)pm[3] * x + (double)pm[7] * y + (double)pm[11] * z + (double)pm[15];
-  o.pw = 1.0 / (o.hw + 1e-7);
+  o.pw = rcp_d(o.hw + 1e-7);
   o.px = ((o.hx * o.pw + 1.0) * (double)W - 1.0) * 0.5;
   o.py = ((o.hy * o.pw + 1.0) * (double)H - 1.0) * 0.5;
   o.fx = (double)W / (2.0 * (double)tanfovx);
@@ -207,7 +216,7 @@ __device__ __forceinline__ void project_gaussian_d(const float p[3], const float
   const double limx = 1.3 * (double)tanfovx, limy = 1.3 * (double)tanfovy;
   o.txc = clampx ? (o.tx < 0.0 ? -limx : limx) * o.tz : o.tx;
   o.tyc = clampy ? (o.ty < 0.0 ? -limy : limy) * o.tz : o.ty;
-  const double itz = 1.0 / o.tz;
+  const double itz = o.itz = rcp_d(o.tz);
   const double J00 = o.fx * itz, J02 = -(o.fx * o.txc) * itz * itz;
   const double J11 = o.fy * itz, J12 = -(o.fy * o.tyc) * itz * itz;
 #pragma unroll
@@ -226,7 +235,7 @@ __device__ __forceinline__ void project_gaussian_d(const float p[3], const float
   o.b = o.U0[0] * o.T1[0] + o.U0[1] * o.T1[1] + o.U0[2] * o.T1[2];
   o.c = o.U1[0] * o.T1[0] + o.U1[1] * o.T1[1] + o.U1[2] * o.T1[2] + 0.3;
   o.det = o.a * o.c - o.b * o.b;
-  const double di = 1.0 / o.det;
+  const double di = o.di = rcp_d(o.det);
   o.conA = o.c * di;
   o.conB = -o.b * di;
   o.conC = o.a * di;

@@ -376,21 +376,23 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
     // never a candidate, exactly like the exact test)
     thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
     // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
-    //   A dx^2 + 2 B dx dy + C dy^2 <= 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T C / det), |dy| <= sqrt(T A / det).
-    // The compositing kernels use them to decide, once per (tile, Gaussian) and in scalar registers, which half of
-    // the tile can be touched at all; they are inflated (same 1e-3 guard in the exponent, 1e-4 relative, 5e-3 px)
-    // so that the box contains every pixel the exact alpha test could accept.  -1: no pixel ever (o <= ~1/255).
+    //   d^T conic d <= T2 = 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T2 Sigma'_xx), |dy| <= sqrt(T2 Sigma'_yy)
+    // (the extent of an ellipse along an axis is set by the COVARIANCE's diagonal: no determinant, no cancellation, so
+    // float32 is enough -- round 3 took the detour over conic and determinant in double: a log, two square roots and
+    // two divisions at half rate).  T2 = -2 ln 2 * thr: the same logarithm as the skip threshold.  The compositing kernels
+    // use the box to decide, once per (tile, Gaussian), which quadrants can be touched at all; it is inflated (the 1e-3
+    // guard in the base-2 exponent, 1e-4 relative, 5e-3 px) so that it contains every pixel the exact alpha test could
+    // accept.  -1: no pixel ever (o <= ~1/255).
     {
-      const double T2 = 2.0 * (log(255.0 * (double)opac) + 1.0e-3 * 0.6931471805599453);
-      const double det = pd.conA * pd.conC - pd.conB * pd.conB;
-      if (T2 > 0.0 && det > 0.0) {
-        ext_x = (float)(sqrt(T2 * pd.conC / det) * 1.0001 + 5.0e-3);
-        ext_y = (float)(sqrt(T2 * pd.conA / det) * 1.0001 + 5.0e-3);
-      } else if (T2 > 0.0) {
-        ext_x = ext_y = 1.0e9f;       // degenerate conic: never skip on the box
+      const float T2 = -1.3862943611198906f * thr;
+      const float sxx = (float)pd.a, syy = (float)pd.c;
+      if (T2 > 0.0f) {
+        const bool sane = sxx < 3.0e38f && syy < 3.0e38f;      // (NaN / inf covariance: never skip on the box)
+        ext_x = sane ? sqrtf(T2 * sxx) * 1.0001f + 5.0e-3f : 1.0e9f;
+        ext_y = sane ? sqrtf(T2 * syy) * 1.0001f + 5.0e-3f : 1.0e9f;
       }
     }
-    invz = (float)(1.0 / pd.tz);
+    invz = (float)pd.itz;
   }
   if constexpr (DEFER) {
     if (deferred) coop_commit_sh(shreg, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
@@ -563,6 +565,9 @@ __device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
   if (atomic) atomicAdd(dst, v); else *dst = v;
 }
 
+#ifndef HGS_K8_STAGE
+#define HGS_K8_STAGE 1     // 0: every lane walks its run of instance records in global memory (round 3; kept for A/B runs)
+#endif
 template <bool ACC, bool LOD>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
 __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
@@ -572,10 +577,83 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
                                                                    hgs_raster_grads out) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const bool in_range = idx < a.P;
+  const uint32_t n = in_range ? g.tiles_touched[idx] : 0u;   // (out-of-range lanes stay for the wave-wide staging below)
+
+  // ---- sum the instance partials (one contiguous run per Gaussian, emission order) --------------------------------
+  // The runs of a wave's 64 Gaussians lie BACK TO BACK in the scratch (emission order = Gaussian order), ~170 records of
+  // 40 bytes: the wave streams that range through LDS with all lanes loading (coalesced, a dozen loads per lane in
+  // flight) and every lane then sums its own run out of LDS -- in the same order as before, so the sums keep their bits.
+  // Round 3 had each lane walk its run in global memory: 2.7 dependent round trips per Gaussian on average, the longest
+  // run of the wave for everybody, at 3 waves per SIMD (160 registers) to hide them.
+  double s[10];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) s[i] = 0.0;
+  static_assert(kInstStride == 10, "instance record = the ten sums, 40 bytes");
+#if HGS_K8_STAGE
+  {
+    constexpr uint32_t kStageRec = 256;                                  // records per wave and pass: 10 KB
+    __shared__ float2 stage[kPreBlock / 64][kStageRec * 5];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    const uint32_t my0 = incl - n, my1 = incl;                           // this lane's run, in records of the wave's range
+    const uint32_t total = __shfl(incl, 63, 64);
+    if (total) {                                                         // (wave-uniform)
+      const unsigned long long nz = __ballot(n != 0u);
+      const int first = __ffsll((long long)nz) - 1;
+      const uint32_t off_mine = n ? g.offsets[idx] : 0u;
+      const size_t base = (size_t)__shfl(off_mine, first, 64);           // (no instances before the first non-empty lane)
+      float2* st = stage[wave];
+      for (uint32_t c0 = 0; c0 < total; c0 += kStageRec) {
+        const uint32_t cn = min(kStageRec, total - c0) * 5u;             // float2 words of this pass
+        const float2* src = reinterpret_cast<const float2*>(inst) + (base + c0) * 5;
+        for (uint32_t t0 = 0; t0 < cn; t0 += 64u * 4u) {                 // four loads in flight per lane
+          float2 v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
+            v[j] = src[min(t, cn - 1u)];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
+            if (t < cn) st[t] = v[j];
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t k0 = max(my0, c0), k1 = min(my1, c0 + kStageRec);
+        for (uint32_t k = k0; k < k1; ++k) {
+          const float2* r = st + (k - c0) * 5u;
+          const float2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
+          s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+          s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
+          s[8] += v4.x; s[9] += v4.y;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();                                 // (the next pass overwrites the stage)
+      }
+    }
+  }
+#else
+  if (n) {
+    const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
+    for (uint32_t k = 0; k < n; ++k) {
+      const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
+      s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+      s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
+      s[8] += v4.x; s[9] += v4.y;
+    }
+  }
+#endif
   if constexpr (!LOD) {
     if (!in_range) return;
   }
-  const uint32_t n = in_range ? g.tiles_touched[idx] : 0u;   // (LOD: out-of-range lanes stay for the scatter's barriers)
 
   float d_mean[3] = {0.f, 0.f, 0.f};
   float d_m2[3] = {0.f, 0.f, 0.f};
@@ -591,18 +669,6 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
   } else {
     CamLds cam;
     load_camera(a, cam);
-    // ---- sum the instance partials (contiguous run: emission order) ----------
-    double s[10];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) s[i] = 0.0;
-    static_assert(kInstStride == 10, "instance record = the ten sums, 40 bytes");
-    const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
-    for (uint32_t k = 0; k < n; ++k) {
-      const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
-      s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
-      s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
-      s[8] += v4.x; s[9] += v4.y;
-    }
     sums6 = (float)s[6]; sums7 = (float)s[7]; sums8 = (float)s[8];
     // ---- recompute the forward projection (double chain; clamp decisions from K1's flags) ----
     const uint32_t flags = g.flags[idx];
@@ -640,7 +706,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
 
     // conic -> 2D covariance
     const double a2 = pd.a, b2 = pd.b, c2 = pd.c;
-    const double di2 = 1.0 / (pd.det * pd.det);
+    const double di2 = pd.di * pd.di;
     const double ga = (-c2 * c2 * gA + b2 * c2 * gB - b2 * b2 * gC) * di2;
     const double gb = (2.0 * b2 * c2 * gA - (a2 * c2 + b2 * b2) * gB + 2.0 * a2 * b2 * gC) * di2;
     const double gc = (-b2 * b2 * gA + a2 * b2 * gB - a2 * a2 * gC) * di2;
@@ -673,7 +739,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
       gJ11 += dT1[j] * (double)cam.vm[j * 4 + 1];
       gJ12 += dT1[j] * (double)cam.vm[j * 4 + 2];
     }
-    const double itz = 1.0 / pd.tz, itz2 = itz * itz, itz3 = itz2 * itz;
+    const double itz = pd.itz, itz2 = itz * itz, itz3 = itz2 * itz;
     const double g_txc = -pd.fx * itz2 * gJ02;
     const double g_tyc = -pd.fy * itz2 * gJ12;
     double g_tz = -pd.fx * itz2 * gJ00 + 2.0 * pd.fx * pd.txc * itz3 * gJ02 - pd.fy * itz2 * gJ11 +
@@ -743,7 +809,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_ar
         o_rec = lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
       // the instance records carry sum X = sum (o G) dL/dalpha; dL/do = sum G dL/dalpha = (sum X) / o.  o <= 0: never
       // blended, sum X = 0
-      const float sums5 = o_rec > 0.0f ? (float)(s[5] / (double)o_rec) : 0.0f;
+      const float sums5 = o_rec > 0.0f ? (float)(s[5] * rcp_d((double)o_rec)) : 0.0f;
       d_op = a.activations ? (float)((double)sums5 * (double)dod * dact) : sums5 * dod;
     }
 
