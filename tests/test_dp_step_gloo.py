@@ -29,7 +29,7 @@ class _Ctx:           # what DataParallelStep needs of a RasterContext when the 
         pass
 
 
-def _run_steps(rank, world, n_steps, views_per_rank, n_views=None):
+def _run_steps(rank, world, n_steps, views_per_rank, n_views=None, sharded=False):
     sys.path.insert(0, HERE)
     import dp_common as dc
     import parity as pa
@@ -38,8 +38,12 @@ def _run_steps(rank, world, n_steps, views_per_rank, n_views=None):
     n_views = world * views_per_rank if n_views is None else n_views
     scene, cams, targets = dc.scene_and_cams(n_views)
     params = {k: getattr(scene, k).clone() for k in dc.NAMES}
-    opt = dc.OracleAdam([dict(params=[params[k]], lr=dc.LRS[k]) for k in dc.NAMES])
-    step = dp.DataParallelStep(params, opt, make_context=_Ctx)
+    if sharded:       # reduce-scatter + Adam on this rank's rows + all-gather (hgs.dp.ShardedDataParallelStep)
+        step = dp.ShardedDataParallelStep(
+            params, lambda sp: dc.OracleAdam([dict(params=[sp[k]], lr=dc.LRS[k]) for k in dc.NAMES]), make_context=_Ctx)
+    else:
+        opt = dc.OracleAdam([dict(params=[params[k]], lr=dc.LRS[k]) for k in dc.NAMES])
+        step = dp.DataParallelStep(params, opt, make_context=_Ctx)
     accum = dict(xyz_gradient_accum=torch.zeros(dc.P, 1), denom=torch.zeros(dc.P, 1), max_radii2D=torch.zeros(dc.P))
     for _ in range(n_steps):
         step.begin()
@@ -63,13 +67,13 @@ def _upstream(target):
     return target[0] - 0.5, target[1] - 0.15
 
 
-def _worker(rank, world, port, q, n_views=None):
+def _worker(rank, world, port, q, n_views=None, sharded=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     sys.path.insert(0, HERE)
     from hgs import dp
     dp.init_from_env(backend="gloo")
-    params, accum = _run_steps(rank, world, 2, 2, n_views=n_views)
+    params, accum = _run_steps(rank, world, 2, 2, n_views=n_views, sharded=sharded)
     # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
     q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
@@ -118,3 +122,31 @@ def test_rank_without_a_view_contributes_zeros():
         assert float((got[0][0][k] - ref_params[k]).abs().max()) <= 1e-6 * scale, k
     for k, v in ref_accum.items():
         assert torch.equal(got[0][1][k], got[2][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_optimizer_step_equals_the_all_reduce_step(world):
+    """reduce-scatter + rank-sharded Adam + all-gather (hgs.dp.ShardedDataParallelStep) against all-reduce + the full
+    Adam step on every rank (DataParallelStep): the same parameters after two steps -- BIT FOR BIT at two ranks (a + b
+    is the only summation order there is), and at three ranks (400 rows: blocks of 134, the last one padded -- the
+    staged all-gather) up to the order in which the two collectives add three numbers.  The ranks of one run always agree
+    bit for bit, and so do the densification statistics."""
+    runs = {}
+    for sharded in (False, True):
+        got = {}
+        for r, params, accum in run_world(_worker, world, extra=(None, sharded), timeout=800, join_timeout=60):
+            got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
+        runs[sharded] = got
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    for k in dc.NAMES:
+        for r in range(1, world):
+            assert torch.equal(runs[True][0][0][k], runs[True][r][0][k]), f"{k}: sharded ranks diverged"
+        a, b = runs[False][0][0][k], runs[True][0][0][k]
+        if world == 2:
+            assert torch.equal(a, b), f"{k}: sharded step differs from the all-reduce step"
+        else:
+            assert float((a - b).abs().max()) <= 1e-6 * float(a.abs().max()), k
+    for k in runs[False][0][1]:
+        assert torch.equal(runs[False][0][1][k], runs[True][0][1][k]), k
