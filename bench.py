@@ -274,6 +274,8 @@ def extra_dropin(name, scene_cpu, W, H, dev, measure, steps, warmup, what):
     sb = survey_bytes(P, V, L, N, T, M)
     out = {"what": what, "metric": "fwd+bwd frames/s", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+           "host_ms_per_step": getattr(measure, "last_host_ms", None),
+           "stage_sum_ms": sum(stages.values()) if stages else None,
            "config": {"gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H, "schedule": "dropin",
                       "capacity_misses": dgrC.stats["capacity_misses"] - miss0},
            "algorithmic_bytes_per_frame": sum(sb.values()), "stages_ms": stages}
@@ -636,6 +638,79 @@ def roofline_object(sb, stages, dom, model_text, extra=None):
     return r
 
 
+def measure_host_floor(dgr, synth, dev, P=2000, W=256, H=256, steps=300):
+    """Wall time per drop-in fwd+bwd at a size whose GPU time is negligible: what the call path costs on THIS host
+    (Python + ctypes + torch allocator + autograd engine + ~17 kernel launches + the wait for the instance count)."""
+    cams = [synth.orbit_camera(W, H, j, 8) for j in range(8)]
+    sc = synth.make_scene(P, cams[0], seed=0)
+    prm = {kk: getattr(sc, kk).to(dev).contiguous().requires_grad_(True)
+           for kk in ("means3D", "shs", "opacities", "scales", "rotations")}
+    gc, gd = synth.upstream_grads(H, W)
+    d = DropIn(dgr, prm, 3, [_settings(dgr, c, dev) for c in cams], gc.to(dev), gd.to(dev), dev)
+    for _ in range(30):
+        d.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        d.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    return {"ms_per_step": ms, "what": f"wall time per drop-in fwd+bwd of {P} Gaussians at {W}x{H} (GPU work ~0.05 ms): the "
+                                       "floor of the call path on this host; a configuration whose GPU stage sum is below it "
+                                       "is host-bound"}
+
+
+def measure_exchange(dp, params, dev, rank, world, rccl_log, reps=8):
+    """N > 1: the gradient exchange of one step ALONE (the two spans of the bucket, back to back, nothing to overlap
+    with), timed per rank with events; what RCCL says about the algorithm / protocol it uses for these sizes."""
+    bucket = dp.GradBucket({kk: tuple(v.shape) for kk, v in params.items()}, dev)
+    spans = [bucket.span(dp.DataParallelStep.EARLY), bucket.span(dp.DataParallelStep.LATE)]
+    for _ in range(3):
+        for sp in spans:
+            dist.all_reduce(sp)
+    torch.cuda.synchronize()
+    dist.barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ev[0].record()
+    for i in range(reps):
+        for sp in spans:
+            dist.all_reduce(sp)
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    mine = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, float(mine))
+    nbytes = int(sum(sp.numel() for sp in spans) * 4)
+    out = {"backend": dist.get_backend(), "bytes_per_step": nbytes, "spans_bytes": [int(sp.numel() * 4) for sp in spans],
+           "exchange_ms_per_rank": per_rank,
+           # all-reduce bus bandwidth in nccl-tests' convention: 2 (N - 1) / N x bytes / time
+           "busbw_GBps": 2.0 * (world - 1) / world * nbytes / (max(per_rank) * 1e-3) / 1e9,
+           "env": {kk: os.environ[kk] for kk in ("NCCL_ALGO", "NCCL_PROTO", "NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS",
+                                                 "HSA_ENABLE_IPC_MODE_LEGACY", "HGS_DP_ALLREDUCE") if kk in os.environ}}
+    try:
+        out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:
+        pass
+    if rank == 0 and rccl_log:
+        try:
+            path = rccl_log.replace("%p", str(os.getpid())).replace("%h", os.uname().nodename)
+            lines = [ln.strip() for ln in open(path, errors="replace")]
+            keep, seen = [], set()
+            for ln in lines:
+                low = ln.lower()
+                if ("algo" in low and "proto" in low) or "channels" in low or "nccl version" in low or "rccl version" in low:
+                    key = ln.split("]")[-1].strip()[:160]
+                    if key not in seen:
+                        seen.add(key)
+                        keep.append(key)
+            out["rccl_trace"] = keep[:24]
+            out["rccl_trace_note"] = ("unique lines of RCCL's INFO log (INIT, TUNING) that name an algorithm / protocol / "
+                                      "channel count; algo 0 Tree 1 Ring, proto 0 LL 1 LL128 2 Simple in RCCL 2.2x")
+        except OSError as e:
+            out["rccl_trace"] = [f"no log: {e!r}"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -677,6 +752,15 @@ def main():
     from hgs import _lib, dp, synth
     import diff_gaussian_rasterization as dgr
 
+    rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HGS_BENCH_RCCL_TRACE", "1") != "0":
+        # the first SCALE record should explain itself: RCCL's own account of the algorithm / protocol it picked for the
+        # bucket goes to a per-process file (never to stdout: the line below stays the only one) and is quoted in the line
+        rccl_log = f"/tmp/hgs_rccl_{os.getpid()}.log"
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,TUNING")
+        os.environ.setdefault("NCCL_DEBUG_FILE", rccl_log)
+        rccl_log = os.environ["NCCL_DEBUG_FILE"]
     rank, local, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rasterizer has no CPU path (see oracle/ for the checker)")
@@ -813,11 +897,16 @@ def main():
             _lib.timing_read(reset=True)
             _lib.timing_enable(True, stages=[DOMINANT])
         barrier()
+        host = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
+            ta = time.perf_counter()
             step()
+            host += time.perf_counter() - ta
         barrier()
         elapsed = time.perf_counter() - t0
+        info["host_ms_per_step"] = host / steps * 1e3       # time spent INSIDE step(): Python, ctypes, launches, host waits
+        measure.last_host_ms = info["host_ms_per_step"]
         stages = {}
         if dominant_timing:
             _lib.timing_enable(False)
@@ -861,7 +950,14 @@ def main():
             views = k
             state.clear()
         res[sched] = dict(value=world * views * steps / elapsed, ms_per_step=elapsed / steps * 1e3, steps=steps,
-                          views_per_step_per_gpu=views, stages=stages)
+                          views_per_step_per_gpu=views, stages=stages, host_ms_per_step=info.get("host_ms_per_step"))
+
+    exchange = None
+    if world > 1:
+        exchange = measure_exchange(dp, params, dev, rank, world, rccl_log)
+    host_floor = None
+    if world == 1 and primary == "dropin":
+        host_floor = measure_host_floor(dgr, synth, dev)
 
     if rank == 0:
         r = res[primary]
@@ -913,7 +1009,14 @@ def main():
             "impl_bytes_per_frame": impl_frame,
             "ms_per_frame_per_gpu": r["ms_per_step"] / kk_,
             "frame_hbm_frac": survey_frame * fps_per_gpu / 1e9 / HBM_PEAK_GBS,
+            # host side of the call path: time inside step() per timed step (it contains the forward's wait for the
+            # instance count, i.e. GPU time of K1 + scan when the host runs ahead), and the floor of the path itself
+            "host_ms_per_step": r.get("host_ms_per_step"),
         }
+        if host_floor is not None:
+            result["host_floor"] = host_floor
+        if exchange is not None:
+            result["exchange"] = exchange
         for name, rr in res.items():
             result[name] = {"value": rr["value"], "unit": "frames/s", "views_per_step_per_gpu": rr["views_per_step_per_gpu"],
                             "steps": rr["steps"], "ms_per_step": rr["ms_per_step"],

@@ -34,9 +34,35 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert abs(rf["achieved"] - rf["algorithmic_bytes"] / (rf["avg_ms"] * 1e-3) / 1e9) <= 1e-6 * rf["achieved"]
     assert d["batched"]["value"] > 0 and d["dropin"]["value"] == d["value"]
     assert d["config"]["capacity_misses"] == 0 and len(d["kernel_source_sha"]) == 16
+    assert 0.0 < d["host_ms_per_step"] <= d["ms_per_step"] * 1.05 and 0.0 < d["host_floor"]["ms_per_step"] < 5.0
     ex = d["extra"]["config2_300k"]                 # the other BASELINE configurations ride in the same line
     assert "error" not in ex, ex
     for k in ("value", "unit", "ms_per_step", "stages_ms", "roofline", "config"):
         assert k in ex, k
     assert ex["config"]["gaussians"] == 300_000 and ex["config"]["tile_instances"] > 500_000
     assert abs(ex["roofline"]["frac"] - ex["roofline"]["achieved"] / 8000.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_as_the_driver_launches_them(gpu):
+    """The N > 1 path of bench.py, launched exactly as the driver launches it (torch.distributed.run, one process per
+    rank) -- here with the two ranks SHARING the one GPU and talking over gloo (HGS_DP_BACKEND), because no multi-GPU node
+    is available to the tests: rank 0 prints the one line, value is the whole-job aggregate of the batched schedule, and
+    the line carries the per-rank exchange times the first SCALE record is supposed to explain itself with."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HGS_DP_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "1", "--gaussians", "20000", "--width", "320", "--height", "192", "--views-per-step", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["schedule"] == "batched"
+    assert d["steps"] == 3 and d["value"] > 0
+    assert abs(d["value"] - 2 * 2 * 1e3 / d["ms_per_step"]) <= 1e-6 * d["value"]     # ranks x views per step / step time
+    ex = d["exchange"]
+    assert ex["backend"] == "gloo" and len(ex["exchange_ms_per_rank"]) == 2 and all(t > 0 for t in ex["exchange_ms_per_rank"])
+    assert ex["bytes_per_step"] == 20000 * 59 * 4 and ex["busbw_GBps"] > 0
