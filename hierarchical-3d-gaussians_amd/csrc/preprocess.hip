@@ -568,8 +568,13 @@ __device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
 #ifndef HGS_K8_STAGE
 #define HGS_K8_STAGE 1     // 0: every lane walks its run of instance records in global memory (round 3; kept for A/B runs)
 #endif
+#ifdef HGS_K8_WPE            // tuning aid: cap the registers so that HGS_K8_WPE waves fit a SIMD (160 registers = 3 today)
+#define HGS_K8_OCC __attribute__((amdgpu_waves_per_eu(HGS_K8_WPE, HGS_K8_WPE)))
+#else
+#define HGS_K8_OCC
+#endif
 template <bool ACC, bool LOD>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
-__global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
+__global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
                                                                    float* __restrict__ drgb,
                                                                    float* __restrict__ dmean_rows,

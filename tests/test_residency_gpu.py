@@ -178,6 +178,6 @@ def test_fly_through_of_a_million_node_hierarchy_streams_bit_identically(gpu):
           bh.stats["evictions"])
     assert all(m >= 0.01 * r[2] for m, r in zip(fetched, refs))    # >= 1 % of the cut streams in on EVERY frame
     assert fetched[16] > 1.5 * fetched[15]                         # the jump is a burst
-    assert sum(fetched) > 1.5 * bh.B and bh.stats["evictions"] > 0.5 * bh.B    # slots are recycled continuously
+    assert sum(fetched) > 1.2 * bh.B and bh.stats["evictions"] > 0.4 * bh.B    # slots are recycled continuously
     assert bh.stats["retries"] == 0
     assert int((bh.slot_of == -2).sum()) == 0
