@@ -21,7 +21,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 
-def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
+def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True, sharded=False):
     sys.path.insert(0, HERE)
     import dp_common as dc
     import parity as pa
@@ -32,8 +32,14 @@ def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
     n_views = world * views_per_rank
     scene, cams, targets = dc.scene_and_cams(n_views)
     params = {k: getattr(scene, k).clone().to(dev).requires_grad_(True) for k in dc.NAMES}
-    opt = Adam([dict(params=[params[k]], lr=dc.LRS[k], name=k) for k in dc.NAMES], lr=0.0, eps=1e-15)
-    step = dp.DataParallelStep(params, opt, backward_stream=torch.cuda.Stream(device=dev) if two_streams else None)
+    sb = torch.cuda.Stream(device=dev) if two_streams else None
+    if sharded:       # reduce-scatter + the fused Adam on this rank's rows + all-gather
+        step = dp.ShardedDataParallelStep(
+            params, lambda sp: Adam([dict(params=[sp[k]], lr=dc.LRS[k], name=k) for k in dc.NAMES], lr=0.0, eps=1e-15),
+            backward_stream=sb)
+    else:
+        opt = Adam([dict(params=[params[k]], lr=dc.LRS[k], name=k) for k in dc.NAMES], lr=0.0, eps=1e-15)
+        step = dp.DataParallelStep(params, opt, backward_stream=sb)
     accum = dict(xyz_gradient_accum=torch.zeros(dc.P, 1, device=dev), denom=torch.zeros(dc.P, 1, device=dev),
                  max_radii2D=torch.zeros(dc.P, device=dev))
     bg = torch.zeros(3)
@@ -57,13 +63,20 @@ def _run_steps(rank, world, n_steps, views_per_rank, two_streams=True):
 
 def _worker(rank, world, port, q, route, views_per_rank=2):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
-                      MASTER_PORT=str(port), HGS_DP_ALLREDUCE=route)
+                      MASTER_PORT=str(port), HGS_DP_ALLREDUCE="" if route == "sharded" else route)
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.join(os.path.dirname(HERE), "hierarchical-3d-gaussians_amd"))
     sys.path.insert(0, os.path.dirname(HERE))
     from hgs import dp
     dp.init_from_env(backend="gloo")
-    params, accum = _run_steps(rank, world, 3, views_per_rank)
+    try:
+        params, accum = _run_steps(rank, world, 3, views_per_rank, sharded=route == "sharded")
+    except RuntimeError as e:          # gloo builds without reduce-scatter / all-gather on GPU tensors: say so, do not hang
+        if route == "sharded" and any(t in str(e).lower() for t in ("not supported", "unsupported", "not implemented")):
+            q.put((rank, {"unsupported": str(e)[:300]}, {}))
+            dist.destroy_process_group()
+            return
+        raise
     # numpy: pickled by value (a tensor would travel as a shared-memory handle that dies with this process)
     q.put((rank, {k: v.numpy() for k, v in params.items()}, {k: v.numpy() for k, v in accum.items()}))
     dist.barrier()
@@ -119,3 +132,25 @@ def test_eight_ranks_on_one_gpu_direct_route(gpu):
         assert err <= 2e-6 * scale, (k, err, scale)
     for k, v in ref_accum.items():
         assert torch.equal(got[0][1][k], got[7][1][k]) and torch.allclose(got[0][1][k], v, rtol=1e-6, atol=0), k
+
+
+@pytest.mark.timeout(900)
+def test_sharded_optimizer_step_on_the_gpu_equals_the_all_reduce_step(gpu):
+    """hgs.dp.ShardedDataParallelStep through the real pieces (HIP rasterizer, batched backwards on a second stream, the
+    fused Adam on this rank's rows): after 3 steps both ranks hold the same bits as the all-reduce route's ranks."""
+    world = 2
+    runs = {}
+    for route in ("dist", "sharded"):
+        got = {}
+        for r, params, accum in run_world(_worker, world, extra=(route,), timeout=800, join_timeout=120):
+            if "unsupported" in params:
+                pytest.skip(f"gloo cannot reduce-scatter / all-gather GPU tensors here: {params['unsupported']}")
+            got[r] = ({k: torch.from_numpy(v) for k, v in params.items()}, {k: torch.from_numpy(v) for k, v in accum.items()})
+        runs[route] = got
+    sys.path.insert(0, HERE)
+    import dp_common as dc
+    for k in dc.NAMES:
+        assert torch.equal(runs["sharded"][0][0][k], runs["sharded"][1][0][k]), f"{k}: sharded ranks diverged"
+        assert torch.equal(runs["sharded"][0][0][k], runs["dist"][0][0][k]), f"{k}: sharded step differs from all-reduce"
+    for k in runs["dist"][0][1]:
+        assert torch.equal(runs["sharded"][0][1][k], runs["dist"][0][1][k]), k
