@@ -633,6 +633,13 @@ def roofline_object(sb, stages, dom, model_text, extra=None):
     r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
          "frac": achieved / HBM_PEAK_GBS, "avg_ms": stages[dom], "algorithmic_bytes": sb[dom], "bytes_model": model_text,
          "traffic": None}
+    # the whole frame next to the dominant kernel: every stage's §8(d) bytes over the sum of the stage times -- the figure
+    # to read when the dominant kernel is ALU-bound and its own HBM fraction says little
+    known = [s_ for s_ in stages if s_ in sb]
+    if known:
+        tot_b, tot_s = sum(sb[s_] for s_ in known), sum(stages[s_] for s_ in known) * 1e-3
+        r["frame"] = {"achieved": tot_b / tot_s / 1e9, "frac": tot_b / tot_s / 1e9 / HBM_PEAK_GBS, "bytes": tot_b,
+                      "ms": tot_s * 1e3, "what": "all stages of the frame: sum of their §8(d) bytes / sum of their times"}
     if extra:
         r.update(extra)
     return r

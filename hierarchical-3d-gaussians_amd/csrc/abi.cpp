@@ -142,7 +142,7 @@ size_t GeomWs::bytes(int32_t P) {
   const size_t p = (size_t)(P > 0 ? P : 1);
   const size_t nblk = (p + kPreBlock - 1) / kPreBlock;
   return align_up(p * kRecFloats * 4) + align_up(p * 4) + align_up(p * 8) + 3 * align_up(p * 4) +
-         align_up((nblk + 1) * 4) + align_up((nblk + 1) * kBands * 4) + align_up(p * 9 * 4) +
+         align_up((nblk + 1) * 4) + align_up((nblk + 1) * kBands * 4) + align_up(p * kJacStride * 4) +
          align_up((size_t)(1 + kBands) * scan_chunks(nblk) * 8) + kAlign;
 }
 GeomWs GeomWs::carve_from(void* base, int32_t P) {
@@ -158,7 +158,7 @@ GeomWs GeomWs::carve_from(void* base, int32_t P) {
   g.flags = carve<uint32_t>(c, p);
   g.block_sums = carve<uint32_t>(c, nblk + 1);
   g.block_band = carve<uint32_t>(c, (nblk + 1) * kBands);
-  g.shjac = carve<float>(c, p * 9);
+  g.shjac = carve<float>(c, p * kJacStride);
   g.scan_chain = carve<unsigned long long>(c, (size_t)(1 + kBands) * scan_chunks(nblk));
   return g;
 }

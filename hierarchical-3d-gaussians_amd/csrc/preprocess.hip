@@ -444,9 +444,12 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
               }
             }
           }
-          float* jd = g.shjac + (size_t)idx * 9;
-#pragma unroll
-          for (int i = 0; i < 9; ++i) jd[i] = J[i];
+          // rows of kJacStride = 12 floats: three 16-byte stores per lane, a wave writes 3 KB of whole cache lines (nine
+          // dword stores at a 36-byte stride touched every line of the block nine times: K1 0.100 -> see DESIGN.md)
+          float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
+          jd[0] = make_float4(J[0], J[1], J[2], J[3]);
+          jd[1] = make_float4(J[4], J[5], J[6], J[7]);
+          jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
         }
         r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
         if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
@@ -982,7 +985,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
     float gdx = 0.f, gdy = 0.f, gdz = 0.f;
     if constexpr (JAC) {
-      const float* J = g.shjac + (size_t)idx * 9;
+      const float4* j4 = reinterpret_cast<const float4*>(g.shjac + (size_t)idx * kJacStride);
+      const float4 ja = j4[0], jb = j4[1], jc = j4[2];
+      const float J[9] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w, jc.x};
       gdx = gr[0] * J[0] + gr[1] * J[1] + gr[2] * J[2];
       gdy = gr[0] * J[3] + gr[1] * J[4] + gr[2] * J[5];
       gdz = gr[0] * J[6] + gr[1] * J[7] + gr[2] * J[8];

@@ -33,6 +33,7 @@ if has prof; then
   cd $R
   python scripts/rocprof_summary.py $(ls gpurun_out/prof_dropin/*.db | head -1) > gpurun_out/kernel_stats_dropin.txt 2>/dev/null; head -22 gpurun_out/kernel_stats_dropin.txt
   python scripts/rocprof_summary.py $(ls gpurun_out/prof_batched/*.db | head -1) > gpurun_out/kernel_stats_batched.txt 2>/dev/null
+  rm -rf gpurun_out/prof_dropin gpurun_out/prof_batched      # the summaries are what is kept (gpurun copies back <= 64 MiB)
 fi
 if has pmc; then
   echo "== PMC passes (drop-in schedule)"
@@ -45,7 +46,9 @@ if has pmc; then
   done
   cd $R
   python scripts/pmc_summary.py SQ=gpurun_out/pmc_SQ/pmc_results.db SQ2=gpurun_out/pmc_SQ2/pmc_results.db F=gpurun_out/pmc_FETCH_SIZE/pmc_results.db W=gpurun_out/pmc_WRITE_SIZE/pmc_results.db > gpurun_out/pmc_summary.json 2>/dev/null; echo "pmc summary exit $?"
+  rm -rf gpurun_out/pmc_SQ gpurun_out/pmc_SQ2 gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
 fi
+du -sh gpurun_out 2>/dev/null
 if has next; then
   echo "== bench_next (SURVEY 8f rows)"
   timeout 600 python scripts/bench_next.py > gpurun_out/bench_next.jsonl 2> gpurun_out/bench_next.err; echo "bench_next exit $?"; cat gpurun_out/bench_next.jsonl; tail -3 gpurun_out/bench_next.err

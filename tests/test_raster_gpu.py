@@ -495,6 +495,26 @@ def test_extremely_elongated_gaussians_stay_well_behaved(gpu):
     assert float(hip["color"].amax(0)[dark].max()) < 1e-2
 
 
+def test_instance_runs_longer_than_the_staging_pass(gpu):
+    """K8a streams a wave's instance records through LDS in passes of 256 records; a Gaussian whose rectangle covers
+    more tiles than that has its run split over several passes (and shares passes with its neighbours' short runs).
+    672x400 = 42 x 25 = 1 050 tiles; four screen-filling Gaussians (1 050 records each) among ordinary ones, placed so
+    that the long runs start at different lanes of their waves (indices 0, 63, 64, 130)."""
+    W, H = 672, 400
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(260, cam, seed=21, s_px=(0.5, 5.0))
+    for i in (0, 63, 64, 130):
+        scene.means3D[i] = torch.tensor([0.1 * (i % 3 - 1), 0.05, 6.0])
+        scene.scales[i] = torch.tensor([4.0, 3.0, 3.5])
+        scene.opacities[i] = 0.08
+    gc, gd = synth.upstream_grads(H, W)
+    bg = torch.tensor([0.05, 0.1, 0.15])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    assert int(oo.geom.tiles_touched[[0, 63, 64, 130]].min()) == 42 * 25
+    _assert_case("long_runs", hip, oo, og, mixed_tol=2.0)      # (screen-filling sums: see test_awkward_inputs)
+
+
 def test_backward_scratch_needs_no_initialisation(gpu):
     """The backward's instance scratch is handed over uninitialised: K7 writes EVERY instance record -- the sums, or
     zeros for instances that no pixel blended (behind every pixel's last contributor, outside the alpha >= 1/255 box,
