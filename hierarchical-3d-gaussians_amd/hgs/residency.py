@@ -189,10 +189,18 @@ class BudgetedHierarchy:
                 self.miss_ids[:m] = torch.sort(self.miss_ids[:m]).values
             try:
                 if m > self.free_top:
-                    top = C.c_uint32(self.free_top)
-                    _lib.check(self.lib.hgs_resid_evict(p(self.stamp), p(self.id_of_slot), p(self.slot_of), self.B,
-                                                        self.frame, m, p(self.free_list), p(self.counters), C.byref(top),
-                                                        s, dev_i), "hgs_resid_evict")
+                    # An eviction costs two passes over the slots and two host round trips: free a batch (1 / 32 of
+                    # the budget) beyond what this view needs, so that a camera in motion evicts every few frames
+                    # instead of on every frame; if that many old rows do not exist, exactly what is needed.
+                    for need in dict.fromkeys((max(m, min(self.B, m + self.B // 32)), m)):
+                        top = C.c_uint32(self.free_top)
+                        rc = self.lib.hgs_resid_evict(p(self.stamp), p(self.id_of_slot), p(self.slot_of), self.B,
+                                                      self.frame, need, p(self.free_list), p(self.counters),
+                                                      C.byref(top), s, dev_i)
+                        if rc == _lib.ERR_CAPACITY and need > m:
+                            continue
+                        _lib.check(rc, "hgs_resid_evict")
+                        break
                     self.stats["evictions"] += int(top.value) - self.free_top
                     self.free_top = int(top.value)
                 if self.profile_fetch:
@@ -222,26 +230,35 @@ class BudgetedHierarchy:
         from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights
         zero3 = torch.zeros(3)
         t = float(tau)
+        probing = False
         if self._regulated is not None and self._regulated > t:
             # the previous view had to be coarsened: start from what fitted then, and only every `probe_every`-th view
-            # one step finer (a cut that does not fit costs a cut and a pass over its rows)
+            # one step finer (a cut that does not fit costs a cut, its weights and a pass over its rows with every miss
+            # queued and taken back: 10 ms at 25 M entries).  A probe that fails doubles the interval (up to 256 views), one
+            # that fits resets it: a camera that stays in a region the budget cannot show finer stops paying for asking.
             self._since_probe += 1
-            probe = self._since_probe >= self.probe_every
-            if probe:
+            probing = self._since_probe >= self.probe_every
+            if probing:
                 self._since_probe = 0
-            t = max(t, self._regulated / growth if probe else self._regulated)
+            t = max(t, self._regulated / growth if probing else self._regulated)
         for attempt in range(1, max_attempts + 1):
             n = expand_to_size(nodes, boxes, t, viewpoint_gpu, zero3, self.ri, self.pi, self.ni)
-            # the weights first: an entry of weight 1 does not need its parent row (make_resident)
-            get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
             try:
+                if n > self.B:          # more node rows than slots: no need to look at them
+                    raise _lib.HgsError(f"a cut of {n} entries cannot fit a budget of {self.B} rows", _lib.ERR_CAPACITY)
+                # the weights first: an entry of weight 1 does not need its parent row (make_resident)
+                get_interpolation_weights(self.ni[:n], t, nodes, boxes, viewpoint_cpu, zero3, self.w, self.ns)
                 ro, po, m = self.make_resident(self.ri[:n], self.pi[:n], self.w)
             except _lib.HgsError as e:
                 if e.code != _lib.ERR_CAPACITY:
                     raise
                 self.stats["retries"] += 1
+                if probing and attempt == 1:
+                    self.probe_every = min(2 * self.probe_every, 256)
                 t = t * growth if t > 0 else 1e-4
                 continue
+            if probing and attempt == 1:
+                self.probe_every = 16
             self.stats["views"] += 1
             self._regulated = t if t > float(tau) else None
             return Selection(n, t, ro, po, self.w, self.ns, m, attempt)
