@@ -81,8 +81,13 @@ __global__ __launch_bounds__(256) void lod_mark_kernel(const int32_t* __restrict
   if (n < N) {
     const int32_t* nd = nodes + (size_t)n * kNodeInts;
     const int par = nd[1];
-    const bool reached = par < 0 || node_size(boxes, par, vp) >= tau;
-    if (reached) cnt = node_size(boxes, n, vp) >= tau ? (uint32_t)nd[3] : (uint32_t)(nd[3] + nd[4]);
+    // size(parent) >= size(n) in float32 too when the boxes nest (smaller numerator, larger denominator, every
+    // operation of node_size monotone under rounding): a node that is too coarse itself has been reached, and its
+    // parent's box -- a second 32-byte gather -- is only read for the nodes that are fine enough
+    const float sn = node_size(boxes, n, vp);
+    const bool coarse = sn >= tau;
+    const bool reached = coarse || par < 0 || node_size(boxes, par, vp) >= tau;
+    if (reached) cnt = coarse ? (uint32_t)nd[3] : (uint32_t)(nd[3] + nd[4]);
     emit_cnt[n] = cnt;
   }
   uint32_t v = cnt;
