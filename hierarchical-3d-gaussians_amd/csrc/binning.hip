@@ -20,6 +20,16 @@
 namespace hgs {
 namespace {
 
+// k / w and k % w for the rank k of a tile inside a rectangle of width w: k < 1023^2 < 2^20, 1 <= w <= 1023.  The quotient
+// of (k + 0.5) * rcp(w) is exact for k < 2^21 (the half keeps exact multiples half a step away from the rounding
+// edge: the error of v_rcp_f32 and of the product, 2^-22 of a quotient < 2^21 / w, stays below 0.5 / w) -- six
+// instructions where the 32-bit integer division expands to about forty.
+__device__ __forceinline__ void divmod_rect(uint32_t k, uint32_t w, uint32_t& q, uint32_t& r) {
+  q = (uint32_t)(((float)k + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+  r = k - q * w;
+}
+
+
 // Per-workgroup instance counts in DEPTH-SORTED Gaussian order (feeds the emission-offset scan).
 __device__ __forceinline__ uint32_t rect_count(uint2 r) {     // rects are zero for culled Gaussians
   return ((r.y & 0xffffu) - (r.x & 0xffffu)) * ((r.y >> 16) - (r.x >> 16));
@@ -73,7 +83,9 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_kernel(int P, int g
     const uint2 rc = lrect[lo];
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
     const uint32_t w = (rc.y & 0xffffu) - minx;
-    const uint32_t ty = miny + k / w, tx = minx + k % w;
+    uint32_t kq, kr;
+    divmod_rect(k, w, kq, kr);
+    const uint32_t ty = miny + kq, tx = minx + kr;
     if (block_base + s < cap) {     // cap < L only when a speculative capacity was too small (caller retries)
       tile_keys[block_base + s] = ty * (uint32_t)gx + tx;
       vals[block_base + s] = gg;
@@ -196,6 +208,7 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
   if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run (K7 / K8 slots)
   __syncthreads();
   const uint32_t total = excl[kPreBlock];
+  const float rcp_per = __builtin_amdgcn_rcpf((float)per);
   for (uint32_t s = tid; s < total; s += kPreBlock) {
     // largest j with excl[j] <= s (zero-count entries are skipped: the search lands on the LAST index whose start is <= s)
     int lo = 0, hi = kPreBlock;
@@ -209,10 +222,12 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
     const uint2 rc = lrect[lo];
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
     const uint32_t w = (rc.y & 0xffffu) - minx;
-    const uint32_t tile = (miny + k / w) * (uint32_t)gx + minx + k % w;
-    uint32_t band = 0;                                    // number of band boundaries <= tile: no per-lane division
-#pragma unroll
-    for (int b = 1; b < kBands; ++b) band += (tile >= (uint32_t)(b * per)) ? 1u : 0u;
+    uint32_t kq, kr;
+    divmod_rect(k, w, kq, kr);
+    const uint32_t tile = (miny + kq) * (uint32_t)gx + minx + kr;
+    // band = tile / per by the same reciprocal trick (tile < 2^20; rcp_per is wave-uniform): three instructions for
+    // the seven compare-and-add pairs of a boundary count
+    const uint32_t band = (uint32_t)(((float)tile + 0.5f) * rcp_per);
     const uint32_t pos = bpos[band] + rb[band][lo] + k;
     if (pos < cap) {       // cap < L only when a speculative capacity was too small (caller retries)
       tile_keys[pos] = tile - band * (uint32_t)per;
