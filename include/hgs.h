@@ -415,13 +415,16 @@ int hgs_p2p_allreduce_sum(int32_t rank, int32_t world, void* const* bufs, void* 
  * Budgeted residency of a hierarchy's attribute rows ("VRAM-budgeted streaming LOD": the `--budget <MB>` of the
  * reference's hierarchy viewer, README.md:233-235 -- "this only defines the budget for the SCENE representation" --
  * whose implementation lives in the un-vendored SIBR viewer; BASELINE configs[4] names it).  Opt-in layer BESIDE the
- * drop-in path (hgs/residency.py): the full attribute arrays stay in pinned, device-mapped HOST memory
- * (hgs_host_alloc); the GPU holds `B` rows in slot arrays.  Per view, after the LOD cut:
+ * drop-in path (hgs/residency.py): the attributes of ALL rows stay in pinned, device-mapped HOST memory
+ * (hgs_host_alloc) as packed rows (HGS_RESID_HOST_ROW_FLOATS); the GPU holds `B` rows in slot arrays.  Per view, after
+ * the LOD cut and its weights:
  *   hgs_resid_mark    every row the cut needs (node row of each entry, and its parent row unless `weights` -- nullable,
  *                     the entries' interpolation weights -- says the weight is exactly 1: the in-op LOD gather does
  *                     not read that parent, and po then repeats the node's slot): resident -> stamped with the
  *                     frame number; absent -> appended ONCE to the miss list (slot_of: >= 0 slot, -1 absent, -2 queued
- *                     this frame); ro / po receive the slots of the resident rows.  Waits; *miss_count_host.
+ *                     this frame); ro / po receive the slots of the resident rows.  Waits; *miss_count_host = rows
+ *                     queued -- also when the call fails with HGS_ERR_INVALID on an index outside [0, G): the caller
+ *                     has to take them out of the queue again (slot_of back to -1).
  *   hgs_resid_evict   when the free list is shorter than the miss list: frees the slots that have gone unused for
  *                     the longest (age histogram on the device, threshold chosen on the host; rows stamped this frame
  *                     are never evicted).  HGS_ERR_CAPACITY if even that is not enough: the working set of the view
