@@ -963,8 +963,8 @@ def main():
     if world > 1:
         exchange = measure_exchange(dp, params, dev, rank, world, rccl_log)
     host_floor = None
-    if world == 1 and primary == "dropin":
-        host_floor = measure_host_floor(dgr, synth, dev)
+    if world == 1 and primary == "dropin" and not args.no_extras:      # (--no-extras: the profiling runs -- no tiny frames
+        host_floor = measure_host_floor(dgr, synth, dev)                # of the same kernels in their per-kernel averages)
 
     if rank == 0:
         r = res[primary]
