@@ -37,7 +37,8 @@ def _small(t, name, n):
         raise RuntimeError(f"{name} must be a tensor")
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be on the GPU (got {t.device})")
-    t = t.to(torch.float32).contiguous()
+    if t.dtype is not torch.float32 or not t.is_contiguous():      # (the usual case costs two attribute reads)
+        t = t.to(torch.float32).contiguous()
     if t.numel() != n:
         raise RuntimeError(f"{name} must have {n} elements, got {t.numel()}")
     return t
@@ -58,8 +59,46 @@ def _lod(weights, kids, P):
 
 class _Call:
     """Everything one forward needs to hand back to the backward.  ``L`` = instances rendered; ``L_ws`` = the
-    instance capacity the binning workspace was carved with (== L on the two-stage path)."""
-    __slots__ = ("args", "keep", "geom", "binb", "img", "L", "L_ws", "P", "W", "H", "device", "scratch", "deferred")
+    instance capacity the binning workspace was carved with (== L on the two-stage path).  The workspaces are byte
+    ranges of at most three arena tensors (``bufs``): raw addresses for the C ABI, ``geom`` / ``binb`` / ``img`` /
+    ``scratch`` as uint8 views on demand (tests, introspection)."""
+    __slots__ = ("args", "keep", "bufs", "p_geom", "p_img", "p_bin", "p_bwd", "n_geom", "n_img", "n_bin", "n_bwd",
+                 "L", "L_ws", "P", "W", "H", "device", "deferred")
+
+    def _view(self, ptr, n):
+        if not ptr:
+            return None
+        for t in self.bufs:
+            off = ptr - t.data_ptr()
+            if 0 <= off and off + n <= t.numel():
+                return t[off:off + n]
+        raise RuntimeError("workspace address outside the call's arenas")
+
+    geom = property(lambda s: s._view(s.p_geom, s.n_geom))
+    img = property(lambda s: s._view(s.p_img, s.n_img))
+    binb = property(lambda s: s._view(s.p_bin, s.n_bin))
+    scratch = property(lambda s: s._view(s.p_bwd, s.n_bwd))
+
+
+_ALIGN = 256
+_plan_cache = {}
+
+
+def _plan(lib, P, W, H, L_ws):
+    """{"geom", "bin", "img", "bwd"} workspace bytes of a frame, each rounded up to 256 -- one hgs_raster_ws_sizes round
+    trip per distinct (P, W, H, L_ws), then a dictionary hit (the speculative capacity is quantised so that it repeats)."""
+    key = (P, W, H, L_ws)
+    pl = _plan_cache.get(key)
+    if pl is None:
+        geom, binb, img, bwd = (C.c_size_t() for _ in range(4))          # (the order of hgs_raster_ws_sizes)
+        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, C.byref(geom), C.byref(binb), C.byref(img), C.byref(bwd)),
+                   "hgs_raster_ws_sizes")
+        up = lambda x: (x.value + _ALIGN - 1) // _ALIGN * _ALIGN
+        pl = {"geom": up(geom), "bin": up(binb), "img": up(img), "bwd": up(bwd)}
+        if len(_plan_cache) > 512:
+            _plan_cache.clear()
+        _plan_cache[key] = pl
+    return pl
 
 
 # Instance count of the previous forward per (device, width, height, Gaussians): lets the next forward of the same
@@ -171,10 +210,6 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     dev = means3D.device
     H, W = int(image_height), int(image_width)
     u8 = dict(dtype=torch.uint8, device=dev)
-    sz = [C.c_size_t() for _ in range(4)]
-    _lib.check(lib.hgs_raster_ws_sizes(P, W, H, 0, *[C.byref(s) for s in sz]), "hgs_raster_ws_sizes")
-    geom = torch.empty(sz[0].value, **u8)
-    img = torch.empty(sz[2].value, **u8)
     radii = torch.empty(P, dtype=torch.int32, device=dev)
     # outputs are allocated before the stage-1 sync so that only the L-sized workspace sits between the stages
     color = torch.empty(3, H, W, dtype=torch.float32, device=dev)
@@ -182,34 +217,58 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         torch.zeros(1, H, W, dtype=torch.float32, device=dev)
     L = C.c_uint32(0)
     devi = dev.index or 0
-    binb = None
-    scratch = None
-    L_ws = 0
+    want_bwd = bool(prepare_backward)
+    call = _Call()
+    call.p_bin = call.p_bwd = call.n_bin = call.n_bwd = 0
     # with lod= the number of rendered rows changes with every cut: the hierarchy (its row count) is the workload
     shape_key = (devi, W, H, P) if lod is None else (devi, W, H, "lod", means3D.shape[0])
     prev = _last_L.get(shape_key) if SPECULATIVE else None
+    L_ws = 0
+    done = False
     if prev is not None and P > 0:
-        # no-bubble path: everything is enqueued before the host learns L
+        # no-bubble path: ONE arena (geometry, per-pixel state, binning, and the backward's scratch when a backward
+        # was announced), everything enqueued before the host learns L.  The capacity is rounded up in steps of 3-6 % so
+        # that consecutive views of a shape ask for the same plan (a dictionary hit instead of a size query).
         L_ws = int(prev * SPEC_GROWTH) + SPEC_SLACK
+        q = 1 << max(L_ws.bit_length() - 5, 0)
+        L_ws = (L_ws + q - 1) // q * q
         stats["speculative_calls"] += 1
-        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
-        binb = torch.empty(sz[1].value, **u8)
-        rc = lib.hgs_raster_fwd(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws, _lib.ptr(radii),
+        pl = _plan(lib, P, W, H, L_ws)
+        n_g, n_i, n_b, n_w = pl["geom"], pl["img"], pl["bin"], (pl["bwd"] if want_bwd else 0)
+        arena = torch.empty(n_g + n_i + n_b + n_w, **u8)
+        base = arena.data_ptr()
+        call.bufs = [arena]
+        call.p_geom, call.n_geom = base, n_g
+        call.p_img, call.n_img = base + n_g, n_i
+        call.p_bin, call.n_bin = base + n_g + n_i, n_b
+        if want_bwd:
+            call.p_bwd, call.n_bwd = base + n_g + n_i + n_b, n_w
+        rc = lib.hgs_raster_fwd(C.byref(a), call.p_geom, call.p_bin, call.p_img, L_ws, _lib.ptr(radii),
                                 _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None, C.byref(L),
                                 _stream(dev), devi)
         if rc == _lib.ERR_CAPACITY:
-            binb = None   # the scene grew by more than 25 %: finish on the exact two-stage path
-            stats["capacity_misses"] += 1
+            stats["capacity_misses"] += 1        # the scene grew by more than 25 %: finish on the exact two-stage path
         else:
             _lib.check(rc, "hgs_raster_fwd")
+            done = True
     else:
-        _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), _lib.ptr(geom), _lib.ptr(radii), C.byref(L),
+        pl = _plan(lib, P, W, H, 0)
+        n_g, n_i = pl["geom"], pl["img"]
+        arena = torch.empty(n_g + n_i, **u8)
+        base = arena.data_ptr()
+        call.bufs = [arena]
+        call.p_geom, call.n_geom, call.p_img, call.n_img = base, n_g, base + n_g, n_i
+        _lib.check(lib.hgs_raster_fwd_stage1(C.byref(a), call.p_geom, _lib.ptr(radii), C.byref(L),
                                              _stream(dev), devi), "hgs_raster_fwd_stage1")
-    if binb is None:
+    if not done:
         L_ws = L.value
-        _lib.check(lib.hgs_raster_ws_sizes(P, W, H, L_ws, None, C.byref(sz[1]), None, C.byref(sz[3])), "hgs_raster_ws_sizes")
-        binb = torch.empty(sz[1].value, **u8)
-        _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), _lib.ptr(geom), _lib.ptr(binb), _lib.ptr(img), L_ws,
+        pl = _plan(lib, P, W, H, L_ws)
+        n_b, n_w = pl["bin"], (pl["bwd"] if want_bwd else 0)
+        arena2 = torch.empty(n_b + n_w, **u8)
+        call.bufs.append(arena2)
+        call.p_bin, call.n_bin = arena2.data_ptr(), n_b
+        call.p_bwd, call.n_bwd = (call.p_bin + n_b, n_w) if want_bwd else (0, 0)
+        _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), call.p_geom, call.p_bin, call.p_img, L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
     # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
@@ -218,12 +277,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     while len(_last_L) > 64:                           # forget the shape that was used longest ago
         _last_L.pop(next(iter(_last_L)))
     stats["last_L"] = L.value
-    call = _Call()
-    call.args, call.keep, call.geom, call.binb, call.img = a, keep, geom, binb, img
+    call.args, call.keep = a, keep
     call.L, call.L_ws, call.P, call.W, call.H, call.device = L.value, L_ws, P, W, H, dev
-    call.scratch = scratch
     call.deferred = None
-    return L.value, color, radii, geom, binb, img, invdepth, call
+    # (geomBuffer, binningBuffer, imgBuffer of the upstream signature: call.geom / call.binb / call.img on demand)
+    return L.value, color, radii, None, None, None, invdepth, call
 
 
 lod_scatter_in_kernel = True     # False: row gradients through memory + lod_gather_backward (kept for 3M % 4 != 0; tests)
@@ -287,17 +345,19 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     g.dL_dshs_rest = p(d_shr)
     a.accumulate_grads = int(bool(accumulate and out is not None))
     a.defer_sh_bwd = int(bool(defer_sh and sh is not None and sh_rest is None))
-    # the backward's scratch (instance records + per-Gaussian colour gradients): needs no initialisation, K7 writes
-    # every instance record
-    bwd_bytes = C.c_size_t()
-    _lib.check(lib.hgs_raster_ws_sizes(P, call.W, call.H, call.L_ws, None, None, None, C.byref(bwd_bytes)),
-               "hgs_raster_ws_sizes")
-    scratch = torch.empty(bwd_bytes.value, dtype=torch.uint8, device=dev)
-    _lib.check(lib.hgs_raster_bwd(C.byref(a), p(call.geom), p(call.binb), p(call.img), p(scratch), call.L_ws,
+    # the backward's scratch (instance records + per-Gaussian colour gradients) was carved from the forward's arena when
+    # the forward knew a backward would follow; it needs no initialisation, K7 writes every instance record
+    p_bwd = call.p_bwd
+    if not p_bwd:
+        n_w = _plan(lib, P, call.W, call.H, call.L_ws)["bwd"]
+        extra = torch.empty(n_w, dtype=torch.uint8, device=dev)
+        call.bufs.append(extra)
+        p_bwd, call.p_bwd, call.n_bwd = extra.data_ptr(), extra.data_ptr(), n_w
+    _lib.check(lib.hgs_raster_bwd(C.byref(a), call.p_geom, call.p_bin, call.p_img, p_bwd, call.L_ws,
                                   p(color), p(invdepth) if use_depth else None, p(dL_dcolor),
                                   p(dL_dinvdepth) if use_depth else None, C.byref(g), _stream(dev),
                                   dev.index or 0), "hgs_raster_bwd")
-    call.deferred = (scratch, d_sh, d_m3) if a.defer_sh_bwd else None
+    call.deferred = (p_bwd, d_sh, d_m3) if a.defer_sh_bwd else None
     if sh_rest is not None:
         return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot, d_shr
     return d_m2, d_col, d_op, d_m3, d_cov, d_sh, d_sc, d_rot
@@ -324,7 +384,7 @@ def sh_backward_batched(calls, accumulate=False):
         chunk = calls[i:i + _lib.MAX_DEFERRED_VIEWS]
         arr = (_lib.ShBwdView * len(chunk))()
         for v, c in zip(arr, chunk):
-            v.geom_ws, v.bwd_ws, v.campos, v.L = c.geom.data_ptr(), c.deferred[0].data_ptr(), c.keep[3].data_ptr(), c.L_ws
+            v.geom_ws, v.bwd_ws, v.campos, v.L = c.p_geom, c.deferred[0], c.keep[3].data_ptr(), c.L_ws
         _lib.check(lib.hgs_raster_sh_bwd_batched(arr, len(chunk), first.P, first.args.M, first.args.sh_degree,
                                                  _lib.ptr(means3D), _lib.ptr(sh), _lib.ptr(d_sh), _lib.ptr(d_m3),
                                                  int(bool(accumulate or i > 0)), _stream(dev), dev.index or 0),
@@ -391,8 +451,9 @@ def raster_views(call):
     """Test/introspection helper: typed torch views of the sorted keys, point list, tile ranges, ..."""
     lib = _lib.lib()
     v = _lib.RasterViews()
-    _lib.check(lib.hgs_raster_views_get(call.P, call.W, call.H, call.L_ws, _lib.ptr(call.geom), _lib.ptr(call.binb),
-                                        _lib.ptr(call.img), C.byref(v)), "hgs_raster_views_get")
+    geom, binb, img = call.geom, call.binb, call.img
+    _lib.check(lib.hgs_raster_views_get(call.P, call.W, call.H, call.L_ws, call.p_geom, call.p_bin, call.p_img,
+                                        C.byref(v)), "hgs_raster_views_get")
 
     def view(buf, addr, dtype, count):
         off = addr - buf.data_ptr()
@@ -402,16 +463,16 @@ def raster_views(call):
     P, L, W, H = call.P, call.L, call.W, call.H
     T = ((W + 15) // 16) * ((H + 15) // 16)
     return {
-        "tile_ids_sorted": view(call.binb, v.tile_ids_sorted, torch.int32, L),
-        "point_list": view(call.binb, v.point_list, torch.int32, L),
-        "ranges": view(call.binb, v.ranges, torch.int32, T * 2).view(T, 2),
-        "tiles_touched": view(call.geom, v.tiles_touched, torch.int32, P),
-        "offsets": view(call.geom, v.offsets, torch.int32, P),
-        "depths": view(call.geom, v.depths, torch.float32, P),
-        "rects": view(call.geom, v.rects, torch.int32, P * 2).view(P, 2),
-        "records": view(call.geom, v.records, torch.float32, P * 16).view(P, 16),
-        "final_T": view(call.img, v.final_T, torch.float32, H * W).view(H, W),
-        "n_contrib": view(call.img, v.n_contrib, torch.int32, H * W).view(H, W),
+        "tile_ids_sorted": view(binb, v.tile_ids_sorted, torch.int32, L),
+        "point_list": view(binb, v.point_list, torch.int32, L),
+        "ranges": view(binb, v.ranges, torch.int32, T * 2).view(T, 2),
+        "tiles_touched": view(geom, v.tiles_touched, torch.int32, P),
+        "offsets": view(geom, v.offsets, torch.int32, P),
+        "depths": view(geom, v.depths, torch.float32, P),
+        "rects": view(geom, v.rects, torch.int32, P * 2).view(P, 2),
+        "records": view(geom, v.records, torch.float32, P * 16).view(P, 16),
+        "final_T": view(img, v.final_T, torch.float32, H * W).view(H, W),
+        "n_contrib": view(img, v.n_contrib, torch.int32, H * W).view(H, W),
     }
 
 

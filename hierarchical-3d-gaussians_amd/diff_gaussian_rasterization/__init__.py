@@ -128,7 +128,7 @@ class _on_backward_stream:
         self.main = torch.cuda.current_stream(sb.device)
         sb.wait_stream(self.main)
         c = self.call
-        for t in tuple(self.tensors) + (c.geom, c.binb, c.img, getattr(c, "scratch", None)) + tuple(c.keep):
+        for t in tuple(self.tensors) + tuple(c.bufs) + tuple(c.keep):
             if torch.is_tensor(t) and t.is_cuda:
                 t.record_stream(sb)
         self.ctx = torch.cuda.stream(sb)
