@@ -206,3 +206,97 @@ def test_source_stamp_ignores_comments_but_not_code():
     assert bench._code_only(a) == bench._code_only(b) != bench._code_only(c)
     assert "http://a//b" in bench._code_only(a)                  # '//' behind a ':' is not a comment
     assert len(bench.kernel_source_sha()) == 16
+
+
+def test_forward_arena_layout_against_the_real_size_functions(monkeypatch):
+    """The Python glue carves ONE arena per forward (geometry, per-pixel state, binning workspace, backward scratch) and
+    hands raw addresses to the C ABI.  No GPU here: the compute entry points are replaced by fakes that check every
+    address range the glue passes against the REAL hgs_raster_ws_sizes (ranges disjoint, each at least as large as the
+    library asks for), on the two-stage path, the speculative path, a capacity miss and an empty scene;
+    hgs_raster_views_get -- pure pointer arithmetic -- runs for real and must hand back correctly shaped views."""
+    import ctypes as C
+    import torch
+    import diff_gaussian_rasterization as dgr
+    from hgs import _lib
+    Cm = dgr._C
+    real = _lib.lib()
+
+    class Fake:
+        def __init__(self):
+            self.calls, self.L_next = [], 5000
+
+        def __getattr__(self, name):
+            return getattr(real, name)
+
+        def _check(self, a, L_ws, **ptrs):
+            g, b, i, w = (C.c_size_t() for _ in range(4))
+            assert real.hgs_raster_ws_sizes(a.P, a.width, a.height, L_ws, C.byref(g), C.byref(b), C.byref(i), C.byref(w)) == 0
+            need = dict(geom=g.value, bin=b.value, img=i.value, bwd=w.value)
+            spans = sorted((p, p + need[k], k) for k, p in ptrs.items())
+            for (a0, a1, ka), (b0, b1, kb) in zip(spans, spans[1:]):
+                assert a1 <= b0, f"{ka} [{a0}, {a1}) overlaps {kb} [{b0}, {b1})"
+
+        def hgs_raster_fwd(self, a, geom, binb, img, L_cap, radii, color, invd, Lref, stream, dev):
+            self._check(a._obj, L_cap, geom=geom, bin=binb, img=img)
+            self.calls.append(("fwd", L_cap))
+            C.cast(Lref, C.POINTER(C.c_uint32))[0] = self.L_next
+            return _lib.ERR_CAPACITY if self.L_next > L_cap else 0
+
+        def hgs_raster_fwd_stage1(self, a, geom, radii, Lref, stream, dev):
+            C.cast(Lref, C.POINTER(C.c_uint32))[0] = self.L_next
+            self.calls.append(("stage1",))
+            return 0
+
+        def hgs_raster_fwd_stage2(self, a, geom, binb, img, L, color, invd, stream, dev):
+            self._check(a._obj, L, geom=geom, bin=binb, img=img)
+            self.calls.append(("stage2", L))
+            return 0
+
+        def hgs_raster_bwd(self, a, geom, binb, img, bwd, L, *rest):
+            self._check(a._obj, L, geom=geom, bin=binb, img=img, bwd=bwd)
+            self.calls.append(("bwd", L))
+            return 0
+
+    fake = Fake()
+    monkeypatch.setattr(_lib, "lib", lambda: fake)
+    monkeypatch.setattr(Cm, "_require_gpu", lambda t, n: t.contiguous())
+    monkeypatch.setattr(Cm, "_small", lambda t, n, k: t.to(torch.float32).contiguous())
+    monkeypatch.setattr(Cm, "_stream", lambda d: None)
+    monkeypatch.setattr(Cm, "_last_L", {})
+    W, H = 208, 144
+    z = lambda *s: torch.zeros(*s)
+
+    def fwd(P, prepare):
+        return Cm.rasterize_gaussians(z(3), z(P, 3), None, z(P, 1), z(P, 3), z(P, 4), 1.0, None, z(4, 4), z(4, 4), 1.0,
+                                      1.0, H, W, z(P, 16, 3), 3, z(3), False, False, None, None, None, None, True,
+                                      prepare_backward=prepare)[-1]
+
+    def bwd(call):
+        Cm.rasterize_gaussians_backward(call, z(3, H, W), z(1, H, W), z(3, H, W), z(1, H, W))
+
+    P = 3000
+    call = fwd(P, True)                                      # first view of a shape: two stages, exact sizes
+    assert [c[0] for c in fake.calls] == ["stage1", "stage2"] and call.L_ws == call.L == 5000
+    v = Cm.raster_views(call)
+    assert v["final_T"].shape == (H, W) and v["records"].shape == (P, 16) and v["point_list"].shape == (5000,)
+    assert call.scratch is not None and len(call.bufs) == 2
+    fake.calls.clear()
+    call = fwd(P, True)                                      # speculative: one arena, the backward's scratch inside it
+    assert [c[0] for c in fake.calls] == ["fwd"] and call.L_ws >= int(5000 * Cm.SPEC_GROWTH) + Cm.SPEC_SLACK
+    assert len(call.bufs) == 1 and call.p_bwd != 0 and Cm.raster_views(call)["n_contrib"].shape == (H, W)
+    bwd(call)
+    assert fake.calls[-1] == ("bwd", call.L_ws)
+    first_plan = call.L_ws
+    call = fwd(P, True)
+    assert call.L_ws == first_plan                           # the quantised capacity repeats: a plan-cache hit
+    fake.calls.clear()
+    fake.L_next = 10 ** 6                                    # the scene grew: capacity miss, exact second stage
+    call = fwd(P, False)
+    assert [c[0] for c in fake.calls] == ["fwd", "stage2"] and call.L_ws == 10 ** 6 and call.p_bwd == 0
+    bwd(call)                                                # a backward nobody announced allocates its scratch itself
+    assert call.p_bwd != 0 and fake.calls[-1] == ("bwd", 10 ** 6)
+    fake.calls.clear()
+    fake.L_next = 0
+    monkeypatch.setattr(Cm, "_last_L", {})
+    call = fwd(0, False)                                     # empty scene
+    assert [c[0] for c in fake.calls] == ["stage1", "stage2"] and call.L == 0
