@@ -246,15 +246,17 @@ print("digest", h.hexdigest(), r["L"])
 
 
 def test_diagnostic_wait_and_count_routes_give_the_same_frame(gpu):
-    """HGS_BLOCKING_WAIT (sleeping host waits instead of polling) and HGS_COUNT_BY_COPY (the instance count by a copy
-    command instead of the scan kernel's store into mapped host memory) are read once per process: one small
+    """HGS_BLOCKING_WAIT (sleeping host waits instead of polling), HGS_COUNT_BY_COPY (the instance count by a copy
+    command instead of the scan kernel's store into mapped host memory) and HGS_SCAN_SPLIT (the workgroup-sum scans by
+    one launch per array, the route of views too large for one resident grid) are read once per process: one small
     fwd+bwd per setting in a process of its own, bit-identical outputs and gradients."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
-    for name, env in (("default", {}), ("blocking", {"HGS_BLOCKING_WAIT": "1"}), ("copy", {"HGS_COUNT_BY_COPY": "1"})):
+    for name, env in (("default", {}), ("blocking", {"HGS_BLOCKING_WAIT": "1"}), ("copy", {"HGS_COUNT_BY_COPY": "1"}),
+                      ("split", {"HGS_SCAN_SPLIT": "1"})):
         r = subprocess.run([sys.executable, "-c", _FRAME_DIGEST, root], env={**os.environ, **env}, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         digests[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")][-1]
-    assert digests["default"] == digests["blocking"] == digests["copy"], digests
+    assert digests["default"] == digests["blocking"] == digests["copy"] == digests["split"], digests
