@@ -190,6 +190,72 @@ def _profile_json(name):
         return None, None
 
 
+PMC_PASSES = {       # one rocprofv3 run per counter group, each with --kernel-trace only (MI355X_MICROARCH.md, HBM / rocprofv3)
+    "SQ": ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU",
+           "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY"],
+    "FETCH": ["FETCH_SIZE"],
+    "WRITE": ["WRITE_SIZE"],
+}
+
+
+def measure_pmc_live(args, N, L, time_limit=75):
+    """HBM traffic and vector-ALU counters of THIS build on THIS box, collected while this command runs: one
+    `rocprofv3 --pmc <group> --kernel-trace` child per counter group around a 3-step drop-in run of this very script at
+    the same configuration (this process is idle meanwhile: nothing else touches HBM), summarised per kernel by
+    scripts/pmc_summary.py and turned into bytes per launch by scripts/make_pmc_json.py (gfx950 corrections there).
+    Returns (traffic, valu, note); (None, None, why) when rocprofv3 is absent, fails or exceeds its time limit -- the
+    caller then falls back to the committed summary of the same build, if there is one."""
+    import glob
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None, "rocprofv3 not found"
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import make_pmc_json
+        import pmc_summary
+    except Exception as e:
+        return None, None, f"scripts/ not importable: {e!r}"
+    tmp = tempfile.mkdtemp(prefix="hgs_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
+             "--no-stage-timing", "--no-secondary", "--schedule", "dropin", "--gaussians", str(args.gaussians),
+             "--width", str(args.width), "--height", str(args.height)]
+    t0 = time.perf_counter()
+    merged = {}
+    try:
+        for name, counters in PMC_PASSES.items():
+            out = os.path.join(tmp, name)
+            cmd = [exe, "--pmc", *counters, "--kernel-trace", "-d", out, "-o", "pmc", "--", *child]
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                    stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=time_limit)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)       # the group this call started, nothing else
+                proc.wait()
+                return None, None, f"rocprofv3 --pmc {name} pass exceeded {time_limit} s"
+            if proc.returncode != 0:
+                return None, None, f"rocprofv3 --pmc {name} pass exited with {proc.returncode}"
+            dbs = sorted(glob.glob(os.path.join(out, "**", "*.db"), recursive=True))
+            if not dbs:
+                return None, None, f"rocprofv3 --pmc {name} pass wrote no database"
+            for kernel, cs in pmc_summary.load(dbs[0]).items():
+                merged.setdefault(kernel, {}).update(cs)
+        traffic, valu = make_pmc_json.derive(merged, N, L)
+        if DOMINANT not in traffic:
+            return None, None, "the counter passes saw no launch of the dominant kernel"
+        return traffic, valu, (f"measured in this run: rocprofv3 --pmc passes ({' | '.join(' '.join(c) for c in PMC_PASSES.values())}; "
+                               f"--kernel-trace only) of 3 drop-in steps of this command in a child process, "
+                               f"{time.perf_counter() - t0:.0f} s")
+    except Exception as e:
+        return None, None, f"live PMC collection failed: {e!r}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 class DropIn:
     """The reference's call shape, one view per step: ``GaussianRasterizer(raster_settings)(means3D, means2D, shs,
     colors_precomp=None, opacities, scales, rotations, cov3D_precomp=None)`` + ``backward`` with fresh ``.grad`` tensors
@@ -744,6 +810,9 @@ def main():
                     help="skip the `extra` objects (BASELINE configs 2 / 3 / 5 and the heavy 1 M variant)")
     ap.add_argument("--extras", default="config2_300k,heavy_1m,config3_train_post,config5_50m_4k_render,config5_budgeted_6gb")
     ap.add_argument("--no-stage-timing", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect the PMC counters of the roofline object in this run (rocprofv3 child processes, "
+                         "~15 s); the committed summary of the same build is used instead.  Implied by --no-extras")
     ap.add_argument("--cpu-baseline-only", type=int, default=0, metavar="L",
                     help="internal: time the CPU oracle for a frame with L tile instances, print JSON, exit")
     args = ap.parse_args()
@@ -1036,6 +1105,7 @@ def main():
             sec = stages[dom] * 1e-3
             traffic_db, traffic_path = _profile_json("pmc_traffic.json")
             valu_db, valu_path = _profile_json("pmc_valu.json")
+            mix_peak = {k_: v_ for k_, v_ in (valu_db or {}).items() if k_ in ("_peak_ginst_s", "_peak_source")}
             # committed PMC summaries are used only if they were collected on THIS build of the kernels
             if traffic_db is not None and traffic_db.get("_src_sha") != src_sha:
                 stale_t, traffic_db = traffic_db.get("_run", "unknown"), None
@@ -1043,27 +1113,43 @@ def main():
                 stale_t = None
             if valu_db is not None and valu_db.get("_src_sha") != src_sha:
                 valu_db = None
+            live_note = None
+            if world == 1 and primary == "dropin" and not (args.no_extras or args.no_live_pmc):
+                live_t, live_v, live_note = measure_pmc_live(args, N, L)
+                if live_t is not None:
+                    # (the measured issue rate of K7's instruction mix is a property of the chip, not of the build)
+                    traffic_db = dict(live_t, _run="this run", _live=True)
+                    valu_db = dict(live_v, _run="this run", _live=True, **mix_peak)
+                    traffic_path = valu_path = "rocprofv3 child processes of this run"
             traffic = (traffic_db or {}).get(dom)
             result["roofline"] = roofline_object(
                 sb, stages, dom,
                 "SURVEY.md §8(d): render_bwd = 24 N + 44 L + 40 V (N pixels, L tile instances, V visible Gaussians: means "
                 "over the views of THIS run); avg_ms = hipEvents around every launch inside the timed steps",
                 {"traffic": traffic, "traffic_upper": (traffic_db or {}).get(dom + "_upper"),
-                 "traffic_source": (f"{traffic_path}['{dom}'] (run id {traffic_db.get('_run', 'unknown')}, kernel sources "
-                                    f"{src_sha} = this build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
-                                    "command -- a committed profile, NOT measured in this run.  Streaming kernels: "
+                 "traffic_source": (((live_note + ".  ") if traffic_db.get("_live") else
+                                     (f"{traffic_path}['{dom}'] (run id {traffic_db.get('_run', 'unknown')}, kernel sources "
+                                      f"{src_sha} = this build): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                      "command -- a committed profile, NOT measured in this run" +
+                                      (f" ({live_note})" if live_note else "") + ".  ")) + "Streaming kernels: "
                                     "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch (gfx950 correction of the guide); the "
                                     "compositing kernels read 64-byte records at random places, for which FETCH_SIZE "
                                     "is exact (profiles/r03_microbench_gather_fetch.txt): FETCH_SIZE KiB + half of "
                                     "the streamed reads of the byte model + WRITE_SIZE KiB; traffic_upper = the "
                                     "uncorrected 2*FETCH_SIZE figure") if traffic else
-                                   (f"dropped: profiles/pmc_traffic.json (run {stale_t}) was collected on another "
-                                    "build of the kernels" if stale_t else None),
+                                   ("; ".join(x for x in (
+                                       live_note, f"dropped: profiles/pmc_traffic.json (run {stale_t}) was collected on "
+                                                  "another build of the kernels" if stale_t else None) if x) or None),
                  "impl_bytes": ab[dom], "impl_achieved": ab[dom] / sec / 1e9,
                  "impl_frac": ab[dom] / sec / 1e9 / HBM_PEAK_GBS,
                  "impl_bytes_model": "this implementation's own traffic model (record and per-instance scratch as laid out in HBM)",
                  "note": "compositing kernels are VALU-issue-bound (gather/blend, no MFMA); the HBM fraction is "
                          "reported because the metric mandates it"})
+            if traffic_db:      # every stage's HBM bytes per launch beside its §8(d) bytes: where re-reads are
+                result["roofline"]["traffic_by_stage"] = {
+                    s_: {"traffic": traffic_db[s_], "algorithmic_bytes": sb.get(s_),
+                         "ratio": (traffic_db[s_] / sb[s_]) if sb.get(s_) else None}
+                    for s_ in stages if s_ in traffic_db}
             # The compositing kernels are VALU-issue-bound: add the vector-ALU view next to the mandated HBM one.
             pv = (valu_db or {}).get(dom)
             if pv:
@@ -1080,9 +1166,11 @@ def main():
                     # SIMD-cycles the launch lasted at the nominal 2.4 GHz: how busy the vector ALUs were
                     "alu_busy_frac": (pv["valu_active_quadcycles_per_wave"] * 4.0 * pv["waves"] / 1024.0) / (sec * 2.4e9)
                     if "valu_active_quadcycles_per_wave" in pv else None,
-                    "source": f"{valu_path} (run id {valu_db.get('_run', 'unknown')}, kernel sources {src_sha} = this "
-                              "build): SQ_INSTS_VALU per launch from a committed rocprofv3 --pmc pass of this command "
-                              "(NOT measured in this run); time from this run; peak_mix_ginst_s = " +
+                    "source": ("SQ_INSTS_VALU per launch measured in this run (rocprofv3 --pmc child process of this "
+                               "command); time from this run; peak_mix_ginst_s = " if valu_db.get("_live") else
+                               f"{valu_path} (run id {valu_db.get('_run', 'unknown')}, kernel sources {src_sha} = this "
+                               "build): SQ_INSTS_VALU per launch from a committed rocprofv3 --pmc pass of this command "
+                               "(NOT measured in this run); time from this run; peak_mix_ginst_s = ") +
                               str(valu_db.get("_peak_source", "assumed"))}
             result["stages_ms"] = stages
             result["stages_gbs"] = {s_: sb[s_] / (v * 1e-3) / 1e9 for s_, v in stages.items() if s_ in sb}

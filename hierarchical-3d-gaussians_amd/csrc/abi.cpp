@@ -131,6 +131,22 @@ hipError_t wait_event(hipEvent_t e) {
   return hipEventSynchronize(e);
 }
 
+int scan_resident_workgroups() {
+  static int cus[kMaxDevices] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1;
+  if (cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
+    cus[dev] = n;                                  // racing first calls store the same value
+  }
+  return cus[dev];
+}
+bool scan_split_forced() {
+  static const bool b = getenv("HGS_SCAN_SPLIT") != nullptr;
+  return b;
+}
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);

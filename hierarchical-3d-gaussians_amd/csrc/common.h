@@ -109,8 +109,11 @@ __host__ __device__ inline int scan_chunks(size_t n) { return (int)((n + kScanCh
 // In-place exclusive scan of sums[0 .. n), total to sums[n], by scan_chunks(n) workgroups of 1024 threads IN ONE LAUNCH:
 // workgroup c (= blockIdx.x) scans entries [c, c + 1) * kScanChunk locally, publishes its total in chain[c] (bit 32 = valid)
 // and adds the published totals of the workgroups before it -- which were dispatched before it and wait for nobody, so
-// the look-back cannot deadlock whatever fits on the chip.  `chain` must be ZERO when the launch starts (the kernel
-// that produces the sums clears it).  One workgroup walking the array 1024 entries per round cost 0.13 ms at the 96 k
+// the look-back cannot deadlock whatever fits on the chip.  HIP does not PROMISE that dispatch order, so the launchers
+// do not lean on it: a grid of at most scan_resident_workgroups() workgroups is resident all at once (every compute unit
+// holds one 1024-thread workgroup of this kernel) and then no order matters; larger jobs are split into one launch per
+// array, and an array of more chunks than that (5e8 rows on 256 compute units) is refused.  `chain` must be ZERO when
+// the launch starts (the kernel that produces the sums clears it).  One workgroup walking the array 1024 entries per round cost 0.13 ms at the 96 k
 // sums of a 24.7 M-row view and 0.24 ms at the 195 k of a 50 M-node cut (one memory round trip + three barriers per
 // round, nothing to overlap them with); the 24 chunk workgroups take one round each.
 // Returns the grand total in the LAST chunk's threads (0 elsewhere).
@@ -179,9 +182,14 @@ __device__ __forceinline__ uint32_t chained_scan_inplace(uint32_t* __restrict__ 
 hipError_t wait_stream(hipStream_t s);
 hipError_t wait_event(hipEvent_t e);
 
+// Compute units of the current device = 1024-thread workgroups of the chained scan that are certainly resident together.
+int scan_resident_workgroups();
+// HGS_SCAN_SPLIT (diagnostic, read once per process): one launch per array even where the single grid fits.
+bool scan_split_forced();
+
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
-// scans block_sums and the kBands columns of block_band (one launch, one workgroup per array)
+// scans block_sums and the kBands columns of block_band (one launch while the grid is resident at once, else one per array)
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror = nullptr);
 // banded: one instance stream per tile band (b.keys_in = band-local tile ids), else one stream of global tile ids
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,

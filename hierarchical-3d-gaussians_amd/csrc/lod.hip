@@ -242,6 +242,11 @@ static int expand_finish(const int32_t* nodes, const ExpandTmp& t, int32_t N, in
                          int32_t* parent_indices, int32_t* nodes_for_render_indices, int32_t capacity,
                          int32_t* count_out_host, hipStream_t s) {
   const int nblk = (N + 255) / 256;
+  if (scan_chunks(nblk) > scan_resident_workgroups()) {
+    set_error("expand_to_size: %d nodes need %d scan workgroups, the device holds %d at once", N, scan_chunks(nblk),
+              scan_resident_workgroups());
+    return HGS_ERR_INVALID;
+  }
   hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(scan_chunks(nblk)), dim3(1024), 0, s, t.block_sums, nblk, t.chain);
   HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
   hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,

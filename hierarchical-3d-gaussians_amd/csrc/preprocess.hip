@@ -1348,9 +1348,24 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
 
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
-  hipLaunchKernelGGL(scan_block_sums_kernel, dim3(scan_chunks(nblk), 1 + kBands), dim3(1024), 0, s, g.block_sums,
-                     g.block_band, nblk, g.scan_chain, total_mirror);
-  HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+  const int chunks = scan_chunks(nblk), resident = scan_resident_workgroups();
+  if (chunks > resident) {
+    set_error("scan_block_sums: %d rows need %d scan workgroups per array, the device holds %d at once", P, chunks, resident);
+    return HGS_ERR_INVALID;
+  }
+  if (chunks * (1 + kBands) <= resident && !scan_split_forced()) {
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(chunks, 1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band,
+                       nblk, g.scan_chain, total_mirror);
+    HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+    return HGS_OK;
+  }
+  // one launch per array (the kernel's row 0 scans its first pointer); above 58.7 M rows on 256 compute units
+  for (int y = 0; y < 1 + kBands; ++y) {
+    uint32_t* sums = y == 0 ? g.block_sums : g.block_band + (size_t)(y - 1) * (nblk + 1);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(chunks, 1), dim3(1024), 0, s, sums, g.block_band, nblk,
+                       g.scan_chain + (size_t)y * chunks, y == 0 ? total_mirror : nullptr);
+    HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+  }
   return HGS_OK;
 }
 

@@ -29,18 +29,13 @@ STAGES = {           # bench.py stage -> substrings of the kernels it launches
 PER_FRAME = {}   # launches per frame of one kernel symbol when it is not 1
 
 
-def main():
-    d = json.load(open(sys.argv[1]))
-    run = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
-    sys.path.insert(0, ROOT)
-    import bench                      # kernel_source_sha(): bench.py only uses a summary collected on the build it runs
-    sha = d.get("_src_sha") or bench.kernel_source_sha()
-    head = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT), "_src_sha": sha}
-    traffic, valu = dict(head), dict(head)
-    d = {k: v for k, v in d.items() if not k.startswith("_") or k == "_L"}
-    # streamed reads of the gather kernels at the configuration the PMC passes run (bench.py defaults: 1920x1080, L from
-    # the run): K6 reads the id list (4 L); K7 the id list + dL/dcolor, dL/dinvdepth, final_T, n_contrib (24 N)
-    N, L = 1920 * 1080, float(d.get("_L", 2_660_211))
+def derive(d, N, L, head=None):
+    """(traffic, valu) dictionaries from a per-kernel counter summary {kernel name: {counter: mean per launch}}.
+    N pixels, L tile instances of the profiled frames (the streamed reads of the two gather kernels)."""
+    traffic, valu = dict(head or {}), dict(head or {})
+    d = {k: v for k, v in d.items() if not k.startswith("_")}
+    # streamed reads of the gather kernels: K6 reads the id list (4 L); K7 the id list + dL/dcolor, dL/dinvdepth,
+    # final_T, n_contrib (24 N)
     streamed = {"render_fwd": 4 * L, "render_bwd": 4 * L + 24 * N}
     for stage, pats in STAGES.items():
         tot = upper = 0.0
@@ -67,6 +62,18 @@ def main():
                                "waves": cs.get("SQ_WAVES"),
                                "valu_active_quadcycles_per_wave": cs.get("SQ_ACTIVE_INST_VALU", 0.0) / w,
                                "wave_quadcycles_per_wave": cs.get("SQ_WAVE_CYCLES", 0.0) / w}
+    return traffic, valu
+
+
+def main():
+    d = json.load(open(sys.argv[1]))
+    run = sys.argv[2] if len(sys.argv) > 2 else os.path.basename(sys.argv[1])
+    sys.path.insert(0, ROOT)
+    import bench                      # kernel_source_sha(): bench.py only uses a summary collected on the build it runs
+    sha = d.get("_src_sha") or bench.kernel_source_sha()
+    head = {"_run": run, "_source": os.path.relpath(sys.argv[1], ROOT), "_src_sha": sha}
+    # the configuration the PMC passes run (bench.py defaults: 1920x1080, L from the run)
+    traffic, valu = derive(d, 1920 * 1080, float(d.get("_L", 2_660_211)), head)
     if len(sys.argv) > 3:
         txt = open(sys.argv[3]).read()
         m = re.search(r"K7 mix.*waves/SIMD=5\s+[\d.]+ us\s+([\d.]+) G wave-inst/s", txt)
