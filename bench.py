@@ -243,7 +243,7 @@ def measure_pmc_live(args, N, L, time_limit=75):
             if not dbs:
                 return None, None, f"rocprofv3 --pmc {name} pass wrote no database"
             for kernel, cs in pmc_summary.load(dbs[0]).items():
-                merged.setdefault(kernel, {}).update(cs)
+                merged.setdefault(pmc_summary.short_name(kernel), {}).update(cs)
         traffic, valu = make_pmc_json.derive(merged, N, L)
         if DOMINANT not in traffic:
             return None, None, "the counter passes saw no launch of the dominant kernel"

@@ -7,7 +7,7 @@ rm -f gpurun_out/parity_log.jsonl gpurun_out/scale_parity.jsonl
 timeout 400 python -m pytest tests -q -m gpu -rA -s -p no:cacheprovider --timeout=300 --durations=6 > gpurun_out/final_pytest_gpu.log 2>&1
 echo "pytest exit $?"; grep -a "passed\|failed" gpurun_out/final_pytest_gpu.log | tail -2; grep -a "^FAILED\|^ERROR" gpurun_out/final_pytest_gpu.log | head
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1; echo "smoke exit $?"
-/usr/bin/time -f "bench wall %e s" timeout 300 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench exit $?"; tail -2 gpurun_out/final_bench.err
+T0=$SECONDS; timeout 300 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err; echo "bench exit $? wall $((SECONDS-T0)) s"; tail -2 gpurun_out/final_bench.err
 python - <<'PY'
 import json
 d = json.loads(open("gpurun_out/final_bench.json").read().strip().splitlines()[-1])

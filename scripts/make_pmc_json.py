@@ -33,7 +33,7 @@ def derive(d, N, L, head=None):
     """(traffic, valu) dictionaries from a per-kernel counter summary {kernel name: {counter: mean per launch}}.
     N pixels, L tile instances of the profiled frames (the streamed reads of the two gather kernels)."""
     traffic, valu = dict(head or {}), dict(head or {})
-    d = {k: v for k, v in d.items() if not k.startswith("_")}
+    d = {k: v for k, v in d.items() if isinstance(v, dict)}        # (metadata entries of a summary file are scalars)
     # streamed reads of the gather kernels: K6 reads the id list (4 L); K7 the id list + dL/dcolor, dL/dinvdepth,
     # final_T, n_contrib (24 N)
     streamed = {"render_fwd": 4 * L, "render_bwd": 4 * L + 24 * N}

@@ -24,13 +24,17 @@ def load(db_path):
     return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in out.items()}
 
 
+def short_name(k):
+    """The mangled symbol without the namespace prefix and the argument list (what the committed summaries are keyed by)."""
+    return k.replace("_ZN3hgs12_GLOBAL__N_1", "hgs::").split("E15hgs")[0][:60]
+
+
 def main():
     res = collections.defaultdict(dict)
     for arg in sys.argv[1:]:
         name, path = arg.split("=", 1)
         for k, cs in load(path).items():
-            short = k.replace("_ZN3hgs12_GLOBAL__N_1", "hgs::").split("E15hgs")[0][:60]
-            res[short].update(cs)
+            res[short_name(k)].update(cs)
     try:        # the build these counters were collected on (bench.py refuses summaries from another build)
         import os
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
