@@ -300,3 +300,42 @@ def test_forward_arena_layout_against_the_real_size_functions(monkeypatch):
     monkeypatch.setattr(Cm, "_last_L", {})
     call = fwd(0, False)                                     # empty scene
     assert [c[0] for c in fake.calls] == ["stage1", "stage2"] and call.L == 0
+
+
+def test_pmc_counters_to_bytes_per_launch():
+    """scripts/make_pmc_json.derive: FETCH_SIZE / WRITE_SIZE (KiB per launch) -> HBM bytes per launch by the rules of
+    MI355X_MICROARCH.md (2 x FETCH for streaming kernels on gfx950; FETCH + half of the streamed reads for the two
+    gather kernels), keyed by bench.py's stage names.  The kernel names are the MANGLED symbols rocprofv3 reports,
+    shortened by pmc_summary.short_name -- a summary whose names start with '_' once lost every kernel to the filter
+    meant for a summary file's metadata entries."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "scripts"))
+    import make_pmc_json
+    import pmc_summary
+    mangled = {
+        "_ZN3hgs12_GLOBAL__N_122render_bwd_quad_kernelILb1EEEv15hgs_raster_argsNS_6GeomWsE": dict(FETCH_SIZE=1000.0, WRITE_SIZE=100.0, SQ_INSTS_VALU=5e6, SQ_WAVES=100.0, SQ_ACTIVE_INST_VALU=4e5, SQ_WAVE_CYCLES=8e5),
+        "_ZN3hgs12_GLOBAL__N_121preprocess_fwd_kernelILb1ELb0ELb1EEEv15hgs_raster_argsNS_6GeomWsEPi": dict(FETCH_SIZE=2000.0, WRITE_SIZE=500.0),
+        "_ZN3hgs12_GLOBAL__N_115tb_count_kernelEPKjjS2_iijiPjS3_i": dict(FETCH_SIZE=10.0, WRITE_SIZE=1.0),
+        "_ZN3hgs12_GLOBAL__N_117tb_scatter_kernelEPKjS2_jS2_iijiiiS2_S2_S2_PjS3_S3_S3_": dict(FETCH_SIZE=20.0, WRITE_SIZE=30.0),
+        "_ZN2at6native29vectorized_elementwise_kernelILi4E": dict(FETCH_SIZE=7.0, WRITE_SIZE=7.0),
+    }
+    d = {pmc_summary.short_name(k): v for k, v in mangled.items()}
+    assert all(not k.startswith("_ZN3hgs") for k in d if "hgs" in k)
+    d["_src_sha"] = "0123456789abcdef"                       # metadata of a summary file: ignored
+    N, L = 1000, 200
+    traffic, valu = make_pmc_json.derive(d, N, L, {"_run": "t"})
+    assert traffic["_run"] == "t" and valu["_run"] == "t"
+    assert traffic["preprocess_fwd"] == (2 * 2000.0 + 500.0) * 1024                    # streaming: 2 x FETCH + WRITE
+    assert traffic["tile_sort"] == (2 * 10.0 + 1.0 + 2 * 20.0 + 30.0) * 1024           # the stage's kernels added up
+    assert traffic["render_bwd"] == (1000.0 + 100.0) * 1024 + (4 * L + 24 * N) / 2     # gather: FETCH exact + streamed / 2
+    assert traffic["render_bwd_upper"] == (2 * 1000.0 + 100.0) * 1024
+    assert "render_fwd" not in traffic and "preprocess_bwd" not in traffic             # no launch seen: no entry
+    assert valu["render_bwd"]["valu_insts_per_launch"] == 5e6 and valu["render_bwd"]["valu_active_quadcycles_per_wave"] == 4e3
+    # the committed summaries were made by the same function from the committed per-kernel file
+    import json
+    src = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    per_kernel = json.load(open(os.path.join(root, src["_source"])))
+    again, _ = make_pmc_json.derive(per_kernel, 1920 * 1080, float(per_kernel.get("_L", 2_660_211)))
+    for k, v in again.items():
+        assert src[k] == v, k
