@@ -3,8 +3,8 @@
 // (README.md:233-235; implemented in the un-vendored SIBR viewer -- nothing to restate, the mechanism here is this
 // library's own).  The full attribute arrays live in pinned host memory mapped into the device's address space; the GPU
 // keeps B rows in slot arrays and an int32 per Gaussian saying where (or that not).  Misses of a view are fetched by a
-// kernel that READS THE HOST ARRAYS ITSELF: 59 floats per row, one wave per row, the 64 lanes' four-byte loads coalesce
-// into the row's contiguous segments -- PCIe carries exactly the rows that are needed, there is no host-side gather and no
+// kernel that READS THE HOST ROWS ITSELF (one packed 256-byte row per Gaussian, sixteen lanes per row, one float4 each:
+// resid_fetch_kernel below) -- PCIe carries exactly the rows that are needed, there is no host-side gather and no
 // staging copy.  Slots are recycled by age (frames since the last use) when the free list runs out.
 #include "common.h"
 
