@@ -210,6 +210,8 @@ def measure_pmc_live(args, N, L, time_limit=75):
     import signal
     import subprocess
     import tempfile
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, None, "this run is itself under a profiler (rocprofv3 environment inherited): no nested counter passes"
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, None, "rocprofv3 not found"

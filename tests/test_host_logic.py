@@ -339,3 +339,16 @@ def test_pmc_counters_to_bytes_per_launch():
     again, _ = make_pmc_json.derive(per_kernel, 1920 * 1080, float(per_kernel.get("_L", 2_660_211)))
     for k, v in again.items():
         assert src[k] == v, k
+
+
+def test_live_pmc_collection_declines_under_a_profiler(monkeypatch):
+    """bench.py's own counter passes (rocprofv3 child processes) are not started from a process that already runs under
+    rocprofv3 -- the driver's profile of the test suite, scripts/final_prof.sh: the reason goes into the line instead."""
+    import sys
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    t, v, why = bench.measure_pmc_live(types.SimpleNamespace(gaussians=1000, width=64, height=64), 64 * 64, 100)
+    assert t is None and v is None and "under a profiler" in why
