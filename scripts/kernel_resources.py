@@ -131,12 +131,9 @@ def occupancy(vgprs, agprs, lds_static, wg_threads, lds_dynamic=0):
 DYNAMIC_LDS = {"preprocess_fwd_kernel": 256 * (16 * 3 + 4) * 4, "sh_bwd_kernel": 256 * (16 * 3 + 4) * 4}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("sources", nargs="*")
-    ap.add_argument("--md", action="store_true", help="markdown table")
-    args = ap.parse_args()
-    sources = args.sources or sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+def collect(sources):
+    """One dictionary per kernel of the given sources (file, kernel, vgpr, agpr, sgpr, lds, lds_dyn, scratch, wg,
+    waves_regs, waves_lds, insts, mix)."""
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         for src in sources:
@@ -144,7 +141,7 @@ def main():
             cmd = [HIPCC] + FLAGS + EXTRA.get(os.path.basename(src), []) + ["-I", os.path.join(ROOT, "include"), src, "-o", out]
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
-                sys.exit(f"{src}: {r.stderr[-2000:]}")
+                raise RuntimeError(f"{src}: {r.stderr[-2000:]}")
             ks = parse(open(out).read())
             names = demangle(list(ks))
             for mangled, k in sorted(ks.items(), key=lambda kv: names[kv[0]]):
@@ -161,6 +158,15 @@ def main():
                                  lds=lds, lds_dyn=dyn, scratch=int(m.get("private_segment_fixed_size", 0)),
                                  spills=int(m.get("vgpr_spill_count", 0)), wg=wg, waves_regs=by_regs, waves_lds=by_lds,
                                  insts=total, mix=mix))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("sources", nargs="*")
+    ap.add_argument("--md", action="store_true", help="markdown table")
+    args = ap.parse_args()
+    rows = collect(args.sources or sorted(glob.glob(os.path.join(CSRC, "*.hip"))))
     hdr = ["file", "kernel", "wg", "VGPR", "SGPR", "LDS B (+dyn)", "scratch B", "waves/SIMD regs", "waves/SIMD LDS",
            "static insts", "f64 %", "trans %", "pk %", "dpp %", "lds %", "ld/st"]
     table = []
