@@ -8,6 +8,7 @@
 #include <time.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -131,16 +132,22 @@ hipError_t wait_event(hipEvent_t e) {
   return hipEventSynchronize(e);
 }
 
+// 1024-thread workgroups of the chained scan that are certainly resident together = compute units of the device -- as far
+// as this process can tell: the attribute does not see a CU mask (HSA_CU_MASK, ROC_GLOBAL_CU_MASK), so with one of them
+// in the environment the answer is 1 (a single chunk per array never looks back; larger jobs are refused with a
+// message).  The scan launch itself is the fallback route since round 5 (preprocess.hip: superblock totals).
 int scan_resident_workgroups() {
-  static int cus[kMaxDevices] = {};
+  static std::atomic<int> cus[kMaxDevices];
+  static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+  if (masked) return 1;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 1;
-  if (cus[dev] == 0) {
-    int n = 0;
+  int n = cus[dev].load(std::memory_order_relaxed);
+  if (n == 0) {
     if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 1;
-    cus[dev] = n;                                  // racing first calls store the same value
+    cus[dev].store(n, std::memory_order_relaxed);
   }
-  return cus[dev];
+  return n;
 }
 bool scan_split_forced() {
   static const bool b = getenv("HGS_SCAN_SPLIT") != nullptr;
@@ -288,14 +295,23 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 
 // Stage-2 launches.  L is exact when L_dev == nullptr; otherwise it is a capacity and the kernels read the
 // actual instance count from device memory.
+// super != nullptr (single-call forward only): K1 left raw workgroup sums + superblock totals, K3 finishes the scans and
+// is the kernel that produces the instance count -- into *mirror (mapped host word) or, without a mapping, by a copy
+// into `stage` -- and `ev` is recorded right behind it.
 static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
-                          const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s) {
+                          const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s,
+                          uint32_t* super = nullptr, uint32_t* mirror = nullptr, uint32_t* stage = nullptr,
+                          hipEvent_t ev = nullptr) {
   int rc;
   const bool bin = L > 0 && tile_bin_supported(T);
-  if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, bin, s)))) return rc;   // also zeroes b.ranges
+  if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, bin, s, super, mirror)))) return rc;   // also zeroes b.ranges
+  if (super) {
+    if (!mirror) HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HGS_HIP(hipEventRecord(ev, s));
+  }
   if (bin) {            // counting pass + scatter pass per tile band; writes the tile ranges too
     const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
-    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, g.block_band, nblk, T, b.ranges, b.big_tiles, b.tile_order, s, a->debug)))) return rc;
+    if ((rc = HGS_TIMED(ST_SORT, s, launch_tile_bin(b.keys_in, b.vals_in, b.vals_out, b.sort_tmp, L, g.block_band, nblk, T, b.ranges, b.big_tiles, b.tile_order, super, s, a->debug)))) return rc;
   } else {              // very large tile grids: stable radix sort by tile id, then ranges off the sorted ids
     if (L > 0) {
       if ((rc = HGS_TIMED(ST_SORT, s, sort_pairs32(b.keys_in, b.vals_in, b.keys_out, b.vals_out, b.sort_tmp, L, L_dev, tile_bits(T), s, a->debug)))) return rc;
@@ -338,7 +354,6 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   const ImgWs im = ImgWs::carve_from(img_ws, a->width, a->height);
   *L_out_host = 0;
   if (a->P == 0) return enqueue_stage2(a, g, b, im, 0, nullptr, T, out_color, out_invdepth, s);
-  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s)))) return rc;
   ThreadHost* th = thread_host(device);
   if (!th) { set_error("cannot allocate pinned host memory / event (device %d)", device); return HGS_ERR_NOMEM; }
   hipEvent_t ev = th->ev[device];
@@ -348,13 +363,30 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   static const bool by_copy = getenv("HGS_COUNT_BY_COPY") != nullptr;     // diagnostic: the copy command instead
   void* mirror = nullptr;
   if (by_copy || hipHostGetDevicePointer(&mirror, stage, 0) != hipSuccess) { (void)hipGetLastError(); mirror = nullptr; }
-  if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug, static_cast<uint32_t*>(mirror))))) return rc;
+  // No scan launch on the usual path: K1 adds its workgroup sums to zeroed superblock totals and K3 finishes the scans
+  // (preprocess.hip, binning.hip).  The scan launch remains for tile grids that take the radix path, for more than
+  // kSuper * kMaxSuper workgroups (16.7 M rows) and when no zeroed block is to be had (HGS_SCAN_LAUNCH=1 forces it).
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
+  uint32_t* super = nullptr;
+  if (L_cap > 0 && tile_bin_supported(T) && nblk <= kSuper * kMaxSuper) super = super_block_acquire(s);
+  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s, super)))) {
+    if (super) super_block_mark_dirty(super);
+    return rc;
+  }
   const uint32_t* L_dev = g.block_sums + nblk;
-  if (!mirror) HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-  hipError_t e = hipEventRecord(ev, s);
+  hipError_t e = hipSuccess;
+  if (!super) {
+    if ((rc = HGS_TIMED(ST_SCAN, s, launch_scan_block_sums(g, a->P, s, a->debug, static_cast<uint32_t*>(mirror))))) return rc;
+    if (!mirror) HGS_HIP(hipMemcpyAsync(stage, L_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    e = hipEventRecord(ev, s);
+  }
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
-  if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s);
+  if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s, super,
+                                           static_cast<uint32_t*>(mirror), stage, ev);
+  if (super && rc) {           // the totals may not have been consumed and cleared: zero them before the next use
+    super_block_mark_dirty(super);
+    return rc;
+  }
   if (e == hipSuccess) e = wait_event(ev);
   if (e != hipSuccess) { set_error("hgs_raster_fwd: %s", hipGetErrorString(e)); return HGS_ERR_HIP; }
   *L_out_host = *stage;

@@ -118,12 +118,21 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // needs no ballots and no barriers.  The key is the BAND-LOCAL tile id.  The tile-binning kernels then run band x's
 // workgroups on XCD x, the XCD that later composites those tiles: every list is assembled in one L2.  Deterministic:
 // no atomics, the order inside a stream is (workgroup, emission order).
+// `super` (K1's superblock totals, preprocess.hip): g.block_sums / g.block_band hold the RAW workgroup sums and this
+// workgroup builds its nine exclusive prefixes and the nine grand totals itself; the last workgroup stores the totals
+// (entry nblk of each array) and the instance count into `total_mirror` (mapped host word, may be null).
+// `zero_words`: n_zero words cleared for the counting kernels that follow (their arrival counters and tile totals).
 __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P, int gx, int T, int per, GeomWs g,
                                                                            uint32_t cap,
                                                                            uint32_t* __restrict__ tile_keys,
                                                                            uint32_t* __restrict__ vals,
-                                                                           uint32_t* __restrict__ ranges, int n_ranges) {
+                                                                           uint32_t* __restrict__ ranges, int n_ranges,
+                                                                           const uint32_t* __restrict__ super,
+                                                                           uint32_t* __restrict__ total_mirror,
+                                                                           uint32_t* __restrict__ zero_words, int n_zero) {
   for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
+  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_zero; r += gridDim.x * kPreBlock) zero_words[r] = 0u;
+  __shared__ uint32_t pre9[1 + kBands], tot9[1 + kBands];
   __shared__ uint32_t excl[kPreBlock + 1];
   __shared__ uint2 lrect[kPreBlock];
   __shared__ uint32_t wave_tot[kPreBlock / 64][kBands + 1];   // [.][kBands]: all bands
@@ -135,12 +144,36 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
   const uint32_t gid = (uint32_t)i;
   // every global load of the prologue is issued here, together: the kernel is latency-bound (3 900 small workgroups)
   const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
-  const uint32_t block_base = g.block_sums[blockIdx.x];
   const int col = gridDim.x + 1;                          // column stride of g.block_band
+  uint32_t block_base = 0;
   uint32_t band_tot = 0, band_off = 0;                    // lanes 0..7 of wave 0: total of band `tid`, this workgroup's offset in it
-  if (tid < kBands) {
-    band_tot = g.block_band[(size_t)tid * col + gridDim.x];
-    band_off = g.block_band[(size_t)tid * col + blockIdx.x];
+  if (!super) {
+    block_base = g.block_sums[blockIdx.x];
+    if (tid < kBands) {
+      band_tot = g.block_band[(size_t)tid * col + gridDim.x];
+      band_off = g.block_band[(size_t)tid * col + blockIdx.x];
+    }
+  } else {
+    // wave w: arrays w, w + 4, w + 8 (0 = all instances, 1 + b = band b).  prefix = superblock totals before this
+    // workgroup's superblock + raw sums of the workgroups before it inside the superblock; total = all superblocks
+    const int sb = (int)blockIdx.x / kSuper, nsb = ((int)gridDim.x + kSuper - 1) / kSuper;
+    for (int a = wave; a < 1 + kBands; a += kPreBlock / 64) {
+      const uint32_t* raw = a == 0 ? g.block_sums : g.block_band + (size_t)(a - 1) * col;
+      const int j = sb * kSuper + lane;
+      uint32_t pre = (j < (int)blockIdx.x) ? raw[j] : 0u;
+      uint32_t tot = 0;
+      for (int s0 = 0; s0 < nsb; s0 += 64) {
+        const uint32_t x = (s0 + lane < nsb) ? super[a * kMaxSuper + s0 + lane] : 0u;
+        tot += x;
+        pre += (s0 + lane < sb) ? x : 0u;
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        pre += __shfl_xor(pre, off, 64);
+        tot += __shfl_xor(tot, off, 64);
+      }
+      if (lane == 0) { pre9[a] = pre; tot9[a] = tot; }
+    }
   }
   const uint32_t cnt = rect_count(myrect);
   lrect[tid] = myrect;
@@ -184,6 +217,16 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
     wave_tot[wave][kBands] = inc;
 #pragma unroll
     for (int b = 0; b < kBands; ++b) wave_tot[wave][b] = incb[b];
+  }
+  if (super) {
+    __syncthreads();                                      // pre9 / tot9 of all four waves
+    block_base = pre9[0];
+    if (tid < kBands) { band_tot = tot9[1 + tid]; band_off = pre9[1 + tid]; }
+    if (blockIdx.x == gridDim.x - 1 && tid <= kBands) {   // the totals, where the scan launch used to leave them
+      uint32_t* arr = tid == 0 ? g.block_sums : g.block_band + (size_t)(tid - 1) * col;
+      arr[gridDim.x] = tot9[tid];
+      if (tid == 0 && total_mirror) *total_mirror = tot9[0];
+    }
   }
   if (wave == 0) {                                        // band base = the totals of the bands before it
     const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
@@ -429,17 +472,101 @@ __device__ __forceinline__ void coop_sort_tile(uint64_t* lk, const float* __rest
   }
 }
 
-// One wave per tile (4 tiles per workgroup) up to kWaveCap instances.  QUAD: a tile with up to kQuadCap is then sorted
-// by the workgroup's four waves together (32 KiB of LDS: chosen by the host when the frame's mean list length says such
-// tiles are common; it costs the one-wave path a fifth of its occupancy).  Larger tiles are filed into the class lists:
-// big[0] / big[1] / big[2] = number of large / huge / medium tiles; big + 3: large list [T], huge list [T], medium list
-// [T] (medium = kWaveCap < n <= kSmallCap, only without QUAD).
-constexpr uint32_t kSmallCap = 2048;
+// Size-unbounded fallback: the NW waves of a workgroup run a stable LSD radix sort (4 x 8 bits of the id, then 4 x 8 bits
+// of the depth key, id as payload) through the tile's own slice of two global scratch arrays.  Slow (one workgroup per
+// such tile) but it needs 2 KB + NW KB of LDS whatever the tile holds.  Used by the 1024-lane kernel for tiles above
+// kLargeCap (NW = 16) and by the one-wave-per-tile kernel for the rare crowded tile of a light frame (NW = 4, below).
+template <int NW>
+struct RadixLds {
+  uint32_t hist[256];
+  uint32_t base[256];
+  uint32_t wave_cnt[NW][256];
+};
+template <int NW>
+__device__ __forceinline__ void radix_sort_tile(RadixLds<NW>& l, uint32_t r0, uint32_t n,
+                                                const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                                uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
+                                                uint32_t* __restrict__ scratch_k2) {
+  constexpr uint32_t NT = NW * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __syncthreads();
+  uint32_t* kA = scratch_k + r0;    // keys ping
+  uint32_t* kB = scratch_k2 + r0;   // keys pong
+  uint32_t* vA = vals + r0;         // values ping (final result lands here: 8 passes = even)
+  uint32_t* vB = scratch_v + r0;    // values pong
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // 8 stable passes: first by id (the tile binning does not order a tile's entries), then by depth bits
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = (pass & 3) * 8;
+    if (pass == 0) {
+      for (uint32_t i = tid; i < n; i += NT) kA[i] = vA[i];
+      __syncthreads();
+    } else if (pass == 4) {     // 4 passes done: the data is back in vA / kA
+      for (uint32_t i = tid; i < n; i += NT) kA[i] = __float_as_uint(depths[vA[i]]);
+      __syncthreads();
+    }
+    if (tid < 256) l.hist[tid] = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += NT) atomicAdd(&l.hist[(kA[i] >> shift) & 255u], 1u);
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t acc = 0;
+      for (int d = 0; d < 256; ++d) { l.base[d] = acc; acc += l.hist[d]; }
+    }
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < n; c0 += NT) {
+      const uint32_t i = c0 + tid;
+      const bool valid = i < n;
+      const uint32_t key = valid ? kA[i] : 0u;
+      const uint32_t val = valid ? vA[i] : 0u;
+      const uint32_t d = (key >> shift) & 255u;
+      uint64_t same = __ballot(valid);
+      if (!valid) same = 0;
+#pragma unroll
+      for (int bit = 0; bit < 8; ++bit) {
+        const uint64_t bal = __ballot((d >> bit) & 1u);
+        same &= ((d >> bit) & 1u) ? bal : ~bal;
+      }
+      for (int t = tid; t < NW * 256; t += NT) (&l.wave_cnt[0][0])[t] = 0;
+      __syncthreads();
+      if (valid && (same & lt_mask) == 0) l.wave_cnt[wave][d] = (uint32_t)__popcll(same);
+      __syncthreads();
+      uint32_t before = 0;                       // same digit in earlier waves of this chunk
+      if (valid) for (int w = 0; w < wave; ++w) before += l.wave_cnt[w][d];
+      const uint32_t pos = valid ? l.base[d] + before + (uint32_t)__popcll(same & lt_mask) : 0u;
+      __syncthreads();
+      if (tid < 256) {                           // advance the digit bases by this chunk's counts
+        uint32_t add = 0;
+        for (int w = 0; w < NW; ++w) add += l.wave_cnt[w][tid];
+        l.base[tid] += add;
+      }
+      if (valid) { kB[pos] = key; vB[pos] = val; }
+      __syncthreads();
+    }
+    uint32_t* t;
+    t = kA; kA = kB; kB = t;
+    t = vA; vA = vB; vB = t;
+    __syncthreads();
+  }
+}
+
+// One wave per tile (4 tiles per workgroup) up to kWaveCap instances.
+// QUAD (chosen by the host when the frame's mean list length says long lists are common; its 32 KiB of LDS cost the
+// one-wave path a fifth of its occupancy): a tile with up to kQuadCap is then sorted by the workgroup's four waves
+// together, larger tiles are filed into the class lists for the oversized-classes launches that follow:
+// big[0] / big[1] = number of large / huge tiles; big + 3: large list [T], huge list [T].
+// !QUAD (light frames): a crowded tile (n > kWaveCap) is rare; the workgroup that meets one sorts it itself with the
+// radix fallback once its waves are done with their own tiles -- the lists stay empty and NO further launch follows
+// (rounds 1-4 launched the 1024-lane kernel with 146 KB of LDS per workgroup behind every frame to find its lists empty:
+// 5 us and a kernel boundary).
 template <bool QUAD>
 __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
                                                                    uint32_t* __restrict__ vals, uint32_t* big, int T,
-                                                                   uint32_t* __restrict__ tile_ids) {
+                                                                   uint32_t* __restrict__ tile_ids,
+                                                                   uint32_t* __restrict__ scratch_k,
+                                                                   uint32_t* __restrict__ scratch_v,
+                                                                   uint32_t* __restrict__ scratch_k2) {
   __shared__ uint64_t lk[QUAD ? kQuadCap : 1];
   __shared__ uint32_t quad_n[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -452,11 +579,15 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_
   if (tile_ids)          // sorted tile-id column (introspection / parity tests) when no global sort produced it
     for (uint32_t i = (uint32_t)lane; i < n; i += 64u) tile_ids[r0 + i] = (uint32_t)tile;
   if (lane == 0) {
-    if (QUAD) quad_n[wave] = (n > kWaveCap && n <= kQuadCap) ? n : 0u;
-    if (n > (QUAD ? kQuadCap : kWaveCap)) {
-      const int cls = n > kLargeCap ? 1 : ((QUAD || n > kSmallCap) ? 0 : 2);
-      const uint32_t slot = atomicAdd(&big[cls], 1u);
-      big[3 + cls * T + slot] = (uint32_t)tile;
+    if (QUAD) {
+      quad_n[wave] = (n > kWaveCap && n <= kQuadCap) ? n : 0u;
+      if (n > kQuadCap) {
+        const int cls = n > kLargeCap ? 1 : 0;
+        const uint32_t slot = atomicAdd(&big[cls], 1u);
+        big[3 + cls * T + slot] = (uint32_t)tile;
+      }
+    } else {
+      quad_n[wave] = n > kWaveCap ? n : 0u;
     }
   }
   if (n > 1 && n <= kWaveCap) {
@@ -494,24 +625,19 @@ __global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_
       coop_sort_tile<4>(lk, depths, vals, ranges[(blockIdx.x * 4 + w) * 2 + 0], quad_n[w], wave);
       __syncthreads();
     }
-  }
-}
-
-// Medium class without QUAD (kWaveCap < n <= kSmallCap) and the large class (.. kLargeCap): one workgroup of 64 GROUP
-// lanes per listed tile, the register-block sort above.  Large tiles outside (lo, hi] are left to the other launch.
-template <int GROUP>
-__device__ __forceinline__ void sort_medium_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
-                                                  const float* __restrict__ depths, uint32_t* __restrict__ vals,
-                                                  const uint32_t* __restrict__ big, int T) {
-  const uint32_t count = big[2];
-  for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-    const uint32_t tile = big[3 + 2 * T + e];
-    const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+  } else {
+    __shared__ RadixLds<4> rl;
     __syncthreads();
-    coop_sort_tile<GROUP>(reinterpret_cast<uint64_t*>(smem), depths, vals, r0, r1 - r0, (int)(threadIdx.x >> 6));
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t cn = quad_n[w];                      // (uniform)
+      if (cn) radix_sort_tile<4>(rl, ranges[(blockIdx.x * 4 + w) * 2 + 0], cn, depths, vals, scratch_k, scratch_v, scratch_k2);
+    }
   }
 }
 
+// The large class (kQuadCap < n <= kLargeCap, filed by the QUAD kernel): one workgroup of 64 GROUP lanes per listed tile,
+// the register-block sort above.  Large tiles outside (lo, hi] are left to the other launch.
 template <int GROUP>
 __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint32_t* __restrict__ ranges,
                                                  const float* __restrict__ depths, uint32_t* __restrict__ vals,
@@ -526,83 +652,18 @@ __device__ __forceinline__ void sort_large_tiles(unsigned char* smem, const uint
   }
 }
 
-// Fallback for tiles above kLargeCap instances: one 1024-thread workgroup runs a stable LSD radix
-// sort (4 x 8 bits of the id, then 4 x 8 bits of the depth key, id as payload) through the tile's own
-// slice of two global scratch arrays.  Slow (one CU per such tile) but size-unbounded.
 __device__ __forceinline__ void sort_huge_tiles(const uint32_t* __restrict__ ranges,
                                                 const float* __restrict__ depths, uint32_t* __restrict__ vals,
                                                 uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
                                                 uint32_t* __restrict__ scratch_k2,
                                                 const uint32_t* __restrict__ big, int T) {
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t base[256];
-  __shared__ uint32_t wave_cnt[16][256];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ RadixLds<16> l;
   const uint32_t count = big[1];
   for (uint32_t e = blockIdx.x; e < count; e += gridDim.x) {
-  const uint32_t tile = big[3 + T + e];
-  const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
-  const uint32_t n = r1 - r0;
-  __syncthreads();
-  uint32_t* kA = scratch_k + r0;    // keys ping
-  uint32_t* kB = scratch_k2 + r0;   // keys pong
-  uint32_t* vA = vals + r0;         // values ping (final result lands here: 8 passes = even)
-  uint32_t* vB = scratch_v + r0;    // values pong
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  // 8 stable passes: first by id (the tile binning does not order a tile's entries), then by depth bits
-  for (int pass = 0; pass < 8; ++pass) {
-    const int shift = (pass & 3) * 8;
-    if (pass == 0) {
-      for (uint32_t i = tid; i < n; i += 1024) kA[i] = vA[i];
-      __syncthreads();
-    } else if (pass == 4) {     // 4 passes done: the data is back in vA / kA
-      for (uint32_t i = tid; i < n; i += 1024) kA[i] = __float_as_uint(depths[vA[i]]);
-      __syncthreads();
-    }
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (uint32_t i = tid; i < n; i += 1024) atomicAdd(&hist[(kA[i] >> shift) & 255u], 1u);
-    __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (int d = 0; d < 256; ++d) { base[d] = acc; acc += hist[d]; }
-    }
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < n; c0 += 1024) {
-      const uint32_t i = c0 + tid;
-      const bool valid = i < n;
-      const uint32_t key = valid ? kA[i] : 0u;
-      const uint32_t val = valid ? vA[i] : 0u;
-      const uint32_t d = (key >> shift) & 255u;
-      uint64_t same = __ballot(valid);
-      if (!valid) same = 0;
-#pragma unroll
-      for (int bit = 0; bit < 8; ++bit) {
-        const uint64_t bal = __ballot((d >> bit) & 1u);
-        same &= ((d >> bit) & 1u) ? bal : ~bal;
-      }
-      for (int t = tid; t < 16 * 256; t += 1024) (&wave_cnt[0][0])[t] = 0;
-      __syncthreads();
-      if (valid && (same & lt_mask) == 0) wave_cnt[wave][d] = (uint32_t)__popcll(same);
-      __syncthreads();
-      uint32_t before = 0;                       // same digit in earlier waves of this chunk
-      if (valid) for (int w = 0; w < wave; ++w) before += wave_cnt[w][d];
-      const uint32_t pos = valid ? base[d] + before + (uint32_t)__popcll(same & lt_mask) : 0u;
-      __syncthreads();
-      if (tid < 256) {                           // advance the digit bases by this chunk's counts
-        uint32_t add = 0;
-        for (int w = 0; w < 16; ++w) add += wave_cnt[w][tid];
-        base[tid] += add;
-      }
-      if (valid) { kB[pos] = key; vB[pos] = val; }
-      __syncthreads();
-    }
-    uint32_t* t;
-    t = kA; kA = kB; kB = t;
-    t = vA; vA = vB; vB = t;
-    __syncthreads();
+    const uint32_t tile = big[3 + T + e];
+    const uint32_t r0 = ranges[tile * 2 + 0], r1 = ranges[tile * 2 + 1];
+    radix_sort_tile<16>(l, r0, r1 - r0, depths, vals, scratch_k, scratch_v, scratch_k2);
   }
-  }   // tile loop
 }
 
 // The oversized classes.  A light frame (their lists are almost always empty: a launch each would cost more than the
@@ -617,8 +678,6 @@ __global__ __launch_bounds__(512) void tile_depth_sort_mid_kernel(const uint32_t
                                                                   uint32_t* __restrict__ vals,
                                                                   const uint32_t* __restrict__ big, int T) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  sort_medium_tiles<8>(smem, ranges, depths, vals, big, T);
-  __syncthreads();
   sort_large_tiles<8>(smem, ranges, depths, vals, big, T, 0u, kMidCap);
 }
 
@@ -629,12 +688,8 @@ __global__ __launch_bounds__(1024) void tile_depth_sort_big_kernel(const uint32_
                                                                    uint32_t* __restrict__ scratch_v,
                                                                    uint32_t* __restrict__ scratch_k2,
                                                                    const uint32_t* __restrict__ big, int T,
-                                                                   uint32_t large_lo) {     // 0: also the medium class
+                                                                   uint32_t large_lo) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  if (large_lo == 0u) {
-    sort_medium_tiles<16>(smem, ranges, depths, vals, big, T);
-    __syncthreads();
-  }
   sort_large_tiles<16>(smem, ranges, depths, vals, big, T, large_lo, kLargeCap);
   __syncthreads();
   sort_huge_tiles(ranges, depths, vals, scratch_k, scratch_v, scratch_k2, big, T);
@@ -663,13 +718,15 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 }  // namespace
 
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
-                           hipStream_t s) {
+                           hipStream_t s, const uint32_t* super, uint32_t* total_mirror) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
+  if (super && !(banded && nblk > 0 && L_cap > 0)) { set_error("duplicate_tiles: superblock totals without the banded path"); return HGS_ERR_INVALID; }
   if (nblk > 0 && L_cap > 0) {
     const int T = grid_x(a.width) * grid_y(a.height);
     if (banded)
       hipLaunchKernelGGL(duplicate_tiles_banded_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), T,
-                         band_tiles(T), g, L_cap, b.keys_in, b.vals_in, b.ranges, T * 2);
+                         band_tiles(T), g, L_cap, b.keys_in, b.vals_in, b.ranges, T * 2, super, total_mirror,
+                         tile_bin_zero_words(b.sort_tmp, L_cap, T), tile_bin_zero_count(T));
     else
       hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
                          b.keys_in, b.vals_in, b.ranges, T * 2);
@@ -701,12 +758,15 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kMidCap * 8)));
     attr_set = true;
   }
-  // lists of more than 1024 instances are common when the mean list is long: then the four-wave variant
+  // lists of more than 1024 instances are common when the mean list is long: then the four-wave variant, and the launches
+  // for the classes it files.  A light frame's rare crowded tile is sorted inside the one-wave kernel: one launch.
+  // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   const bool quad = (uint64_t)L > (uint64_t)T * 512u;
   auto kern = quad ? tile_depth_sort_wave_kernel<true> : tile_depth_sort_wave_kernel<false>;
   hipLaunchKernelGGL(kern, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out, b.big_tiles, T,
-                     fill_tile_ids ? b.keys_out : nullptr);
+                     fill_tile_ids ? b.keys_out : nullptr, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp));
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
+  if (!quad) return HGS_OK;
   const int big_grid = T < 256 ? T : 256;
   const bool heavy = (uint64_t)L > (uint64_t)T * 1024u;
   if (heavy) {
@@ -714,7 +774,6 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
                        b.vals_out, b.big_tiles, T);
     HGS_LAUNCH_CHECK("tile_depth_sort_mid", s, a.debug);
   }
-  // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   hipLaunchKernelGGL(tile_depth_sort_big_kernel, dim3(big_grid), dim3(1024), kLargeCap * 8, s, b.ranges, g.depths,
                      b.vals_out, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp), b.big_tiles, T,
                      heavy ? kMidCap : 0u);

@@ -188,12 +188,28 @@ int scan_resident_workgroups();
 bool scan_split_forced();
 
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
-int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s);
+// super (optional): zeroed superblock totals (super_block_acquire): K1 adds its workgroup sums to them, g.block_sums /
+// g.block_band keep the RAW sums, no scan launch follows and K3 builds its prefixes itself (preprocess.hip, binning.hip)
+int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s,
+                          uint32_t* super = nullptr);
+// Superblocks of K1's workgroup sums: kSuper consecutive workgroups; the library-owned block holds (1 + kBands) rows of
+// kMaxSuper totals per (device, stream).  acquire: nullptr = take the scan launch (more than kMaxSuper superblocks is
+// the caller's check).  mark_dirty: an error return left totals behind, zero them before the next use.
+constexpr int kSuper = 64;
+constexpr int kMaxSuper = 1024;
+uint32_t* super_block_acquire(hipStream_t s);
+size_t super_block_bytes();
+void super_block_mark_dirty(const uint32_t* words);
 // scans block_sums and the kBands columns of block_band (one launch while the grid is resident at once, else one per array)
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror = nullptr);
 // banded: one instance stream per tile band (b.keys_in = band-local tile ids), else one stream of global tile ids
+// super: K1's superblock totals (g holds raw workgroup sums, see launch_preprocess_fwd), banded only; the kernel's last
+// workgroup then stores the totals and, into *total_mirror (optional, device-visible), the instance count
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
-                           hipStream_t s);
+                           hipStream_t s, const uint32_t* super = nullptr, uint32_t* total_mirror = nullptr);
+// the words of the tile-binning scratch that the banded K3 clears for the counting kernels (tile_bin.hip)
+uint32_t* tile_bin_zero_words(void* tmp, uint32_t L_cap, int32_t T);
+int tile_bin_zero_count(int32_t T);
 int launch_tile_ranges(const BinWs& b, uint32_t L_cap, const uint32_t* L_dev, int32_t T, hipStream_t s, bool debug);
 // b.tile_order from the final b.ranges (one small workgroup; counting sort over quantised instance counts)
 int launch_tile_order(const BinWs& b, int32_t T, hipStream_t s, bool debug);
@@ -251,7 +267,7 @@ size_t tile_bin_tmp_bytes(uint32_t L, int32_t T);
 // row nblk)
 int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
                     const uint32_t* band_totals, int32_t nblk, int32_t T, uint32_t* ranges, uint32_t* big,
-                    uint32_t* tile_order, hipStream_t s, bool debug);
+                    uint32_t* tile_order, uint32_t* super, hipStream_t s, bool debug);
 size_t sort_tmp_bytes(uint32_t n);
 int sort_pairs(const uint64_t* keys_in, const uint32_t* vals_in, uint64_t* keys_out, uint32_t* vals_out,
                void* tmp, uint32_t n, int end_bit, hipStream_t s, bool debug);

@@ -6,6 +6,10 @@
 // at SH degree 3 (fwd), 236 B in + 248 B out (bwd).
 #include "gaussian_math.h"
 
+#include <stdlib.h>
+
+#include <mutex>
+
 namespace hgs {
 
 namespace {
@@ -264,18 +268,226 @@ __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, f
     if (i < n) sh[i] = lod_lerp(x[i], y[i], l.w, l.u);
 }
 
-template <bool JAC, bool LOD, bool DEFER>   // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
+
+// ---- M = 16, plain [P, 16, 3] layout: the coefficient block in two HALVES, straight into LDS ------------------------
+// K1 at M = 16 used to stage the workgroup's whole block (256 rows x 52 floats = 53 KB) through LDS and to hold its
+// twelve 16-byte loads per lane in registers across the double-precision chain: 53 KB and 144 registers both capped the
+// kernel at 3 waves per SIMD, and it is bound by latency, not by its arithmetic or by HBM.  Here a row travels as two
+// halves of 8 coefficients (96 bytes): `global_load_lds_dwordx4` writes them into LDS without passing through registers
+// (nothing to hold across the chain), the image of a half is 24 KB per workgroup (five workgroups per compute unit),
+// half 1 is fetched while half 0 is being evaluated (its cache lines are the ones half 0 just brought in), and with an
+// active degree below 2 it is not fetched at all.
+//   LDS image of one half: row r = 6 chunks of 16 bytes at r * 96, UNPADDED (the DMA's destination is the wave's base +
+//   16 * lane: no room for pad).  A ds_read_b128 of the same chunk by 16 consecutive-ish rows would hit every bank group
+//   twice (96 r mod 256 takes 8 values); row r therefore keeps chunk c in slot (c + f(r)) mod 6, f(r) = bit 3 of r --
+//   the rows of one lane group then cover all 16 bank groups.  The swizzle is applied on the SOURCE address of the DMA
+//   and on the read, never on the destination (cdna_hip_programming.md rule 21).
+constexpr int kHalfChunks = 6;                       // 16-byte chunks per half row (8 coefficients x 3 channels)
+constexpr int kHalfBytes = kPreBlock * kHalfChunks * 16;
+typedef const void __attribute__((address_space(1))) * gptr_t;
+typedef void __attribute__((address_space(3))) * lptr_t;
+
+template <int HALF>
+__device__ __forceinline__ void sh48_issue_half(const float* __restrict__ shs, int block_first, int P, float* lds) {
+  const int count = min(kPreBlock, P - block_first);
+  const char* src = reinterpret_cast<const char*>(shs + (size_t)block_first * 48) + HALF * 96;
+  const int wave_base = (int)(threadIdx.x & ~63u);
+#pragma unroll
+  for (int k = 0; k < kHalfChunks; ++k) {
+    const int slot = k * kPreBlock + (int)threadIdx.x;          // linear 16-byte slot of the LDS image
+    const int row = slot / kHalfChunks, cs = slot - row * kHalfChunks;
+    int c = cs - ((row >> 3) & 1);                               // the logical chunk this slot keeps
+    c = c < 0 ? c + kHalfChunks : c;
+    char* dst = reinterpret_cast<char*>(lds) + (size_t)(k * kPreBlock + wave_base) * 16;   // wave-uniform
+    if (row < count)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * 192 + c * 16), (lptr_t)dst, 16, 0, 0);
+  }
+}
+// this lane's half row, logical chunks [C0, C0 + 3): 12 floats = 4 coefficients
+template <int C0>
+__device__ __forceinline__ void sh48_read_quarter(const float* lds, float v[12]) {
+  const int row = threadIdx.x, f = (row >> 3) & 1;
+  const float* base = lds + row * 24 + f * 4;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float4 t = (C0 + c < 5) ? *reinterpret_cast<const float4*>(base + (C0 + c) * 4)
+                                  : *reinterpret_cast<const float4*>(lds + row * 24 + (f ? 0 : 20));
+    v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+  }
+}
+
+// rgb and (JAC) d(rgb)/d(direction) sums over the four coefficients [K0, K0 + 4); same order of additions as the
+// one-block loop (k ascending), so the two routes give the same bits
+template <bool JAC, int K0>
+__device__ __forceinline__ void sh48_accumulate4(int deg, float dx, float dy, float dz, const float sh[12], float rgb[3],
+                                                 float J[9]) {
+  const int nb = (deg + 1) * (deg + 1);
+  float b[16];
+  sh_basis(deg, dx, dy, dz, b);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (K0 + k < nb) {
+      rgb[0] += b[K0 + k] * sh[k * 3 + 0];
+      rgb[1] += b[K0 + k] * sh[k * 3 + 1];
+      rgb[2] += b[K0 + k] * sh[k * 3 + 2];
+    }
+  }
+  if constexpr (JAC) {
+    float dbx[16], dby[16], dbz[16];
+    sh_basis_grad(deg, dx, dy, dz, dbx, dby, dbz);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (K0 + k < nb) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          J[0 + c] += dbx[K0 + k] * sh[k * 3 + c];
+          J[3 + c] += dby[K0 + k] * sh[k * 3 + c];
+          J[6 + c] += dbz[K0 + k] * sh[k * 3 + c];
+        }
+      }
+    }
+  }
+}
+// one half (coefficients [8 HALF, 8 HALF + 8)) of this lane's row out of the LDS image, in two pieces of four
+template <bool JAC, int HALF>
+__device__ __forceinline__ void sh48_half_from_lds(const float* lds, bool vis, int deg, float dx, float dy, float dz,
+                                                   float rgb[3], float J[9]) {
+  float sh[12];
+  sh48_read_quarter<0>(lds, sh);
+  if (vis) sh48_accumulate4<JAC, HALF * 8>(deg, dx, dy, dz, sh, rgb, J);
+  sh48_read_quarter<3>(lds, sh);
+  if (vis) sh48_accumulate4<JAC, HALF * 8 + 4>(deg, dx, dy, dz, sh, rgb, J);
+}
+// the same from global memory (mostly-culled workgroups: visible lanes only), 48 bytes at a time
+template <bool JAC>
+__device__ __forceinline__ void sh48_row_from_global(const float* __restrict__ shs, int idx, int deg, float dx, float dy,
+                                                     float dz, float rgb[3], float J[9]) {
+  const float4* src = reinterpret_cast<const float4*>(shs + (size_t)idx * 48);
+  const int nb = (deg + 1) * (deg + 1);
+  float sh[12];
+#define HGS_SH48_Q(Q)                                                                         \
+  if (Q * 4 < nb) {                                                                           \
+    _Pragma("unroll") for (int c = 0; c < 3; ++c) {                                           \
+      const float4 t = src[Q * 3 + c];                                                        \
+      sh[c * 4 + 0] = t.x; sh[c * 4 + 1] = t.y; sh[c * 4 + 2] = t.z; sh[c * 4 + 3] = t.w;     \
+    }                                                                                         \
+    sh48_accumulate4<JAC, Q * 4>(deg, dx, dy, dz, sh, rgb, J);                                \
+  }
+  HGS_SH48_Q(0) HGS_SH48_Q(1) HGS_SH48_Q(2) HGS_SH48_Q(3)
+#undef HGS_SH48_Q
+}
+
+// ---- the per-workgroup sums of K1 and their scan -----------------------------------------------------------------------
+// Every workgroup of K1 leaves nine sums (its instances, and its instances per tile band); K3 needs their exclusive scans
+// over the workgroups.  Rounds 1-4 ran a scan launch between K1 and K3 (6.6 us + a kernel boundary for 140 KB).  With
+// `super` given, that launch is gone: K1 also ADDS its sums (fire-and-forget atomics, nobody waits for an answer) to the
+// totals of its SUPERBLOCK of kSuper consecutive workgroups, and workgroup b of K3 puts its nine prefixes together
+// itself -- the superblock totals before b's superblock plus the raw sums of the workgroups before b inside it: two
+// 64-lane loads and two wave reductions per array (binning.hip).  Integer adds commute, the consumer runs behind a
+// kernel boundary: no hand-off inside a launch, no assumption about dispatch order, residency or placement.
+// The superblock totals must be ZERO when K1 starts; they live in a block owned by the library per (device, stream),
+// zeroed when it is created and zeroed again by the counting kernel that follows K3 (tile_bin.hip) -- a workspace carved
+// from the caller's memory is fresh on every call and would need a memset launch in front of K1, the launch this is
+// there to save.
+// instances per tile band of one rectangle, added to the workgroup's LDS counters.  Almost every rectangle lies inside ONE
+// band (first and last tile in the same band: seven compares each, no division); one that straddles boundaries counts
+// (# of its tiles with id < x) at the boundaries x = b * per it spans, in closed form.
+__device__ __forceinline__ void k1_band_count(const Proj& pr, uint32_t touched, int gx, int gy, uint32_t* band_cnt) {
+  const int T = gx * gy, per = band_tiles(T), w = pr.maxx - pr.minx;
+  const int t_first = pr.miny * gx + pr.minx, t_last = (pr.maxy - 1) * gx + pr.maxx - 1;
+  int b_first = 0, b_last = 0;
+#pragma unroll
+  for (int b = 1; b < kBands; ++b) {
+    b_first += (t_first >= b * per) ? 1 : 0;
+    b_last += (t_last >= b * per) ? 1 : 0;
+  }
+  if (b_first == b_last) {
+    atomicAdd(&band_cnt[b_first], touched);
+  } else {
+    int prev = 0;
+    for (int b = b_first; b <= b_last; ++b) {
+      const int x = min((b + 1) * per, T);
+      const int xr = x / gx, xc = x - xr * gx;
+      int cnt = (min(max(xr, pr.miny), pr.maxy) - pr.miny) * w;
+      if (xr >= pr.miny && xr < pr.maxy) cnt += min(max(xc - pr.minx, 0), w);
+      if (cnt > prev) atomicAdd(&band_cnt[b], (uint32_t)(cnt - prev));
+      prev = cnt;
+    }
+  }
+}
+
+// The continuous quantities of a visible Gaussian's 2D record (double-precision chain, gaussian_math.h).
+struct K1Rec {
+  float opac, thr, ext_x, ext_y, invz;
+  float gx_hi, gy_hi, gx_lo, gy_lo, A2, B2, C2;
+};
+__device__ __forceinline__ void k1_continuous(const hgs_raster_args& a, const CamLds& cam, const Proj& pr,
+                                              const float p[3], const float sc_act[3], const float q_act[4],
+                                              float opac, K1Rec& o) {
+  o.opac = opac;
+  ProjD pd;
+  if (a.cov3D_precomp) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
+  } else {
+    cov3d_from_scale_rot_d(sc_act, a.scale_modifier, q_act, pd);
+  }
+  project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
+  // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
+  o.gx_hi = (float)pd.px; o.gy_hi = (float)pd.py;
+  o.gx_lo = (float)(pd.px - (double)o.gx_hi); o.gy_lo = (float)(pd.py - (double)o.gy_hi);
+  // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
+  const double kLog2e = 1.4426950408889634;
+  o.A2 = (float)(-0.5 * kLog2e * pd.conA);
+  o.B2 = (float)(-kLog2e * pd.conB);
+  o.C2 = (float)(-0.5 * kLog2e * pd.conC);
+  // The compositing kernels clamp the exponent at 0 instead of testing its sign ("power > 0 -> skip" never fires
+  // for a positive definite conic).  Rounding the three coefficients to float32 must therefore not make an extremely
+  // elongated conic indefinite (relative determinant below ~1e-7: sigma of thousands of pixels): if it does, the
+  // mixed term is pulled back inside by one part in a million.
+  {
+    const double lim = 4.0 * (double)o.A2 * (double)o.C2;
+    if (!((double)o.B2 * (double)o.B2 < lim)) o.B2 = (float)copysign(sqrt(fmax(lim, 0.0)) * (1.0 - 1.0e-6), (double)o.B2);
+  }
+  // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
+  // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
+  // never a candidate, exactly like the exact test)
+  o.thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
+  // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
+  //   d^T conic d <= T2 = 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T2 Sigma'_xx), |dy| <= sqrt(T2 Sigma'_yy)
+  // (the extent of an ellipse along an axis is set by the COVARIANCE's diagonal: no determinant, no cancellation, so
+  // float32 is enough).  T2 = -2 ln 2 * thr: the same logarithm as the skip threshold.  The compositing kernels
+  // use the box to decide, once per (tile, Gaussian), which quadrants can be touched at all; it is inflated (the 1e-3
+  // guard in the base-2 exponent, 1e-4 relative, 5e-3 px) so that it contains every pixel the exact alpha test could
+  // accept.  -1: no pixel ever (o <= ~1/255).
+  o.ext_x = -1.0f; o.ext_y = -1.0f;
+  {
+    const float T2 = -1.3862943611198906f * o.thr;
+    const float sxx = (float)pd.a, syy = (float)pd.c;
+    if (T2 > 0.0f) {
+      const bool sane = sxx < 3.0e38f && syy < 3.0e38f;      // (NaN / inf covariance: never skip on the box)
+      o.ext_x = sane ? sqrtf(T2 * sxx) * 1.0001f + 5.0e-3f : 1.0e9f;
+      o.ext_y = sane ? sqrtf(T2 * syy) * 1.0001f + 5.0e-3f : 1.0e9f;
+    }
+  }
+  o.invz = (float)pd.itz;
+}
+
+template <bool JAC, bool LOD, bool DEFER, bool H48>
+                                // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
                                 // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
                                 // ahead of the double-precision chain (their own instantiations: the extra state
-                                // would cost every other caller of K1 its occupancy)
-__global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
-                                                                   int32_t* __restrict__ radii) {
+                                // would cost every other caller of K1 its occupancy); H48: plain [P, 16, 3] block in
+                                // two halves straight into LDS (above; DEFER and LOD do not apply)
+__device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, const GeomWs& g,
+                                                    int32_t* __restrict__ radii, uint32_t* __restrict__ super) {
+  static_assert(!(H48 && (LOD || DEFER)), "the half-row route is the plain layout's");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds_sh = reinterpret_cast<float*>(smem_raw);
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   __shared__ uint32_t band_cnt[kBands];          // this workgroup's instances per tile band (binning: band streams)
   if (threadIdx.x < kBands) band_cnt[threadIdx.x] = 0u;
-  if (blockIdx.x == 0)        // the scan launch that follows publishes its chunk totals here (common.h)
+  if (!super && blockIdx.x == 0)        // the scan launch that follows publishes its chunk totals here (common.h)
     for (int t = threadIdx.x; t < (1 + kBands) * scan_chunks(gridDim.x); t += kPreBlock) g.scan_chain[t] = 0ull;
   __syncthreads();
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
@@ -289,6 +501,7 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   pr.visible = false;
   float p[3] = {0.f, 0.f, 0.f};
   float sc_act[3] = {0.f, 0.f, 0.f}, q_act[4] = {1.f, 0.f, 0.f, 0.f};   // activated scale / rotation
+  float opac = 0.f;
   constexpr bool lod = LOD;
   const int shn = a.M * 3;
   if (idx < a.P) {
@@ -300,6 +513,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
       float* pad = lds_sh + threadIdx.x * sh_row_stride(shn) + shn;
       pad[0] = __uint_as_float((uint32_t)lr.r); pad[1] = __uint_as_float((uint32_t)lr.p); pad[2] = lr.w;
     }
+    if constexpr (H48) {
+      // every ordinary load of the kernel is issued up here: while the LDS DMA below is in flight the compiler waits
+      // for ALL outstanding memory operations at the first use of any load's result
+      opac = load_opacity<LOD>(a, idx, nullptr);
+      if (a.interpolation_weights && a.num_node_kids)
+        opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
+    }
     if (a.cov3D_precomp) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) pr.c3[i] = a.cov3D_precomp[(size_t)idx * 6 + i];
@@ -310,17 +530,43 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
     }
     project_gaussian(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, gx, gy, pr);
   }
+  // ---- the workgroup's sums: instances, and instances per tile band (feed the offsets scans) -----------------------------
+  if (idx < a.P && pr.visible) {
+    touched = (uint32_t)((pr.maxx - pr.minx) * (pr.maxy - pr.miny));
+    k1_band_count(pr, touched, gx, gy, band_cnt);
+  }
+  {
+    const uint32_t ws = wave_sum_u32(touched);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
+  }
   // SH coefficients: stream the workgroup's block through LDS when most of it is visible (coalesced),
   // fall back to per-lane loads (visible lanes only) when most of the block is culled.
-  // Plain layout: the block's loads are ISSUED here, into registers, and committed to LDS only after the
-  // double-precision chain below -- K1 holds 3 waves per SIMD (LDS), too few to hide the latency of a load that is
-  // waited for on the spot (0.114 -> 0.092 ms at 1 M Gaussians).
   bool coop = false, deferred = false;
+  const bool sh_lds = a.shs && (shn & 3) == 0;
+  const int nvis = __syncthreads_count(pr.visible);        // (also orders wave_tot / band_cnt)
+  if (threadIdx.x < 64) {                                  // (wave 0) raw sums; with `super` also into the superblock totals
+    uint32_t mine = 0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int w = 0; w < kPreBlock / 64; ++w) mine += wave_tot[w];
+      g.block_sums[blockIdx.x] = mine;
+    } else if (threadIdx.x <= kBands) {
+      mine = band_cnt[threadIdx.x - 1];
+      g.block_band[(size_t)(threadIdx.x - 1) * (gridDim.x + 1) + blockIdx.x] = mine;
+    }
+    if (super && threadIdx.x <= kBands && mine)
+      __hip_atomic_fetch_add(&super[threadIdx.x * kMaxSuper + (blockIdx.x / kSuper)], mine, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // Plain layout: the block's loads are ISSUED here and land while the double-precision chain below runs -- K1 is
+  // bound by latency, not by its arithmetic or by HBM.
   float4 shreg[DEFER ? 12 : 1];
-  if (a.shs && (shn & 3) == 0) {
-    coop = __syncthreads_count(pr.visible) * 2 >= kPreBlock;
+  if (sh_lds) {
+    coop = nvis * 2 >= kPreBlock;
     if (coop) {
-      if (lod) {
+      if constexpr (H48) {
+        sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+      } else if (lod) {
         coop_gather_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
       } else if (a.shs_rest) {
         coop_load_seg(a.shs, blockIdx.x * kPreBlock, a.P, 3, 0, sh_row_stride(shn), lds_sh);
@@ -336,134 +582,130 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
   // ---- everything that does not need the coefficients: the double-precision chain, the record's geometry ----------
   int32_t rad = 0;
   uint32_t flags = 0;
-  float opac = 0.f, thr = 0.f, ext_x = -1.0f, ext_y = -1.0f, invz = 0.f;
-  float gx_hi = 0.f, gy_hi = 0.f, gx_lo = 0.f, gy_lo = 0.f, A2 = 0.f, B2 = 0.f, C2 = 0.f;
+  K1Rec rec;
+  rec.opac = 0.f; rec.thr = 0.f; rec.ext_x = -1.0f; rec.ext_y = -1.0f; rec.invz = 0.f;
+  rec.gx_hi = 0.f; rec.gy_hi = 0.f; rec.gx_lo = 0.f; rec.gy_lo = 0.f; rec.A2 = 0.f; rec.B2 = 0.f; rec.C2 = 0.f;
   if (idx < a.P && pr.visible) {
-    touched = (uint32_t)((pr.maxx - pr.minx) * (pr.maxy - pr.miny));
     rad = (int32_t)pr.rad_f;
     if (pr.clampx) flags |= 8u;
     if (pr.clampy) flags |= 16u;
-    opac = load_opacity<LOD>(a, idx, nullptr);
-    if (a.interpolation_weights && a.num_node_kids)
-      opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
-    // continuous quantities from the double-precision chain (see gaussian_math.h)
-    ProjD pd;
-    if (a.cov3D_precomp) {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) pd.c3[i] = (double)pr.c3[i];
-    } else {
-      cov3d_from_scale_rot_d(sc_act, a.scale_modifier, q_act, pd);
+    if constexpr (!H48) {
+      opac = load_opacity<LOD>(a, idx, nullptr);
+      if (a.interpolation_weights && a.num_node_kids)
+        opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
     }
-    project_gaussian_d(p, cam.vm, cam.pm, a.width, a.height, a.tanfovx, a.tanfovy, pr.clampx, pr.clampy, pd);
-    // pixel centre as hi + lo floats: the render kernels make it tile-relative before use
-    gx_hi = (float)pd.px; gy_hi = (float)pd.py;
-    gx_lo = (float)(pd.px - (double)gx_hi); gy_lo = (float)(pd.py - (double)gy_hi);
-    // conic pre-scaled to a base-2 exponent: power2 = A2*dx^2 + C2*dy^2 + B2*dx*dy
-    const double kLog2e = 1.4426950408889634;
-    A2 = (float)(-0.5 * kLog2e * pd.conA);
-    B2 = (float)(-kLog2e * pd.conB);
-    C2 = (float)(-0.5 * kLog2e * pd.conC);
-    // The compositing kernels clamp the exponent at 0 instead of testing its sign ("power > 0 -> skip" never fires
-    // for a positive definite conic).  Rounding the three coefficients to float32 must therefore not make an extremely
-    // elongated conic indefinite (relative determinant below ~1e-7: sigma of thousands of pixels): if it does, the
-    // mixed term is pulled back inside by one part in a million.
-    {
-      const double lim = 4.0 * (double)A2 * (double)C2;
-      if (!((double)B2 * (double)B2 < lim)) B2 = (float)copysign(sqrt(fmax(lim, 0.0)) * (1.0 - 1.0e-6), (double)B2);
-    }
-    // log-domain skip threshold of the compositing kernels: alpha >= 1/255 <=> power2 >= log2(1/255) - log2(o);
-    // 1e-3 guard band so the exact alpha test keeps every borderline decision (opacity <= 0 -> +inf / NaN:
-    // never a candidate, exactly like the exact test)
-    thr = (-7.994353436858858f - 1.0e-3f) - __builtin_amdgcn_logf(opac);
-    // Half extents (pixels) of the axis-aligned box around the region where alpha can reach 1/255:
-    //   d^T conic d <= T2 = 2 (ln(255 o) + guard)  =>  |dx| <= sqrt(T2 Sigma'_xx), |dy| <= sqrt(T2 Sigma'_yy)
-    // (the extent of an ellipse along an axis is set by the COVARIANCE's diagonal: no determinant, no cancellation, so
-    // float32 is enough -- round 3 took the detour over conic and determinant in double: a log, two square roots and
-    // two divisions at half rate).  T2 = -2 ln 2 * thr: the same logarithm as the skip threshold.  The compositing kernels
-    // use the box to decide, once per (tile, Gaussian), which quadrants can be touched at all; it is inflated (the 1e-3
-    // guard in the base-2 exponent, 1e-4 relative, 5e-3 px) so that it contains every pixel the exact alpha test could
-    // accept.  -1: no pixel ever (o <= ~1/255).
-    {
-      const float T2 = -1.3862943611198906f * thr;
-      const float sxx = (float)pd.a, syy = (float)pd.c;
-      if (T2 > 0.0f) {
-        const bool sane = sxx < 3.0e38f && syy < 3.0e38f;      // (NaN / inf covariance: never skip on the box)
-        ext_x = sane ? sqrtf(T2 * sxx) * 1.0001f + 5.0e-3f : 1.0e9f;
-        ext_y = sane ? sqrtf(T2 * syy) * 1.0001f + 5.0e-3f : 1.0e9f;
-      }
-    }
-    invz = (float)pd.itz;
+    k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
   }
   if constexpr (DEFER) {
     if (deferred) coop_commit_sh(shreg, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
   }
+  if constexpr (H48) {      // the DMA of half 0 has landed before any wave passes the barrier
+    if (coop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   if (coop) __syncthreads();
-  // ---- colour, then the record -------------------------------------------------------------------------------------
-  if (idx < a.P) {
-    if (pr.visible) {
-      float rgb[3];
-      if (a.colors_precomp) {
-        rgb[0] = a.colors_precomp[idx * 3 + 0];
-        rgb[1] = a.colors_precomp[idx * 3 + 1];
-        rgb[2] = a.colors_precomp[idx * 3 + 2];
-      } else {
-        float sh[48];
-        if (coop) lds_row_read(lds_sh, shn, sh);
-        else if (lod) load_sh_lod(a, idx, sh);
-        else if (a.shs_rest) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
-        else load_sh(a.shs, idx, a.M, sh);
-        float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
-        const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-        dx *= inv; dy *= inv; dz *= inv;
-        float b[16];
-        sh_basis(a.sh_degree, dx, dy, dz, b);
-        const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < nb) {
-            r0 += b[k] * sh[k * 3 + 0];
-            r1 += b[k] * sh[k * 3 + 1];
-            r2 += b[k] * sh[k * 3 + 2];
-          }
+  // ---- colour ---------------------------------------------------------------------------------------------------------
+  float rgb[3] = {0.f, 0.f, 0.f};
+  const bool vis = idx < a.P && pr.visible;
+  if constexpr (H48) {            // (launched with a.shs only)
+    {
+      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (coop) {
+        // (the barrier above waited for the DMA of half 0)
+        const bool second = a.sh_degree > 1;               // coefficients 8 .. 15 belong to degrees 2 and 3
+        sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, J);
+        if (second) {
+          __syncthreads();                                 // every lane has read its half 0: the image may be replaced
+          sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, J);
         }
+      } else if (vis) {
+        sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, J);
+      }
+      if (vis) {
         if constexpr (JAC) {
-          // d(rgb)/d(direction) for the backward's SH kernel (it would otherwise read the 3M coefficients again just to
-          // form these nine sums): J[d][c] = sum_k db_k/d(dir_d) * sh[k][c]
-          float dbx[16], dby[16], dbz[16];
-          sh_basis_grad(a.sh_degree, dx, dy, dz, dbx, dby, dbz);
-          float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            if (k < nb) {
-#pragma unroll
-              for (int c = 0; c < 3; ++c) {
-                J[0 + c] += dbx[k] * sh[k * 3 + c];
-                J[3 + c] += dby[k] * sh[k * 3 + c];
-                J[6 + c] += dbz[k] * sh[k * 3 + c];
-              }
-            }
-          }
-          // rows of kJacStride = 12 floats: three 16-byte stores per lane, a wave writes 3 KB of whole cache lines (nine
-          // dword stores at a 36-byte stride touched every line of the block nine times: K1 0.100 -> see DESIGN.md)
           float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
           jd[0] = make_float4(J[0], J[1], J[2], J[3]);
           jd[1] = make_float4(J[4], J[5], J[6], J[7]);
           jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
         }
-        r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
-        if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
-        if (r1 < 0.f) { r1 = 0.f; flags |= 2u; }
-        if (r2 < 0.f) { r2 = 0.f; flags |= 4u; }
-        rgb[0] = r0; rgb[1] = r1; rgb[2] = r2;
+        rgb[0] += 0.5f; rgb[1] += 0.5f; rgb[2] += 0.5f;
+        if (rgb[0] < 0.f) { rgb[0] = 0.f; flags |= 1u; }
+        if (rgb[1] < 0.f) { rgb[1] = 0.f; flags |= 2u; }
+        if (rgb[2] < 0.f) { rgb[2] = 0.f; flags |= 4u; }
       }
+    }
+  } else if (vis) {
+    if (a.colors_precomp) {
+      rgb[0] = a.colors_precomp[idx * 3 + 0];
+      rgb[1] = a.colors_precomp[idx * 3 + 1];
+      rgb[2] = a.colors_precomp[idx * 3 + 2];
+    } else {
+      float sh[48];
+      if (coop) lds_row_read(lds_sh, shn, sh);
+      else if (lod) load_sh_lod(a, idx, sh);
+      else if (a.shs_rest) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
+      else load_sh(a.shs, idx, a.M, sh);
+      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
+      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      float b[16];
+      sh_basis(a.sh_degree, dx, dy, dz, b);
+      const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
+      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < nb) {
+          r0 += b[k] * sh[k * 3 + 0];
+          r1 += b[k] * sh[k * 3 + 1];
+          r2 += b[k] * sh[k * 3 + 2];
+        }
+      }
+      if constexpr (JAC) {
+        // d(rgb)/d(direction) for the backward's SH kernel (it would otherwise read the 3M coefficients again just to
+        // form these nine sums): J[d][c] = sum_k db_k/d(dir_d) * sh[k][c]
+        float dbx[16], dby[16], dbz[16];
+        sh_basis_grad(a.sh_degree, dx, dy, dz, dbx, dby, dbz);
+        float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          if (k < nb) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              J[0 + c] += dbx[k] * sh[k * 3 + c];
+              J[3 + c] += dby[k] * sh[k * 3 + c];
+              J[6 + c] += dbz[k] * sh[k * 3 + c];
+            }
+          }
+        }
+        // rows of kJacStride = 12 floats: three 16-byte stores per lane, a wave writes 3 KB of whole cache lines (nine
+        // dword stores at a 36-byte stride touched every line of the block nine times)
+        float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
+        jd[0] = make_float4(J[0], J[1], J[2], J[3]);
+        jd[1] = make_float4(J[4], J[5], J[6], J[7]);
+        jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
+      }
+      r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
+      if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
+      if (r1 < 0.f) { r1 = 0.f; flags |= 2u; }
+      if (r2 < 0.f) { r2 = 0.f; flags |= 4u; }
+      rgb[0] = r0; rgb[1] = r1; rgb[2] = r2;
+    }
+  }
+  // ---- the record and the per-Gaussian arrays ----------------------------------------------------------------------------
+  if (idx < a.P) {
+    if (pr.visible) {
       const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
                                 ((uint32_t)(pr.maxx - pr.minx) << 20);
-      float4* rec = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
-      rec[0] = make_float4(gx_hi, gy_hi, A2, B2);
-      rec[1] = make_float4(C2, opac, rgb[0], rgb[1]);
-      rec[2] = make_float4(rgb[2], invz, ext_x, __uint_as_float(rectbits));
-      rec[3] = make_float4(gx_lo, gy_lo, thr, ext_y);
+      float4* recp = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
+      recp[0] = make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2);
+      recp[1] = make_float4(rec.C2, rec.opac, rgb[0], rgb[1]);
+      recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
+      recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
     }
     // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
     reinterpret_cast<uint2*>(g.rects)[idx] =
@@ -474,43 +716,23 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
     g.tiles_touched[idx] = touched;
     g.flags[idx] = flags;
   }
-  if (idx < a.P && pr.visible) {
-      // instances per tile band.  Almost every rectangle lies inside ONE band (first and last tile in the same band:
-      // seven compares each, no division); one that straddles boundaries counts (# of its tiles with id < x) at the
-      // boundaries x = b * per it spans, in closed form.
-      const int T = gx * gy, per = band_tiles(T), w = pr.maxx - pr.minx;
-      const int t_first = pr.miny * gx + pr.minx, t_last = (pr.maxy - 1) * gx + pr.maxx - 1;
-      int b_first = 0, b_last = 0;
-#pragma unroll
-      for (int b = 1; b < kBands; ++b) {
-        b_first += (t_first >= b * per) ? 1 : 0;
-        b_last += (t_last >= b * per) ? 1 : 0;
-      }
-      if (b_first == b_last) {
-        atomicAdd(&band_cnt[b_first], touched);
-      } else {
-        int prev = 0;
-        for (int b = b_first; b <= b_last; ++b) {
-          const int x = min((b + 1) * per, T);
-          const int xr = x / gx, xc = x - xr * gx;
-          int cnt = (min(max(xr, pr.miny), pr.maxy) - pr.miny) * w;
-          if (xr >= pr.miny && xr < pr.maxy) cnt += min(max(xc - pr.minx, 0), w);
-          if (cnt > prev) atomicAdd(&band_cnt[b], (uint32_t)(cnt - prev));
-          prev = cnt;
-        }
-      }
-    }
-  // per-workgroup instance count (feeds the offsets scan)
-  const uint32_t ws = wave_sum_u32(touched);
-  if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = ws;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = 0;
-#pragma unroll
-    for (int w = 0; w < kPreBlock / 64; ++w) t += wave_tot[w];
-    g.block_sums[blockIdx.x] = t;
-  }
-  if (threadIdx.x < kBands) g.block_band[(size_t)threadIdx.x * (gridDim.x + 1) + blockIdx.x] = band_cnt[threadIdx.x];
+}
+
+template <bool JAC, bool LOD, bool DEFER>
+__global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
+                                                                   int32_t* __restrict__ radii, uint32_t* __restrict__ super) {
+  preprocess_fwd_body<JAC, LOD, DEFER, false>(a, g, radii, super);
+}
+// The half-row route: 24 KB of LDS per workgroup allow five workgroups per compute unit; the registers are held to what
+// HGS_K1_H48_WAVES waves per SIMD leave (128 at 4).
+#ifndef HGS_K1_H48_WAVES
+#define HGS_K1_H48_WAVES 4
+#endif
+template <bool JAC>
+__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_fwd_h48_kernel(hgs_raster_args a, GeomWs g,
+                                                                                         int32_t* __restrict__ radii,
+                                                                                         uint32_t* __restrict__ super) {
+  preprocess_fwd_body<JAC, false, false, true>(a, g, radii, super);
 }
 
 // Exclusive scan of the per-workgroup sums (nblk = P/256): grid row 0 scans block_sums, rows 1..kBands the columns of
@@ -817,7 +1039,9 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
         o_rec = lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
       // the instance records carry sum X = sum (o G) dL/dalpha; dL/do = sum G dL/dalpha = (sum X) / o.  o <= 0: never
       // blended, sum X = 0
-      const float sums5 = o_rec > 0.0f ? (float)(s[5] * rcp_d((double)o_rec)) : 0.0f;
+      // (exact division, once per Gaussian: rcp_d seeds from v_rcp_f32, which overflows for a denormal opacity -- the
+      // Newton step would then turn 0 x inf into a NaN that poisons the optimizer state)
+      const float sums5 = o_rec > 0.0f ? (float)(s[5] / (double)o_rec) : 0.0f;
       d_op = a.activations ? (float)((double)sums5 * (double)dod * dact) : sums5 * dod;
     }
 
@@ -1331,16 +1555,59 @@ int launch_sh_bwd_batched(const ShBwdViews& v, int32_t P, int32_t M, int32_t sh_
   return HGS_OK;
 }
 
-int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s) {
+// Zeroed superblock totals of K1 (above), one block per (device, stream): launches on one stream run one after the other
+// and the counting kernel behind K3 leaves the block at zero, so it is zeroed by the host only when it is created -- or
+// when an error return between K1 and that kernel left it `dirty`.  At most kMaxSyncBlocks distinct streams are served;
+// further ones (and HGS_SCAN_LAUNCH=1) take the separate scan launch.
+namespace {
+constexpr int kMaxSyncBlocks = 64;
+struct SyncBlock { int device; hipStream_t stream; uint32_t* words; bool dirty; };
+std::mutex g_sync_mu;
+SyncBlock g_sync[kMaxSyncBlocks];
+int g_sync_n = 0;
+}  // namespace
+size_t super_block_bytes() { return (size_t)(1 + kBands) * kMaxSuper * sizeof(uint32_t); }
+uint32_t* super_block_acquire(hipStream_t s) {
+  static const bool off = getenv("HGS_SCAN_LAUNCH") != nullptr;
+  if (off) return nullptr;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  for (int i = 0; i < g_sync_n; ++i) {
+    SyncBlock& b = g_sync[i];
+    if (b.device != dev || b.stream != s) continue;
+    if (b.dirty) {
+      if (hipMemsetAsync(b.words, 0, super_block_bytes(), s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+      b.dirty = false;
+    }
+    return b.words;
+  }
+  if (g_sync_n == kMaxSyncBlocks) return nullptr;
+  uint32_t* w = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&w), super_block_bytes()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (hipMemsetAsync(w, 0, super_block_bytes(), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
+  g_sync[g_sync_n++] = {dev, s, w, false};
+  return w;
+}
+void super_block_mark_dirty(const uint32_t* words) {
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  for (int i = 0; i < g_sync_n; ++i)
+    if (g_sync[i].words == words) g_sync[i].dirty = true;
+}
+
+int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
-    const size_t lds_bytes = a.shs ? (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float) : 0;
     const bool jac = a.prepare_backward && a.shs;
-    const bool defer = a.shs && !a.shs_rest && !a.lod_render_indices && ((a.M * 3) & 3) == 0;
+    const bool plain = a.shs && !a.shs_rest && !a.lod_render_indices && ((a.M * 3) & 3) == 0;
+    const bool h48 = plain && a.M == 16;
+    const bool defer = plain && !h48;
+    const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)kHalfBytes : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
     auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
+              : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
               : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
                       : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
-    hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii);
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
   }
   return HGS_OK;

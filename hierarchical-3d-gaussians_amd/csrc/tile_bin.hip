@@ -44,55 +44,88 @@ __device__ __forceinline__ BandStream band_stream(const uint32_t* __restrict__ b
   return s;
 }
 
-// grid = kBands * max_chunks; workgroup b: band b % kBands (= its XCD), chunk b / kBands of that band's stream
+// The binning scratch (BinWs::sort_tmp): the count table, the group sums, then -- adjacent, cleared together by K3
+// (binning.hip: zero_words) -- the tile totals and the arrival counters of the chunk groups.
+struct TbScratch {
+  uint32_t *table, *gsum, *totals, *arrive;
+};
+__host__ inline TbScratch tb_carve(void* tmp, uint32_t L_cap, int32_t T, uint32_t chunk) {
+  const size_t max_chunks = ((size_t)(L_cap ? L_cap : 1) + chunk - 1) / chunk;
+  const size_t per = band_tiles(T), Tp = per * kBands;
+  char* c = static_cast<char*>(tmp);
+  TbScratch t;
+  t.table = carve<uint32_t>(c, (size_t)kBands * max_chunks * per);
+  t.gsum = carve<uint32_t>(c, (size_t)kGroups * Tp);
+  t.totals = carve<uint32_t>(c, Tp + (size_t)kBands * kGroups);
+  t.arrive = t.totals + Tp;
+  return t;
+}
+
+__device__ __forceinline__ void store_sc1(uint32_t* p, uint32_t v) {      // write-through (global_store_dword ... sc1)
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// grid = kBands * max_chunks; workgroup b: band b % kBands (= its XCD), chunk b / kBands of that band's stream.
+// COUNT AND COLUMN SCAN IN ONE LAUNCH (rounds 1-4: two, the second 5.5 us + a kernel boundary for 2.6 MB): the chunks of
+// a band form kGroups groups; the workgroup that completes a group -- the last of the group's chunks to count itself in
+// on the group's arrival counter -- scans the group's rows per tile (exclusive, in place), stores the group sums and
+// adds them to the tile totals.  Nobody waits for anybody.  Hand-over = recipe R1 of cdna_hip_programming.md Guideline
+// 16: the rows are stored WRITE-THROUGH (sc1), every storing wave drains its stores, then one lane arrives (agent-scope
+// atomic); the finishing workgroup runs one agent-scope acquire (its vector L1; its L2 never held these lines: sc1 stores
+// do not leave them there) before it reads the rows with plain loads.  Placement only decides speed (a band's
+// workgroups share an XCD), never the result.  `totals` and `arrive` are zero on entry (cleared by K3).
+// `super` (may be null): K1's superblock totals, consumed by K3 -- zeroed here for the next frame on this stream.
 __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __restrict__ keys, uint32_t cap,
                                                               const uint32_t* __restrict__ band_totals, int col, int per,
                                                               uint32_t chunk, int max_chunks,
-                                                              uint32_t* __restrict__ table, uint32_t* __restrict__ totals,
-                                                              int Tp) {
+                                                              uint32_t* __restrict__ table, uint32_t* __restrict__ gsum,
+                                                              uint32_t* __restrict__ totals, uint32_t* __restrict__ arrive,
+                                                              int Tp, uint32_t* __restrict__ super, int n_super) {
   extern __shared__ uint32_t h[];
-  if (blockIdx.x == 0)      // per-tile totals are accumulated with atomics by the column scan that follows
-    for (int t = threadIdx.x; t < Tp; t += kTbThreads) totals[t] = 0u;
+  __shared__ uint32_t completes_group;
+  for (int r = blockIdx.x * kTbThreads + threadIdx.x; r < n_super; r += gridDim.x * kTbThreads) super[r] = 0u;
   const int band = blockIdx.x % kBands, c = blockIdx.x / kBands;
   const BandStream st = band_stream(band_totals, col, band, cap);
   const uint32_t base = st.begin + (uint32_t)c * chunk;
-  if (base >= st.end) return;                              // beyond the band's last chunk: no table row is read either
+  if (base >= st.end) return;                              // beyond the band's last chunk: not part of any group
   for (int t = threadIdx.x; t < per; t += kTbThreads) h[t] = 0u;
   __syncthreads();
   const uint32_t end = min(base + chunk, st.end);
   for (uint32_t i = base + threadIdx.x; i < end; i += kTbThreads) atomicAdd(&h[keys[i]], 1u);
   __syncthreads();
   uint32_t* row = table + ((size_t)band * max_chunks + c) * per;
-  for (int t = threadIdx.x; t < per; t += kTbThreads) row[t] = h[t];
-}
-
-// grid (ceil(per / 256), kGroups, kBands): exclusive scan over the chunks of one group, per tile of the band; group sums to
-// gsum[g][tile] and (atomically) to totals[tile]  (tile = global tile id = band * per + local id; arrays padded to Tp = 8 per)
-__global__ __launch_bounds__(kTbThreads) void tb_colscan_kernel(uint32_t* __restrict__ table,
-                                                                const uint32_t* __restrict__ band_totals, int col, int per,
-                                                                uint32_t chunk, int max_chunks, uint32_t cap, int Tp,
-                                                                uint32_t* __restrict__ gsum, uint32_t* __restrict__ totals) {
-  const int t = blockIdx.x * kTbThreads + threadIdx.x;
-  if (t >= per) return;
-  const int g = blockIdx.y, band = blockIdx.z;
-  const BandStream st = band_stream(band_totals, col, band, cap);
+  for (int t = threadIdx.x; t < per; t += kTbThreads) store_sc1(&row[t], h[t]);
+  // ---- arrive on the chunk group; the workgroup that completes it scans it ---------------------------------------------
   const int nchunks = (int)((st.end - st.begin + chunk - 1) / chunk);
   const int cpg = (nchunks + kGroups - 1) / kGroups;
-  const int c0 = g * cpg, c1 = min(c0 + cpg, nchunks);
-  uint32_t* tb = table + (size_t)band * max_chunks * per + t;
-  uint32_t acc = 0;
-  for (int cb = c0; cb < c1; cb += 8) {           // 8 independent loads in flight, then the 8 prefix stores
-    uint32_t v[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = (cb + k < c1) ? tb[(size_t)(cb + k) * per] : 0u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (cb + k < c1) tb[(size_t)(cb + k) * per] = acc;
-      acc += v[k];
-    }
+  const int g = c / cpg, c0 = g * cpg, c1 = min(c0 + cpg, nchunks);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its row stores have left
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t before = __hip_atomic_fetch_add(&arrive[band * kGroups + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t done = before == (uint32_t)(c1 - c0 - 1);
+    if (done) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    completes_group = done;
   }
-  gsum[(size_t)g * Tp + band * per + t] = acc;
-  if (acc) atomicAdd(&totals[band * per + t], acc);
+  __syncthreads();
+  if (!completes_group) return;
+  uint32_t* tb0 = table + (size_t)band * max_chunks * per;
+  for (int t = threadIdx.x; t < per; t += kTbThreads) {
+    uint32_t* tb = tb0 + t;
+    uint32_t acc = 0;
+    for (int cb = c0; cb < c1; cb += 8) {           // 8 independent loads in flight, then the 8 prefix stores
+      uint32_t v[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (cb + k < c1) ? tb[(size_t)(cb + k) * per] : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (cb + k < c1) tb[(size_t)(cb + k) * per] = acc;
+        acc += v[k];
+      }
+    }
+    gsum[(size_t)g * Tp + band * per + t] = acc;
+    if (acc) atomicAdd(&totals[band * per + t], acc);
+  }
 }
 
 // Launch order of the one-wave-per-tile kernels (K6, K7) for one band: the band's tiles by DESCENDING instance count
@@ -226,31 +259,33 @@ size_t tile_bin_tmp_bytes(uint32_t L, int32_t T) {
   const uint32_t chunk = tb_chunk(T);
   const size_t max_chunks = ((size_t)(L ? L : 1) + chunk - 1) / chunk;
   const size_t per = band_tiles(T), Tp = per * kBands;
-  return align_up(kBands * max_chunks * per * 4) + align_up((size_t)kGroups * Tp * 4) + align_up(Tp * 4) + kAlign;
+  return align_up(kBands * max_chunks * per * 4) + align_up((size_t)kGroups * Tp * 4) +
+         align_up((Tp + (size_t)kBands * kGroups) * 4) + kAlign;
 }
+
+uint32_t* tile_bin_zero_words(void* tmp, uint32_t L_cap, int32_t T) {
+  return tile_bin_supported(T) ? tb_carve(tmp, L_cap, T, tb_chunk(T)).totals : nullptr;
+}
+int tile_bin_zero_count(int32_t T) { return tile_bin_supported(T) ? band_tiles(T) * kBands + kBands * kGroups : 0; }
 
 // keys / vals: the banded instance streams (band-local tile id, Gaussian id); vals_out: ids grouped by tile (unordered
 // inside a tile); ranges [T,2], the depth-sort class counters (big[0..2]) and the compositing kernels' launch order
-// (tile_order) are written as well.
+// (tile_order) are written as well.  The scratch's tile totals and arrival counters must be zero (the banded K3 clears
+// them).  super (optional): K1's superblock totals, cleared here for the next frame.
 int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_out, void* tmp, uint32_t L_cap,
                     const uint32_t* band_totals, int32_t nblk, int32_t T, uint32_t* ranges, uint32_t* big,
-                    uint32_t* tile_order, hipStream_t s, bool debug) {
+                    uint32_t* tile_order, uint32_t* super, hipStream_t s, bool debug) {
   const uint32_t chunk = tb_chunk(T);
   const int max_chunks = (int)(((size_t)L_cap + chunk - 1) / chunk);
   const int per = band_tiles(T), Tp = per * kBands, col = nblk + 1;
-  char* c = static_cast<char*>(tmp);
-  uint32_t* table = carve<uint32_t>(c, (size_t)kBands * max_chunks * per);
-  uint32_t* gsum = carve<uint32_t>(c, (size_t)kGroups * Tp);
-  uint32_t* totals = carve<uint32_t>(c, (size_t)Tp);
+  const TbScratch t = tb_carve(tmp, L_cap, T, chunk);
   const size_t lds = (size_t)per * 4;          // <= 16 KiB (T <= 32768)
   hipLaunchKernelGGL(tb_count_kernel, dim3(kBands * max_chunks), dim3(kTbThreads), lds, s, keys, L_cap, band_totals, col, per,
-                     chunk, max_chunks, table, totals, Tp);
+                     chunk, max_chunks, t.table, t.gsum, t.totals, t.arrive, Tp, super,
+                     super ? (int)(super_block_bytes() / sizeof(uint32_t)) : 0);
   HGS_LAUNCH_CHECK("tile_bin_count", s, debug);
-  hipLaunchKernelGGL(tb_colscan_kernel, dim3((per + kTbThreads - 1) / kTbThreads, kGroups, kBands), dim3(kTbThreads), 0, s,
-                     table, band_totals, col, per, chunk, max_chunks, L_cap, Tp, gsum, totals);
-  HGS_LAUNCH_CHECK("tile_bin_colscan", s, debug);
   hipLaunchKernelGGL(tb_scatter_kernel, dim3(kBands * max_chunks + kBands), dim3(kTbThreads), lds, s, keys, vals, L_cap,
-                     band_totals, col, per, chunk, max_chunks, T, Tp, table, gsum, totals, vals_out, ranges, big, tile_order);
+                     band_totals, col, per, chunk, max_chunks, T, Tp, t.table, t.gsum, t.totals, vals_out, ranges, big, tile_order);
   HGS_LAUNCH_CHECK("tile_bin_scatter", s, debug);
   return HGS_OK;
 }

@@ -110,6 +110,7 @@ class BudgetedHierarchy:
         self.ns = torch.zeros(cap, **i32)
         self.frame = 0
         self._regulated = None          # granularity the previous view was coarsened to (None: the request fitted)
+        self._skip_batch = 0            # evictions left that skip the batch attempt (it failed recently)
         self._since_probe, self.probe_every = 0, 16
         self.stats = dict(views=0, rows_fetched=0, bytes_fetched=0, evictions=0, retries=0)
         self.profile_fetch = False      # True: (rows, start event, end event) of every fetch launch -> self.fetch_events
@@ -192,12 +193,19 @@ class BudgetedHierarchy:
                     # An eviction costs two passes over the slots and two host round trips: free a batch (1 / 32 of
                     # the budget) beyond what this view needs, so that a camera in motion evicts every few frames
                     # instead of on every frame; if that many old rows do not exist, exactly what is needed.
-                    for need in dict.fromkeys((max(m, min(self.B, m + self.B // 32)), m)):
+                    # A view whose working set nearly fills the budget has no such batch to give: after a failed
+                    # batch attempt the next 16 evictions ask for exactly what they need (one pass, one round trip).
+                    batch = max(m, min(self.B, m + self.B // 32))
+                    if self._skip_batch > 0:
+                        self._skip_batch -= 1
+                        batch = m
+                    for need in dict.fromkeys((batch, m)):
                         top = C.c_uint32(self.free_top)
                         rc = self.lib.hgs_resid_evict(p(self.stamp), p(self.id_of_slot), p(self.slot_of), self.B,
                                                       self.frame, need, p(self.free_list), p(self.counters),
                                                       C.byref(top), s, dev_i)
                         if rc == _lib.ERR_CAPACITY and need > m:
+                            self._skip_batch = 16
                             continue
                         _lib.check(rc, "hgs_resid_evict")
                         break

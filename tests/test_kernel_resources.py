@@ -19,15 +19,15 @@ pytestmark = pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") and s
 FRAME = {
     "render_fwd_quad_kernel<true>": (80, 6),
     "render_bwd_quad_kernel<true>": (128, 4),
-    "preprocess_fwd_kernel<true, false, true>": (144, 3),
+    # K1 at M = 16: the SH block in two halves straight into LDS (24 KB per workgroup), round 5; was (144, 3)
+    "preprocess_fwd_h48_kernel<true>": (96, 5),
+    "preprocess_fwd_h48_kernel<false>": (96, 5),
     "preprocess_bwd_kernel<false, false>": (160, 3),
     "sh_bwd_kernel<false, true, false>": (72, 3),
     "duplicate_tiles_banded_kernel": (40, 8),
     "tile_depth_sort_wave_kernel<false>": (72, 7),
-    "tb_count_kernel": (56, 8),
-    "tb_colscan_kernel": (32, 8),
+    "tb_count_kernel": (56, 8),             # count + column scan in one launch (round 5)
     "tb_scatter_kernel": (40, 8),
-    "scan_block_sums_kernel": (48, 8),
 }
 
 
@@ -61,4 +61,4 @@ def test_double_precision_stays_where_conditioning_needs_it(rows):
                  "duplicate_tiles_banded_kernel", "tb_scatter_kernel", "tile_depth_sort_wave_kernel<false>"):
         assert rows[name]["mix"]["valu_f64"] == 0, name
     assert rows["preprocess_bwd_kernel<false, false>"]["mix"]["valu_f64"] > 0
-    assert rows["preprocess_fwd_kernel<true, false, true>"]["mix"]["valu_f64"] > 0
+    assert rows["preprocess_fwd_h48_kernel<true>"]["mix"]["valu_f64"] > 0

@@ -247,16 +247,79 @@ print("digest", h.hexdigest(), r["L"])
 
 def test_diagnostic_wait_and_count_routes_give_the_same_frame(gpu):
     """HGS_BLOCKING_WAIT (sleeping host waits instead of polling), HGS_COUNT_BY_COPY (the instance count by a copy
-    command instead of the scan kernel's store into mapped host memory) and HGS_SCAN_SPLIT (the workgroup-sum scans by
-    one launch per array, the route of views too large for one resident grid) are read once per process: one small
+    command instead of a kernel's store into mapped host memory), HGS_SCAN_LAUNCH (the workgroup sums scanned by a launch
+    between K1 and K3 -- the route of rounds 1-4, kept for the radix path and very large P -- instead of K1's superblock
+    totals finished by K3) and HGS_SCAN_SPLIT (that launch once per array) are read once per process: one small
     fwd+bwd per setting in a process of its own, bit-identical outputs and gradients."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for name, env in (("default", {}), ("blocking", {"HGS_BLOCKING_WAIT": "1"}), ("copy", {"HGS_COUNT_BY_COPY": "1"}),
-                      ("split", {"HGS_SCAN_SPLIT": "1"})):
+                      ("split", {"HGS_SCAN_SPLIT": "1", "HGS_SCAN_LAUNCH": "1"}), ("scanlaunch", {"HGS_SCAN_LAUNCH": "1"})):
         r = subprocess.run([sys.executable, "-c", _FRAME_DIGEST, root], env={**os.environ, **env}, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])
         digests[name] = [l for l in r.stdout.splitlines() if l.startswith("digest")][-1]
-    assert digests["default"] == digests["blocking"] == digests["copy"] == digests["split"], digests
+    assert digests["default"] == digests["blocking"] == digests["copy"] == digests["split"] == digests["scanlaunch"], digests
+
+
+def test_culled_workgroups_and_active_degrees_on_the_half_row_route(gpu):
+    """K1 at M = 16 stages the SH block in two halves straight into LDS (round 5).  Three things the usual scenes do not
+    reach: workgroups whose Gaussians are mostly off screen (per-lane loads of the visible rows instead of the DMA), a
+    last workgroup that is not full, and active degrees 0 / 1 (the second half is never fetched) and 2 -- each against the
+    oracle, indices bit-exact."""
+    cam = synth.make_camera(160, 96)
+    for deg, P, spread in ((3, 2000 + 37, 4.0), (0, 1500, 1.0), (1, 1500 + 255, 2.5), (2, 1024 + 1, 1.0)):
+        scene = synth.make_scene(P, cam, seed=40 + deg, sh_degree=3)
+        scene.sh_degree = deg                                   # stored M = 16, active degree deg
+        # spread > 1: most Gaussians leave the frustum sideways, in random order -> every workgroup is "mostly culled"
+        scene.means3D[:, :2] *= spread
+        gc, gd = synth.upstream_grads(96, 160, seed=3)
+        bg = torch.tensor([0.2, 0.1, 0.3])
+        oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+        hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+        idx = pa.check_indices(hip, oo)
+        assert all(v == 0 for v in idx.values()), (deg, idx)
+        vis = float((oo.geom.radii > 0).mean())
+        if spread > 2:
+            assert vis < 0.45, vis                              # the fallback is what ran
+        pa.assert_stats(f"half-row route deg={deg} P={P} visible={vis:.2f}", pa.compare(hip, oo, og))
+
+
+def test_binning_hand_overs_hold_under_load(gpu):
+    """The counting kernel of the tile binning scans a chunk group's rows in the workgroup that completes the group
+    (release / acquire inside one launch, tile_bin.hip), K3 finishes the scans of K1's workgroup sums from superblock
+    totals that K1 adds up with atomics, and both lean on words that an earlier kernel of the SAME frame zeroed.  A stale
+    row or a dirty counter is a wrong tile list, so: 1 500 frames of one scene back to back -- while a second stream keeps
+    the memory system busy with uneven bursts -- every frame's tile ranges and sorted list equal to the oracle's."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W, H, P = 1280, 720, 150_000
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(P, cam, seed=21)
+    geom = ro.geometry_spec(scene.means3D.numpy(), scene.scales.numpy(), scene.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            cam.tanfovx, cam.tanfovy, 1.0)
+    binning = ro.binning_spec(geom)
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    sc = scene.to(gpu)
+    ref_ranges = torch.from_numpy(binning.ranges.astype(np.int64)).to(gpu)
+    ref_list = torch.from_numpy(binning.point_list.astype(np.int64)).to(gpu)
+    side = torch.cuda.Stream()
+    junk = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    bad = torch.zeros((), dtype=torch.int64, device=gpu)
+    n_frames = 1500
+    for it in range(n_frames):
+        if it % 3 == 0:
+            with torch.cuda.stream(side):                        # bursts of different lengths next to the frames
+                for _ in range(1 + it % 4):
+                    junk[: (8 + 8 * (it % 7)) << 20].add_(1)
+        L, color, radii, geomb, binb, img, invd, call = dgr._C.rasterize_gaussians(
+            rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+            rs.interpolation_weights, rs.num_node_kids, False)
+        assert L == binning.num_rendered, (it, L)
+        v = dgr._C.raster_views(call)
+        bad += (v["ranges"].to(torch.int64) != ref_ranges).sum() + (v["point_list"].to(torch.int64) != ref_list).sum()
+    torch.cuda.synchronize()
+    assert int(bad.item()) == 0, f"{int(bad.item())} mismatching entries over {n_frames} frames"
