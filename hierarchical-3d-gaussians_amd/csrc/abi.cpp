@@ -392,6 +392,12 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   *L_out_host = *stage;
   if (rc) return rc;
   if (*L_out_host > L_cap) {
+    if (super) {
+      // the caller finishes on hgs_raster_fwd_stage2 over THIS geometry workspace, whose K3 expects the workgroup sums
+      // scanned: scan the raw sums now (the superblock totals are consumed and cleared; this path is the rare one)
+      HGS_HIP(hipMemsetAsync(g.scan_chain, 0, (size_t)(1 + kBands) * scan_chunks(nblk) * sizeof(unsigned long long), s));
+      if ((rc = launch_scan_block_sums(g, a->P, s, a->debug, nullptr))) return rc;
+    }
     set_error("instance count %u exceeds the capacity %u given to hgs_raster_fwd", *L_out_host, L_cap);
     return HGS_ERR_CAPACITY;
   }

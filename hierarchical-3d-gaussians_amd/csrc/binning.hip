@@ -218,21 +218,24 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
 #pragma unroll
     for (int b = 0; b < kBands; ++b) wave_tot[wave][b] = incb[b];
   }
-  if (super) {
-    __syncthreads();                                      // pre9 / tot9 of all four waves
+  if (!super && wave == 0) {                              // band base = the totals of the bands before it
+    const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
+    if (tid < kBands) bpos[tid] = incl - band_tot + band_off;
+  }
+  __syncthreads();
+  if (super) {                                            // (pre9 / tot9 of all four waves are there now)
     block_base = pre9[0];
-    if (tid < kBands) { band_tot = tot9[1 + tid]; band_off = pre9[1 + tid]; }
+    if (wave == 0) {
+      if (tid < kBands) { band_tot = tot9[1 + tid]; band_off = pre9[1 + tid]; }
+      const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
+      if (tid < kBands) bpos[tid] = incl - band_tot + band_off;       // (read after the barrier in front of the slot loop)
+    }
     if (blockIdx.x == gridDim.x - 1 && tid <= kBands) {   // the totals, where the scan launch used to leave them
       uint32_t* arr = tid == 0 ? g.block_sums : g.block_band + (size_t)(tid - 1) * col;
       arr[gridDim.x] = tot9[tid];
       if (tid == 0 && total_mirror) *total_mirror = tot9[0];
     }
   }
-  if (wave == 0) {                                        // band base = the totals of the bands before it
-    const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
-    if (tid < kBands) bpos[tid] = incl - band_tot + band_off;
-  }
-  __syncthreads();
   uint32_t wbase = 0;
   for (int w = 0; w < wave; ++w) wbase += wave_tot[w][kBands];
   const uint32_t my_excl = wbase + inc - cnt;

@@ -373,6 +373,16 @@ __device__ __forceinline__ float lod_opacity(float o, float w, int kids, float* 
   return w * o + (1.0f - w) * (1.0f - pw);
 }
 
+// unit view direction (p - campos) / |p - campos| and 1 / |p - campos|: one piece of code (contraction off) for every
+// kernel that evaluates the SH basis, so that forward, backward and all instantiations see the same direction bits
+__device__ __forceinline__ float unit_dir(const float p[3], const float* cam, float& dx, float& dy, float& dz) {
+#pragma clang fp contract(off)
+  dx = p[0] - cam[0]; dy = p[1] - cam[1]; dz = p[2] - cam[2];
+  const float inv = 1.0f / sqrtf((dx * dx + dy * dy) + dz * dz);
+  dx *= inv; dy *= inv; dz *= inv;
+  return inv;
+}
+
 constexpr float SH_C0 = 0.28209479177387814f;
 constexpr float SH_C1 = 0.4886025119029199f;
 constexpr float SH_C2_0 = 1.0925484305920792f;
@@ -389,7 +399,10 @@ constexpr float SH_C3_5 = 1.445305721320277f;
 constexpr float SH_C3_6 = -0.5900435899266435f;
 
 // SH basis values for a unit direction (utils/sh_utils.py:57-112 polynomial).
+// (contraction off, like the geometry chain: the values must not depend on what the surrounding kernel lets the
+// compiler fuse -- K1's instantiations have to give the same colour bits, tests/test_lod_gpu.py)
 __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float b[16]) {
+#pragma clang fp contract(off)
   b[0] = SH_C0;
   if (deg > 0) {
     b[1] = -SH_C1 * y;
@@ -418,6 +431,7 @@ __device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, flo
 // d(basis_k)/d(x,y,z)
 __device__ __forceinline__ void sh_basis_grad(int deg, float x, float y, float z, float dbx[16],
                                               float dby[16], float dbz[16]) {
+#pragma clang fp contract(off)
   dbx[0] = dby[0] = dbz[0] = 0.0f;
   if (deg > 0) {
     dbx[1] = 0.0f;      dby[1] = -SH_C1;    dbz[1] = 0.0f;

@@ -326,10 +326,10 @@ __device__ __forceinline__ void sh48_accumulate4(int deg, float dx, float dy, fl
   sh_basis(deg, dx, dy, dz, b);
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if (K0 + k < nb) {
-      rgb[0] += b[K0 + k] * sh[k * 3 + 0];
-      rgb[1] += b[K0 + k] * sh[k * 3 + 1];
-      rgb[2] += b[K0 + k] * sh[k * 3 + 2];
+    if (K0 + k < nb) {                                     // (explicit FMAs: the same bits in every instantiation)
+      rgb[0] = __builtin_fmaf(b[K0 + k], sh[k * 3 + 0], rgb[0]);
+      rgb[1] = __builtin_fmaf(b[K0 + k], sh[k * 3 + 1], rgb[1]);
+      rgb[2] = __builtin_fmaf(b[K0 + k], sh[k * 3 + 2], rgb[2]);
     }
   }
   if constexpr (JAC) {
@@ -340,9 +340,9 @@ __device__ __forceinline__ void sh48_accumulate4(int deg, float dx, float dy, fl
       if (K0 + k < nb) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-          J[0 + c] += dbx[K0 + k] * sh[k * 3 + c];
-          J[3 + c] += dby[K0 + k] * sh[k * 3 + c];
-          J[6 + c] += dbz[K0 + k] * sh[k * 3 + c];
+          J[0 + c] = __builtin_fmaf(dbx[K0 + k], sh[k * 3 + c], J[0 + c]);
+          J[3 + c] = __builtin_fmaf(dby[K0 + k], sh[k * 3 + c], J[3 + c]);
+          J[6 + c] = __builtin_fmaf(dbz[K0 + k], sh[k * 3 + c], J[6 + c]);
         }
       }
     }
@@ -473,6 +473,44 @@ __device__ __forceinline__ void k1_continuous(const hgs_raster_args& a, const Ca
   o.invz = (float)pd.itz;
 }
 
+// Tuning aid (scripts/diag_k1_anatomy.py; never defined in the product build): HGS_K1X = bit mask of parts of the
+// half-row K1 to leave out -- 1 record store, 2 Jacobian store, 4 SH block (no DMA, no LDS reads), 8 double-precision
+// chain, 16 the 4- and 8-byte arrays -- to see what each costs.
+#ifdef HGS_K1X
+#define K1X(bit) (((HGS_K1X) & (bit)) != 0)
+#else
+#define K1X(bit) false
+#endif
+// How the half-row K1 stores its 64-byte records and 48-byte Jacobian rows: 1 = through the wave's own part of the LDS
+// image (free once the wave has read its last half row; a lane's row of NV 16-byte pieces goes to LDS as it will lie in
+// memory, then every store instruction of the wave writes 1 KB of consecutive bytes), 0 = straight from the lane (NV
+// instructions that each touch 64 different cache lines: a row-per-lane store pattern is bound by the rate at which
+// the memory pipeline takes partial lines, not by bandwidth).
+#ifndef HGS_K1_COALESCED_STORES
+#define HGS_K1_COALESCED_STORES 1
+#endif
+// v[NV] of lane l = the NV consecutive float4 of row (row0 + l) of a [rows, NV] float4 array at dst; rows whose bit in
+// `mask` is clear are not written.  wave_lds: >= 64 * NV * 16 bytes private to the calling wave.
+template <int NV>
+__device__ __forceinline__ void wave_store_rows(float4* __restrict__ dst, size_t row0, const float4 (&v)[NV],
+                                                unsigned long long mask, float4* wave_lds) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int q = 0; q < NV; ++q) wave_lds[lane * NV + q] = v[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = j * 64 + lane;                 // float4 index inside the wave's block of rows
+    const int r = i / NV;
+    const float4 t = wave_lds[i];
+    if ((mask >> r) & 1ull) dst[row0 * NV + i] = t;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();               // (the next use of wave_lds overwrites it)
+}
+
 template <bool JAC, bool LOD, bool DEFER, bool H48>
                                 // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
                                 // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
@@ -565,7 +603,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     coop = nvis * 2 >= kPreBlock;
     if (coop) {
       if constexpr (H48) {
-        sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+        if (!K1X(4)) sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
       } else if (lod) {
         coop_gather_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
       } else if (a.shs_rest) {
@@ -594,7 +632,8 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       if (a.interpolation_weights && a.num_node_kids)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
     }
-    k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
+    if (!K1X(8)) k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
+    else { rec.opac = opac; rec.gx_hi = pr.px; rec.gy_hi = pr.py; rec.A2 = pr.conA; rec.B2 = pr.conB; rec.C2 = pr.conC; rec.invz = pr.tz; }
   }
   if constexpr (DEFER) {
     if (deferred) coop_commit_sh(shreg, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
@@ -606,38 +645,34 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   // ---- colour ---------------------------------------------------------------------------------------------------------
   float rgb[3] = {0.f, 0.f, 0.f};
   const bool vis = idx < a.P && pr.visible;
+  float J[JAC ? 9 : 1];
   if constexpr (H48) {            // (launched with a.shs only)
-    {
-      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
-      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-      dx *= inv; dy *= inv; dz *= inv;
-      float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (coop) {
-        // (the barrier above waited for the DMA of half 0)
-        const bool second = a.sh_degree > 1;               // coefficients 8 .. 15 belong to degrees 2 and 3
-        sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, J);
-        if (second) {
-          __syncthreads();                                 // every lane has read its half 0: the image may be replaced
-          sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, J);
-        }
-      } else if (vis) {
-        sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, J);
+    float dx, dy, dz;
+    unit_dir(p, cam.cam, dx, dy, dz);
+    float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (coop && !K1X(4)) {
+      // (the barrier above waited for the DMA of half 0)
+      const bool second = a.sh_degree > 1;               // coefficients 8 .. 15 belong to degrees 2 and 3
+      sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+      if (second) {
+        __syncthreads();                                 // every lane has read its half 0: the image may be replaced
+        sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
       }
-      if (vis) {
-        if constexpr (JAC) {
-          float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-          jd[0] = make_float4(J[0], J[1], J[2], J[3]);
-          jd[1] = make_float4(J[4], J[5], J[6], J[7]);
-          jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
-        }
-        rgb[0] += 0.5f; rgb[1] += 0.5f; rgb[2] += 0.5f;
-        if (rgb[0] < 0.f) { rgb[0] = 0.f; flags |= 1u; }
-        if (rgb[1] < 0.f) { rgb[1] = 0.f; flags |= 2u; }
-        if (rgb[2] < 0.f) { rgb[2] = 0.f; flags |= 4u; }
-      }
+    } else if (vis && !K1X(4)) {
+      sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, Jt);
+    }
+    if constexpr (JAC) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) J[i] = Jt[i];
+    }
+    if (vis) {
+      rgb[0] += 0.5f; rgb[1] += 0.5f; rgb[2] += 0.5f;
+      if (rgb[0] < 0.f) { rgb[0] = 0.f; flags |= 1u; }
+      if (rgb[1] < 0.f) { rgb[1] = 0.f; flags |= 2u; }
+      if (rgb[2] < 0.f) { rgb[2] = 0.f; flags |= 4u; }
     }
   } else if (vis) {
     if (a.colors_precomp) {
@@ -650,45 +685,24 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       else if (lod) load_sh_lod(a, idx, sh);
       else if (a.shs_rest) load_sh_split(a.shs, a.shs_rest, idx, a.M, sh);
       else load_sh(a.shs, idx, a.M, sh);
-      float dx = p[0] - cam.cam[0], dy = p[1] - cam.cam[1], dz = p[2] - cam.cam[2];
-      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-      dx *= inv; dy *= inv; dz *= inv;
-      float b[16];
-      sh_basis(a.sh_degree, dx, dy, dz, b);
-      const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
-      float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k < nb) {
-          r0 += b[k] * sh[k * 3 + 0];
-          r1 += b[k] * sh[k * 3 + 1];
-          r2 += b[k] * sh[k * 3 + 2];
-        }
-      }
+      float dx, dy, dz;
+      unit_dir(p, cam.cam, dx, dy, dz);
+      // (the same four-coefficient steps as the half-row route: one piece of code, one rounding behaviour -- the in-kernel
+      // LOD interpolation must give the bits of the Python glue's rows rendered by the plain call)
+      float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      sh48_accumulate4<JAC, 0>(a.sh_degree, dx, dy, dz, sh, rgb, Jt);
+      sh48_accumulate4<JAC, 4>(a.sh_degree, dx, dy, dz, sh + 12, rgb, Jt);
+      sh48_accumulate4<JAC, 8>(a.sh_degree, dx, dy, dz, sh + 24, rgb, Jt);
+      sh48_accumulate4<JAC, 12>(a.sh_degree, dx, dy, dz, sh + 36, rgb, Jt);
       if constexpr (JAC) {
-        // d(rgb)/d(direction) for the backward's SH kernel (it would otherwise read the 3M coefficients again just to
-        // form these nine sums): J[d][c] = sum_k db_k/d(dir_d) * sh[k][c]
-        float dbx[16], dby[16], dbz[16];
-        sh_basis_grad(a.sh_degree, dx, dy, dz, dbx, dby, dbz);
-        float J[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          if (k < nb) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              J[0 + c] += dbx[k] * sh[k * 3 + c];
-              J[3 + c] += dby[k] * sh[k * 3 + c];
-              J[6 + c] += dbz[k] * sh[k * 3 + c];
-            }
-          }
-        }
         // rows of kJacStride = 12 floats: three 16-byte stores per lane, a wave writes 3 KB of whole cache lines (nine
         // dword stores at a 36-byte stride touched every line of the block nine times)
         float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-        jd[0] = make_float4(J[0], J[1], J[2], J[3]);
-        jd[1] = make_float4(J[4], J[5], J[6], J[7]);
-        jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
+        jd[0] = make_float4(Jt[0], Jt[1], Jt[2], Jt[3]);
+        jd[1] = make_float4(Jt[4], Jt[5], Jt[6], Jt[7]);
+        jd[2] = make_float4(Jt[8], 0.f, 0.f, 0.f);
       }
+      float r0 = rgb[0], r1 = rgb[1], r2 = rgb[2];
       r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
       if (r0 < 0.f) { r0 = 0.f; flags |= 1u; }
       if (r1 < 0.f) { r1 = 0.f; flags |= 2u; }
@@ -697,24 +711,57 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     }
   }
   // ---- the record and the per-Gaussian arrays ----------------------------------------------------------------------------
-  if (idx < a.P) {
-    if (pr.visible) {
-      const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) |
-                                ((uint32_t)(pr.maxx - pr.minx) << 20);
-      float4* recp = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
-      recp[0] = make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2);
-      recp[1] = make_float4(rec.C2, rec.opac, rgb[0], rgb[1]);
-      recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
-      recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
+  const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) | ((uint32_t)(pr.maxx - pr.minx) << 20);
+  bool rows_stored = false;
+  if constexpr (H48 && HGS_K1_COALESCED_STORES) {
+    if (coop && !K1X(4)) {                 // (uniform; the wave's 6 KB of the half-row image are its own by now)
+      rows_stored = true;
+      float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) + (threadIdx.x >> 6) * (kHalfBytes / (kPreBlock / 64)));
+      const unsigned long long vmask = __ballot(vis);
+      const size_t row0 = (size_t)blockIdx.x * kPreBlock + (threadIdx.x & ~63u);
+      if (!K1X(1)) {
+        const float4 r4[4] = {make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2), make_float4(rec.C2, rec.opac, rgb[0], rgb[1]),
+                              make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits)),
+                              make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y)};
+        wave_store_rows<4>(reinterpret_cast<float4*>(g.records), row0, r4, vmask, wl);
+      }
+      if constexpr (JAC) {
+        if (!K1X(2)) {
+          const float4 j4[3] = {make_float4(J[0], J[1], J[2], J[3]), make_float4(J[4], J[5], J[6], J[7]),
+                                make_float4(J[8], 0.f, 0.f, 0.f)};
+          wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), row0, j4, vmask, wl);
+        }
+      }
     }
-    // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
-    reinterpret_cast<uint2*>(g.rects)[idx] =
-        pr.visible ? make_uint2((uint32_t)pr.minx | ((uint32_t)pr.miny << 16), (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16))
-                   : make_uint2(0u, 0u);
-    radii[idx] = rad;
-    g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
-    g.tiles_touched[idx] = touched;
-    g.flags[idx] = flags;
+  }
+  if (idx < a.P) {
+    if (pr.visible && !rows_stored) {
+      if (!K1X(1)) {
+        float4* recp = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
+        recp[0] = make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2);
+        recp[1] = make_float4(rec.C2, rec.opac, rgb[0], rgb[1]);
+        recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
+        recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
+      }
+      if constexpr (H48 && JAC) {
+        if (!K1X(2)) {
+          float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
+          jd[0] = make_float4(J[0], J[1], J[2], J[3]);
+          jd[1] = make_float4(J[4], J[5], J[6], J[7]);
+          jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
+        }
+      }
+    }
+    if (!K1X(16)) {
+      // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
+      reinterpret_cast<uint2*>(g.rects)[idx] =
+          pr.visible ? make_uint2((uint32_t)pr.minx | ((uint32_t)pr.miny << 16), (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16))
+                     : make_uint2(0u, 0u);
+      radii[idx] = rad;
+      g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
+      g.tiles_touched[idx] = touched;
+      g.flags[idx] = flags;
+    }
   }
 }
 
@@ -1201,9 +1248,8 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
     const float gr[3] = {drgb[idx * 3 + 0], drgb[idx * 3 + 1], drgb[idx * 3 + 2]};
     float pm[3];
     load_mean<LOD>(a, lod_row_gather<LOD>(a, idx), pm);
-    const float dx = pm[0] - a.campos[0], dy = pm[1] - a.campos[1], dz = pm[2] - a.campos[2];
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+    float ux, uy, uz;
+    const float inv = unit_dir(pm, a.campos, ux, uy, uz);
     float b[16];
     sh_basis(a.sh_degree, ux, uy, uz, b);
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
@@ -1418,9 +1464,9 @@ __device__ __forceinline__ void sh_bwd_batched_body(const ShBwdViews& v, int P, 
 #pragma unroll
         for (int i = 0; i < 48; ++i) dotc[i / 3] += (i % 3 == 0 ? gr0 : i % 3 == 1 ? gr1 : gr2) * sh_reg[i];
       }
-      const float dx = px - v.campos[w][0], dy = py - v.campos[w][1], dz = pz - v.campos[w][2];
-      const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-      const float ux = dx * inv, uy = dy * inv, uz = dz * inv;
+      const float pxyz[3] = {px, py, pz};
+      float ux, uy, uz;
+      const float inv = unit_dir(pxyz, v.campos[w], ux, uy, uz);
       {
         float b[16];
         sh_basis(sh_degree, ux, uy, uz, b);
@@ -1502,9 +1548,9 @@ __global__ __launch_bounds__(kPreBlock) void sh_colors_batched_kernel(ShFwdViews
   const float px = means3D[idx * 3 + 0], py = means3D[idx * 3 + 1], pz = means3D[idx * 3 + 2];
   const int nb = (sh_degree + 1) * (sh_degree + 1);
   for (int w = 0; w < v.n; ++w) {
-    float dx = px - v.campos[w][0], dy = py - v.campos[w][1], dz = pz - v.campos[w][2];
-    const float inv = 1.0f / sqrtf(dx * dx + dy * dy + dz * dz);
-    dx *= inv; dy *= inv; dz *= inv;
+    const float pxyz[3] = {px, py, pz};
+    float dx, dy, dz;
+    unit_dir(pxyz, v.campos[w], dx, dy, dz);
     float b[16];
     sh_basis(sh_degree, dx, dy, dz, b);
     float r0 = 0.f, r1 = 0.f, r2 = 0.f;

@@ -33,6 +33,7 @@ from oracle import raster_oracle as ro
 pytestmark = pytest.mark.gpu
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+F32_ORACLE = os.environ.get("HGS_F32_ORACLE", "1") != "0"     # the float32-oracle reference figures (costs one more oracle pass)
 
 
 def _log(payload):
@@ -121,6 +122,40 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
     loss.backward()
     og = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=rot.grad)
 
+    # ---- whose error is it?  The SAME oracle with the kernels' precision split (per-Gaussian stage in float64, blend and
+    # its backward in float32) against the float64 oracle: what float32 arithmetic costs on this scene whatever the
+    # implementation.  Fragile pixels leave both losses (their decisions may differ by precision).
+    f32 = {}
+    if F32_ORACLE:
+        okd = torch.from_numpy(~oo.fragile)
+        m3f, scf, rotf, opf, shf = map(req, (sub_scene.means3D, sub_scene.scales, sub_scene.rotations,
+                                             sub_scene.opacities, sub_scene.shs))
+        m2f = torch.zeros(sub_scene.P, 3, requires_grad=True)
+        of = ro.rasterize(m3f, m2f, shf, None, opf, scf, rotf, None, image_height=H, image_width=W, tanfovx=cam.tanfovx,
+                          tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0, viewmatrix=cam.world_view_transform,
+                          projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree, campos=cam.camera_center,
+                          interpolation_weights=None if w is None else w[sub_t],
+                          num_node_kids=None if kids is None else kids[sub_t], tiles=tiles, dtype=torch.float32,
+                          geom_dtype=torch.float64)
+        okf = okd & torch.from_numpy(~of.fragile)
+        lf = (of.color * (gc_m * okf).to(of.color.dtype)).sum()
+        if do_depth:
+            lf = lf + (of.invdepth * (gd_m * okf).to(of.invdepth.dtype)).sum()
+        lf.backward()
+        # the float64 gradients of the same (fragile-free) loss
+        for t in (m3, m2, op, sh, sc, rot):
+            t.grad = None
+        l64 = (oo.color * (gc_m * okf).double()).sum()
+        if do_depth:
+            l64 = l64 + (oo.invdepth * (gd_m * okf).double()).sum()
+        l64.backward()
+        ref64 = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=rot.grad)
+        got32 = dict(means3D=m3f.grad, means2D=m2f.grad, opacities=opf.grad, shs=shf.grad, scales=scf.grad,
+                     rotations=rotf.grad)
+        for k in ref64:
+            st = pa.err_stats(got32[k], ref64[k])
+            f32["d_" + k] = dict(mixed=st["mixed"], p999_rel=st["p999_rel"], maxrel=st["maxrel"])
+
     # ---- compare ---------------------------------------------------------------------------------------------------
     ok = mask & torch.from_numpy(~oo.fragile)
     stats = {"fragile_frac": float(oo.fragile[mask.numpy()].mean()), "rows_touching_fragile": pa.rows_touching_fragile(oo)}
@@ -138,13 +173,20 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
         nonzero_outside[k] = int((hg[outside] != 0).reshape(int(outside.sum()), -1).any(dim=1).sum())
     payload = dict(case=name, P=P, W=W, H=H, L=int(binning.num_rendered), tiles=len(tiles),
                    tile_instances_sampled=int(per_tile[tiles].sum()), longest_list=int(per_tile.max()),
-                   sub_scene=int(sub.shape[0]), indices=idx, stats=stats, nonzero_rows_outside=nonzero_outside)
+                   sub_scene=int(sub.shape[0]), indices=idx, stats=stats, nonzero_rows_outside=nonzero_outside,
+                   float32_oracle_vs_float64=f32)
     _log(payload)
     print(json.dumps(payload, default=float))
     assert stats["fragile_frac"] <= pa.FRAGILE_FRAC
     assert stats["n_contrib_mismatch"] == 0
     assert all(v == 0 for v in nonzero_outside.values()), nonzero_outside
-    pa.assert_stats(name, stats)
+    # norm-wise 1e-5 on everything; element-wise: within the mixed bound, or within 1.5 x what the float32 ORACLE loses
+    # against float64 on the same tiles (a float32 sum over a tile's pixels has that error whoever evaluates it)
+    for k, v in stats.items():
+        if not isinstance(v, dict):
+            continue
+        allow = max(1.0, 1.5 * f32.get(k, {}).get("mixed", 0.0))
+        pa.assert_stats(name, {k: v}, mixed_tol=allow)
 
 
 def test_config2_300k_1080p(gpu):
