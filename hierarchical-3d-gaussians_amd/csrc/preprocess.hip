@@ -511,15 +511,18 @@ __device__ __forceinline__ void wave_store_rows(float4* __restrict__ dst, size_t
   __builtin_amdgcn_wave_barrier();               // (the next use of wave_lds overwrites it)
 }
 
-template <bool JAC, bool LOD, bool DEFER, bool H48>
+template <bool JAC, bool LOD, bool DEFER, bool H48, bool GEOM_ONLY = false>
                                 // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
                                 // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
                                 // ahead of the double-precision chain (their own instantiations: the extra state
                                 // would cost every other caller of K1 its occupancy); H48: plain [P, 16, 3] block in
-                                // two halves straight into LDS (above; DEFER and LOD do not apply)
+                                // two halves straight into LDS (above; DEFER and LOD do not apply); GEOM_ONLY (with
+                                // H48): everything but the colour -- the record's colour slots are left zero and
+                                // preprocess_color_h48_kernel (below) fills them in, concurrently with the binning
 __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, const GeomWs& g,
                                                     int32_t* __restrict__ radii, uint32_t* __restrict__ super) {
   static_assert(!(H48 && (LOD || DEFER)), "the half-row route is the plain layout's");
+  static_assert(!GEOM_ONLY || (H48 && !JAC), "the geometry-only kernel is the half-row route's first part");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds_sh = reinterpret_cast<float*>(smem_raw);
   __shared__ uint32_t wave_tot[kPreBlock / 64];
@@ -580,7 +583,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   // SH coefficients: stream the workgroup's block through LDS when most of it is visible (coalesced),
   // fall back to per-lane loads (visible lanes only) when most of the block is culled.
   bool coop = false, deferred = false;
-  const bool sh_lds = a.shs && (shn & 3) == 0;
+  const bool sh_lds = !GEOM_ONLY && a.shs && (shn & 3) == 0;
   const int nvis = __syncthreads_count(pr.visible);        // (also orders wave_tot / band_cnt)
   if (threadIdx.x < 64) {                                  // (wave 0) raw sums; with `super` also into the superblock totals
     uint32_t mine = 0;
@@ -646,7 +649,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   float rgb[3] = {0.f, 0.f, 0.f};
   const bool vis = idx < a.P && pr.visible;
   float J[JAC ? 9 : 1];
-  if constexpr (H48) {            // (launched with a.shs only)
+  if constexpr (GEOM_ONLY) {
+    // (colour, clamp flags and Jacobian: preprocess_color_h48_kernel)
+  } else if constexpr (H48) {     // (launched with a.shs only)
     float dx, dy, dz;
     unit_dir(p, cam.cam, dx, dy, dz);
     float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -714,7 +719,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) | ((uint32_t)(pr.maxx - pr.minx) << 20);
   bool rows_stored = false;
   if constexpr (H48 && HGS_K1_COALESCED_STORES) {
-    if (coop && !K1X(4)) {                 // (uniform; the wave's 6 KB of the half-row image are its own by now)
+    if ((GEOM_ONLY || coop) && !K1X(4)) {  // (uniform; the wave's 6 KB of the half-row image are its own by now)
       rows_stored = true;
       float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) + (threadIdx.x >> 6) * (kHalfBytes / (kPreBlock / 64)));
       const unsigned long long vmask = __ballot(vis);
@@ -780,6 +785,81 @@ __global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_fwd_h4
                                                                                          int32_t* __restrict__ radii,
                                                                                          uint32_t* __restrict__ super) {
   preprocess_fwd_body<JAC, false, false, true>(a, g, radii, super);
+}
+
+// ---- K1 in two kernels (M = 16, plain layout, single-call forward) -------------------------------------------------------
+// The binning that follows K1 (K3, the counting partition, the per-tile depth sort: ~110 us of small, latency-bound
+// kernels at the metric configuration) needs K1's RECTANGLES AND DEPTHS, not its colours; the colours are first read by
+// K6.  And the colour part of K1 is its bandwidth: 192 of the 236 bytes it reads per Gaussian and the 48-byte Jacobian row
+// (profiles/r05_k1_anatomy.txt: 30 + 13 of its 80 us).  So the half-row route is split:
+//   preprocess_geom_h48_kernel   on the caller's stream: everything but the colour (44 bytes in per Gaussian); the
+//                                record's three colour floats are left zero;
+//   preprocess_color_h48_kernel  on a second stream of the library, started when the first has finished, running NEXT TO
+//                                the binning kernels: SH block (two halves by LDS DMA), colour into bytes 24..35 of the
+//                                record, the clamp bits into the flags word, the Jacobian row;
+// and K6 waits for the second (abi.cpp).  The frame's critical path loses what the colour kernel takes (~50 us).
+template <bool JAC>
+__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_color_h48_kernel(hgs_raster_args a, GeomWs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* lds_sh = reinterpret_cast<float*>(smem_raw);
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  // every ordinary load up here (see the fused kernel): visibility, the mean, the flags word the clamp bits go into
+  const bool vis = idx < a.P && g.tiles_touched[idx] != 0u;
+  float p[3] = {0.f, 0.f, 1.f};
+  uint32_t flags = 0;
+  if (idx < a.P) {
+    p[0] = a.means3D[(size_t)idx * 3 + 0]; p[1] = a.means3D[(size_t)idx * 3 + 1]; p[2] = a.means3D[(size_t)idx * 3 + 2];
+    flags = g.flags[idx];
+  }
+  const float cam[3] = {a.campos[0], a.campos[1], a.campos[2]};
+  const bool coop = __syncthreads_count(vis) * 2 >= kPreBlock;
+  if (coop) sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+  float dx, dy, dz;
+  unit_dir(p, cam, dx, dy, dz);
+  float rgb[3] = {0.f, 0.f, 0.f};
+  float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (coop) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of half 0 has landed before any wave passes the barrier
+    __syncthreads();
+    const bool second = a.sh_degree > 1;                 // coefficients 8 .. 15 belong to degrees 2 and 3
+    sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+    if (second) {
+      __syncthreads();                                   // every lane has read its half 0: the image may be replaced
+      sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+    }
+  } else if (vis) {
+    sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, Jt);
+  }
+  if (vis) {
+    uint32_t cbits = 0;
+    rgb[0] += 0.5f; rgb[1] += 0.5f; rgb[2] += 0.5f;
+    if (rgb[0] < 0.f) { rgb[0] = 0.f; cbits |= 1u; }
+    if (rgb[1] < 0.f) { rgb[1] = 0.f; cbits |= 2u; }
+    if (rgb[2] < 0.f) { rgb[2] = 0.f; cbits |= 4u; }
+    if (cbits) g.flags[idx] = flags | cbits;
+    float* rp = g.records + (size_t)idx * kRecFloats + 6;        // q1.z, q1.w, q2.x
+    rp[0] = rgb[0]; rp[1] = rgb[1]; rp[2] = rgb[2];
+  }
+  if constexpr (JAC) {
+    const float4 j4[3] = {make_float4(Jt[0], Jt[1], Jt[2], Jt[3]), make_float4(Jt[4], Jt[5], Jt[6], Jt[7]),
+                          make_float4(Jt[8], 0.f, 0.f, 0.f)};
+    if (coop && HGS_K1_COALESCED_STORES) {               // (uniform; the wave's own 6 KB of the image, see the fused kernel)
+      float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) + (threadIdx.x >> 6) * (kHalfBytes / (kPreBlock / 64)));
+      wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), (size_t)blockIdx.x * kPreBlock + (threadIdx.x & ~63u), j4,
+                         __ballot(vis), wl);
+    } else if (vis) {
+      float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
+      jd[0] = j4[0]; jd[1] = j4[1]; jd[2] = j4[2];
+    }
+  }
+}
+__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_geom_h48_kernel(hgs_raster_args a, GeomWs g,
+                                                                                          int32_t* __restrict__ radii,
+                                                                                          uint32_t* __restrict__ super) {
+  preprocess_fwd_body<false, false, false, true, true>(a, g, radii, super);
 }
 
 // Exclusive scan of the per-workgroup sums (nblk = P/256): grid row 0 scans block_sums, rows 1..kBands the columns of
@@ -1641,20 +1721,41 @@ void super_block_mark_dirty(const uint32_t* words) {
     if (g_sync[i].words == words) g_sync[i].dirty = true;
 }
 
-int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super) {
+bool preprocess_fwd_splits(const hgs_raster_args& a) {
+  static const bool fused = getenv("HGS_K1_FUSED") != nullptr;      // diagnostic: K1 as one kernel
+  return !fused && a.P > 0 && a.shs && !a.shs_rest && !a.lod_render_indices && a.M == 16;
+}
+
+int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super,
+                          bool geometry_only) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     const bool jac = a.prepare_backward && a.shs;
     const bool plain = a.shs && !a.shs_rest && !a.lod_render_indices && ((a.M * 3) & 3) == 0;
     const bool h48 = plain && a.M == 16;
     const bool defer = plain && !h48;
+    if (geometry_only && !h48) { set_error("launch_preprocess_fwd: the geometry-only kernel needs the plain M = 16 layout"); return HGS_ERR_INVALID; }
     const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)kHalfBytes : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-    auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
-              : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
-              : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
-                      : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
-    hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
+    if (geometry_only) {
+      hipLaunchKernelGGL(preprocess_geom_h48_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
+    } else {
+      auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
+                : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
+                : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
+                        : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
+      hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
+    }
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
+  }
+  return HGS_OK;
+}
+
+int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream_t s) {
+  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
+  if (nblk > 0) {
+    auto k = (a.prepare_backward && a.shs) ? preprocess_color_h48_kernel<true> : preprocess_color_h48_kernel<false>;
+    hipLaunchKernelGGL(k, dim3(nblk), dim3(kPreBlock), (size_t)kHalfBytes, s, a, g);
+    HGS_LAUNCH_CHECK("preprocess_color", s, a.debug);
   }
   return HGS_OK;
 }
