@@ -227,8 +227,11 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
 // dmean_rows / lod_flag: scratch of the in-kernel LOD scatter (hgs_raster_args.lod_scatter): the per-row mean gradient
 // K8a hands to K8b, and the "parent indices are not non-decreasing" word (set by launch_lod_monotone)
+// L: the frame's instance count (a frame of long runs sums them with a kernel of its own in front of K8a; inst_grads is
+// consumed: that kernel leaves a long run's sums over the run's first records)
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
-                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, hipStream_t s);
+                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, uint32_t L,
+                          hipStream_t s);
 int launch_lod_monotone(const int32_t* parent_indices, int32_t n, uint32_t* flag, hipStream_t s);
 // Per-view device pointers of the batched SH kernels.  Kept small (24 pointers): they are kernel arguments and must
 // stay in scalar registers across the view loop.

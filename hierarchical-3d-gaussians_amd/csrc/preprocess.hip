@@ -917,6 +917,59 @@ __device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
   if (atomic) atomicAdd(dst, v); else *dst = v;
 }
 
+// ---- long runs of instance records (K8a) ------------------------------------------------------------------------------
+// K8a sums each Gaussian's run of instance records (one lane per Gaussian).  Benchmark scenes have 2.7 records per
+// Gaussian; a TRAINED scene at 1080p has 28 on average and Gaussians that cover thousands of tiles (the 1080p run of
+// profiles/r05_config2_config3_scripts_run1.log: K8 1.9 ms of a 3.6 ms frame, 11.7 ms on a hierarchy cut -- one lane
+// walking 3 000 records while 63 wait).  When the frame's mean run is long (launch_preprocess_bwd) this kernel runs in
+// front of K8a: one wave per 64 Gaussians, every run of more than kK8LongRun records is summed by the WHOLE wave
+// (lane i takes records i, i + 64, ...: consecutive 40-byte records, coalesced; double-precision partial sums; lanes
+// 0 .. 9 fold the 64 partials of one component each) and the ten sums are stored, as doubles, OVER THE RUN'S FIRST TWO
+// RECORDS -- the run is consumed, nobody else reads it.  K8a then takes a long run's sums from there.
+constexpr uint32_t kK8LongRun = 48;
+__global__ __launch_bounds__(kPreBlock) void k8_presum_long_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                                   const uint32_t* __restrict__ offsets,
+                                                                   float* __restrict__ inst) {
+  __shared__ double red_all[kPreBlock / 64][640];
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
+  unsigned long long todo = __ballot(n > kK8LongRun);
+  if (todo == 0ull) return;
+  const uint32_t off_mine = n > kK8LongRun ? offsets[idx] : 0u;
+  double* red = red_all[threadIdx.x >> 6];
+  while (todo) {                                                         // (wave-uniform)
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    const uint32_t rn = (uint32_t)__shfl((int)n, owner, 64);
+    const size_t rbase = (size_t)__shfl(off_mine, owner, 64);
+    const float2* ip = reinterpret_cast<const float2*>(inst) + rbase * 5;
+    double t[10];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) t[i] = 0.0;
+#pragma unroll 4
+    for (uint32_t k = (uint32_t)lane; k < rn; k += 64u) {
+      const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
+      t[0] += v0.x; t[1] += v0.y; t[2] += v1.x; t[3] += v1.y;
+      t[4] += v2.x; t[5] += v2.y; t[6] += v3.x; t[7] += v3.y;
+      t[8] += v4.x; t[9] += v4.y;
+    }
+#pragma unroll
+    for (int i = 0; i < 10; ++i) red[i * 64 + lane] = t[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 10) {
+      double acc = 0.0;
+#pragma unroll 8
+      for (int j = 0; j < 64; ++j) acc += red[lane * 64 + j];
+      reinterpret_cast<double*>(inst + rbase * kInstStride)[lane] = acc;   // (40-byte records: 8-byte aligned)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                     // (the next long run overwrites the scratch)
+  }
+}
+
 #ifndef HGS_K8_STAGE
 #define HGS_K8_STAGE 1     // 0: every lane walks its run of instance records in global memory (round 3; kept for A/B runs)
 #endif
@@ -931,7 +984,7 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
                                                                    float* __restrict__ drgb,
                                                                    float* __restrict__ dmean_rows,
                                                                    const uint32_t* __restrict__ lod_flag,
-                                                                   hgs_raster_grads out) {
+                                                                   hgs_raster_grads out, int presummed) {
   const int idx = blockIdx.x * kPreBlock + threadIdx.x;
   const bool in_range = idx < a.P;
   const uint32_t n = in_range ? g.tiles_touched[idx] : 0u;   // (out-of-range lanes stay for the wave-wide staging below)
@@ -946,68 +999,92 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
 #pragma unroll
   for (int i = 0; i < 10; ++i) s[i] = 0.0;
   static_assert(kInstStride == 10, "instance record = the ten sums, 40 bytes");
-#if HGS_K8_STAGE
+  // Two routes per wave:
+  //   * (always in frames of short runs, launch_preprocess_bwd) the wave streams its contiguous range of records through
+  //     LDS, each lane sums its own run from there;
+  //   * `presummed` and a run of more than kK8LongRun records in the wave: k8_presum_long_kernel left that run's ten sums
+  //     at its start; the other lanes walk their short runs in global memory (the wave's range is mostly the long run).
   {
     constexpr uint32_t kStageRec = 256;                                  // records per wave and pass: 10 KB
     __shared__ float2 stage[kPreBlock / 64][kStageRec * 5];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = n;
+    const unsigned long long long_mask = presummed ? __ballot(n > kK8LongRun) : 0ull;
+    if (long_mask == 0ull) {
+#if HGS_K8_STAGE
+      uint32_t incl = n;
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
-    }
-    const uint32_t my0 = incl - n, my1 = incl;                           // this lane's run, in records of the wave's range
-    const uint32_t total = __shfl(incl, 63, 64);
-    if (total) {                                                         // (wave-uniform)
-      const unsigned long long nz = __ballot(n != 0u);
-      const int first = __ffsll((long long)nz) - 1;
-      const uint32_t off_mine = n ? g.offsets[idx] : 0u;
-      const size_t base = (size_t)__shfl(off_mine, first, 64);           // (no instances before the first non-empty lane)
-      float2* st = stage[wave];
-      for (uint32_t c0 = 0; c0 < total; c0 += kStageRec) {
-        const uint32_t cn = min(kStageRec, total - c0) * 5u;             // float2 words of this pass
-        const float2* src = reinterpret_cast<const float2*>(inst) + (base + c0) * 5;
-        for (uint32_t t0 = 0; t0 < cn; t0 += 64u * 4u) {                 // four loads in flight per lane
-          float2 v[4];
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
+      const uint32_t my0 = incl - n, my1 = incl;                         // this lane's run, in records of the wave's range
+      const uint32_t total = __shfl(incl, 63, 64);
+      if (total) {                                                       // (wave-uniform)
+        const unsigned long long nz = __ballot(n != 0u);
+        const int first = __ffsll((long long)nz) - 1;
+        const uint32_t off_mine = n ? g.offsets[idx] : 0u;
+        const size_t base = (size_t)__shfl(off_mine, first, 64);         // (no instances before the first non-empty lane)
+        float2* st = stage[wave];
+        for (uint32_t c0 = 0; c0 < total; c0 += kStageRec) {
+          const uint32_t cn = min(kStageRec, total - c0) * 5u;           // float2 words of this pass
+          const float2* src = reinterpret_cast<const float2*>(inst) + (base + c0) * 5;
+          for (uint32_t t0 = 0; t0 < cn; t0 += 64u * 4u) {               // four loads in flight per lane
+            float2 v[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
-            v[j] = src[min(t, cn - 1u)];
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
+              v[j] = src[min(t, cn - 1u)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
+              if (t < cn) st[t] = v[j];
+            }
           }
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t t = t0 + (uint32_t)j * 64u + (uint32_t)lane;
-            if (t < cn) st[t] = v[j];
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          const uint32_t k0 = max(my0, c0), k1 = min(my1, c0 + kStageRec);
+          for (uint32_t k = k0; k < k1; ++k) {
+            const float2* r = st + (k - c0) * 5u;
+            const float2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
+            s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+            s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
+            s[8] += v4.x; s[9] += v4.y;
           }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();                               // (the next pass overwrites the stage)
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t k0 = max(my0, c0), k1 = min(my1, c0 + kStageRec);
-        for (uint32_t k = k0; k < k1; ++k) {
-          const float2* r = st + (k - c0) * 5u;
-          const float2 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3], v4 = r[4];
+      }
+#else
+      if (n) {
+        const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
+        for (uint32_t k = 0; k < n; ++k) {
+          const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
           s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
           s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
           s[8] += v4.x; s[9] += v4.y;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                 // (the next pass overwrites the stage)
+      }
+#endif
+    } else if (n != 0u) {
+      const size_t off = (size_t)g.offsets[idx];
+      if (n > kK8LongRun) {
+        const double* ps = reinterpret_cast<const double*>(inst + off * kInstStride);
+#pragma unroll
+        for (int i = 0; i < 10; ++i) s[i] = ps[i];
+      } else {
+        const float2* ip = reinterpret_cast<const float2*>(inst) + off * 5;
+#pragma unroll 2
+        for (uint32_t k = 0; k < n; ++k) {
+          const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
+          s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
+          s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
+          s[8] += v4.x; s[9] += v4.y;
+        }
       }
     }
   }
-#else
-  if (n) {
-    const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
-    for (uint32_t k = 0; k < n; ++k) {
-      const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
-      s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
-      s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
-      s[8] += v4.x; s[9] += v4.y;
-    }
-  }
-#endif
   if constexpr (!LOD) {
     if (!in_range) return;
   }
@@ -1789,12 +1866,22 @@ int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug
 }
 
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
-                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, hipStream_t s) {
+                          float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, uint32_t L,
+                          hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
+    // long runs first, when the frame has them: mean run above 6 records (L > 6 P; HGS_K8_PRESUM=0 / 1 forces)
+    static const char* force = getenv("HGS_K8_PRESUM");
+    const bool presum = force ? force[0] == '1' : (uint64_t)L > 6ull * (uint64_t)a.P;
+    if (presum) {
+      hipLaunchKernelGGL(k8_presum_long_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.tiles_touched, g.offsets,
+                         const_cast<float*>(inst_grads));
+      HGS_LAUNCH_CHECK("preprocess_bwd_long_runs", s, a.debug);
+    }
     auto k8a = a.lod_render_indices ? preprocess_bwd_kernel<false, true>      // (accumulation is refused with lod, abi.cpp)
                                     : (a.accumulate_grads ? preprocess_bwd_kernel<true, false> : preprocess_bwd_kernel<false, false>);
-    hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, dmean_rows, lod_flag, out);
+    hipLaunchKernelGGL(k8a, dim3(nblk), dim3(kPreBlock), 0, s, a, g, inst_grads, drgb, dmean_rows, lod_flag, out,
+                       presum ? 1 : 0);
     HGS_LAUNCH_CHECK("preprocess_bwd", s, a.debug);
     if (a.shs && out.dL_dshs && !a.defer_sh_bwd) {
       const size_t lds_bytes = (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);

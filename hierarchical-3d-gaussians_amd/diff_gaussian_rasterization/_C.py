@@ -223,6 +223,15 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # with lod= the number of rendered rows changes with every cut: the hierarchy (its row count) is the workload
     shape_key = (devi, W, H, P) if lod is None else (devi, W, H, "lod", means3D.shape[0])
     prev = _last_L.get(shape_key) if SPECULATIVE else None
+    any_key = (devi, W, H, "any")
+    if prev is None and SPECULATIVE and lod is None and P > 0:
+        # A row count never seen at this resolution -- train_post.py hands the op another cut every iteration
+        # (gaussian_renderer/__init__.py:199-235 gathers the rows before the call), densification changes P every 300:
+        # scale the last frame's instance count of this resolution by the ratio of the row counts instead of falling
+        # back to the two-stage path with its host round trip (1080p run of round 5: 92 % of train_post's calls did)
+        near = _last_L.get(any_key)
+        if near is not None and near[0] > 0 and 0.25 <= P / near[0] <= 4.0:
+            prev = int(near[1] * (P / near[0])) + 1
     L_ws = 0
     done = False
     if prev is not None and P > 0:
@@ -274,6 +283,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
     _last_L.pop(shape_key, None)                       # (re-inserted at the end: the dict is kept in order of last use)
     _last_L[shape_key] = L.value if lod is None else max(L.value, int(0.9 * (prev or 0)))
+    if lod is None and P > 0:
+        _last_L.pop(any_key, None)
+        _last_L[any_key] = (P, L.value)
     while len(_last_L) > 64:                           # forget the shape that was used longest ago
         _last_L.pop(next(iter(_last_L)))
     stats["last_L"] = L.value

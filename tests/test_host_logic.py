@@ -295,6 +295,11 @@ def test_forward_arena_layout_against_the_real_size_functions(monkeypatch):
     call = fwd(P, True)
     assert call.L_ws == first_plan                           # the quantised capacity repeats: a plan-cache hit
     fake.calls.clear()
+    call = fwd(P + 700, True)                                # another row count at this resolution (train_post.py: a new
+    assert [c[0] for c in fake.calls] == ["fwd"]             # cut every iteration): capacity scaled from the last frame
+    assert call.L_ws >= int(5000 * (P + 700) / P * Cm.SPEC_GROWTH)
+    bwd(call)
+    fake.calls.clear()
     fake.L_next = 10 ** 6                                    # the scene grew: capacity miss, exact second stage
     call = fwd(P, False)
     assert [c[0] for c in fake.calls] == ["fwd", "stage2"] and call.L_ws == 10 ** 6 and call.p_bwd == 0

@@ -818,3 +818,24 @@ def test_noncontiguous_inputs_and_inplace_update_detection(gpu):
         op.mul_(0.5)
     with pytest.raises(RuntimeError, match="modified by an inplace operation"):
         color.sum().backward()
+
+
+def test_large_footprints_take_the_long_run_route(gpu):
+    """Gaussians that cover tens to hundreds of tiles (a trained scene, a coarse hierarchy cut): 60 instance records per
+    Gaussian on average, runs of several hundred.  The backward sums such runs with a wave per run in front of K8a
+    (k8_presum_long_kernel, preprocess.hip; the frame's mean run decides) -- pixels, indices and every gradient against
+    the oracle."""
+    W, H, P = 320, 192, 1200
+    cam = synth.make_camera(W, H)
+    scene = synth.make_scene(P, cam, seed=29, s_px=(6.0, 40.0))
+    scene.opacities = scene.opacities * 0.35                  # keep the pixels from saturating behind a few layers
+    gc, gd = synth.upstream_grads(H, W, seed=5)
+    bg = torch.tensor([0.1, 0.0, 0.2])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    idx = pa.check_indices(hip, oo)
+    assert all(v == 0 for v in idx.values()), idx
+    tt = oo.geom.tiles_touched
+    assert hip["L"] > 6 * P and int(tt.max()) > 48 * 4, (hip["L"], int(tt.max()))
+    assert int(((tt > 0) & (tt <= 48)).sum()) > 0             # short runs next to long ones
+    pa.assert_stats("large footprints", pa.compare(hip, oo, og))
