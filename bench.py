@@ -518,6 +518,9 @@ def extra_config5(dev, steps, warmup, leaves=25_000_000, tau_px=3.0):
            "config": {"hierarchy_nodes": G, "leaves": leaves, "tau_px": tau_px, "mean_cut": nm, "width": W, "height": H,
                       "hierarchy_build_s": t_build, "resident_bytes": int(G * (59 * 4 + 28 + 32)),
                       "capacity_misses": misses,
+                      # the camera centres' host copies are remembered on the tensor objects here (a viewer loop
+                      # that keeps its Camera objects); a stock script pays one blocking 12-byte read per frame instead
+                      "viewpoint_cache": True,
                       "device_allocations_in_timed_region": seg_allocs,   # hipMalloc calls of the caching allocator
                       "expand_to_size_ms": cut_ms},     # host time of the cut incl. the wait for everything enqueued before it
            "stages_ms": stages}
@@ -626,6 +629,21 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
                                                   rotations=full["rotations"])[0]
         for i in range(min(3, steps)):
             resident(warmup + i, sels[i][1])
+        # how tight the regulation is (untimed): rows a view NEEDS at the granularity it settled at = its cut's node rows
+        # + the distinct parent rows of entries of weight < 1 (make_resident fetches nothing else), against the budget --
+        # and, for comparison, at one escalation step finer (tau / 1.2), the step the regulator could not take
+        mark = torch.zeros(G, dtype=torch.bool, device=dev)
+
+        def rows_needed(k, t):
+            n = expand_to_size(nodes, boxes, t, vps[k][0], torch.zeros(3), ri, pi, ni)
+            get_interpolation_weights(ni[:n], t, nodes, boxes, vps[k][1], torch.zeros(3), w, ns)
+            mark.zero_()
+            mark[ri[:n].long()] = True
+            lt1 = w[:n] < 1.0
+            mark[pi[:n].long()[lt1]] = True
+            return int(mark.sum().item()), n
+        need = [rows_needed(warmup + i, sels[i][1]) for i in range(steps)]
+        finer = [rows_needed(warmup + i, sels[i][1] / 1.2) for i in range(0, steps, max(1, steps // 4))]
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(steps):
             color_r = resident(warmup + i, sels[i][1])
@@ -653,6 +671,15 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
                        "rendered_tau_px": sum(px(s[1]) for s in sels) / len(sels),
                        "rendered_tau_px_range": [px(min(s[1] for s in sels)), px(max(s[1] for s in sels))],
                        "mean_cut": sum(s[0] for s in sels) / len(sels),
+                       "rows_needed_per_frame_min_median_max": [min(r for r, _ in need), sorted(r for r, _ in need)[len(need) // 2],
+                                                                max(r for r, _ in need)],
+                       "budget_occupancy_min_median_max": [min(r for r, _ in need) / bh.B, sorted(r for r, _ in need)[len(need) // 2] / bh.B,
+                                                           max(r for r, _ in need) / bh.B],
+                       "rows_needed_one_step_finer_over_budget": [r / bh.B for r, _ in finer],
+                       "occupancy_note": "rows_needed = node rows of the cut + distinct parent rows of entries of weight < 1 at "
+                                         "the granularity the frame settled at, over budget_rows; one_step_finer = the same at "
+                                         "tau / 1.2 (sampled frames): above 1 means the regulator's next finer step cannot fit",
+                       "viewpoint_cache": True,
                        "cuts_per_frame": sum(s[3] for s in sels) / len(sels),
                        "rows_fetched_per_frame": (bh.stats["rows_fetched"] - f0) / steps,
                        "rows_fetched_per_frame_min_median_max": [min(rows), sorted(rows)[len(rows) // 2], max(rows)],
@@ -1120,6 +1147,19 @@ def main():
             result["host_floor"] = host_floor
         if exchange is not None:
             result["exchange"] = exchange
+        if world > 1 and "dropin" in res and "batched" in res:
+            # the >= 6x question of north_star answered for BOTH schedules from one run: `batched` (k views per rank per
+            # step, one exchange per step) and the partition north_star describes -- one view per rank per optimizer step,
+            # global batch N, the 59 P-float gradient bucket all-reduced EVERY step, nothing to hide it under
+            pv, ex_ms = res["dropin"], (max(exchange["exchange_ms_per_rank"]) if exchange else None)
+            result["per_view_dp"] = {
+                "what": "north_star's partition: one view per rank per optimizer step (global batch N = n_gpus), all-reduce "
+                        "of the whole gradient bucket every step, one stream; compare value across N",
+                "value": pv["value"], "unit": "frames/s", "views_per_step_per_gpu": 1, "global_batch": world,
+                "ms_per_step": pv["ms_per_step"], "steps": pv["steps"],
+                "exchange_alone_ms": ex_ms,
+                "exchange_share_of_step": (ex_ms / pv["ms_per_step"]) if ex_ms else None,
+                "measured_on_hardware": True}
         for name, rr in res.items():
             result[name] = {"value": rr["value"], "unit": "frames/s", "views_per_step_per_gpu": rr["views_per_step_per_gpu"],
                             "steps": rr["steps"], "ms_per_step": rr["ms_per_step"],

@@ -41,6 +41,8 @@
 //    loop): a row's record address depends on a list entry that is itself in LDS, and at 4 waves per SIMD two dependent
 //    LDS round trips per iteration are not hidden by the other waves (K7 0.426 -> 0.385 ms; with the pixels' colour
 //    gradients in registers instead of LDS 0.339).
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -741,10 +743,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
 
 }  // namespace
 
+// Diagnostic (timing only, results incomplete): HGS_RENDER_GRID_LIMIT=n launches only the first n workgroups of K6 / K7 --
+// how the kernels' time scales with the number of tiles (launch tail, occupancy: profiles/r05_k6_k7_page.md).
+static int render_grid_limit(int nblk) {
+  static const char* e = getenv("HGS_RENDER_GRID_LIMIT");
+  if (!e) return nblk;
+  const int n = atoi(e);
+  return n > 0 && n < nblk ? n : nblk;
+}
+
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, hipStream_t s) {
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
-  const int nblk = ((T + 7) / 8) * 8;
+  const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth;
   auto kern = depth ? render_fwd_quad_kernel<true> : render_fwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
@@ -759,7 +770,7 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s) {
   (void)out_color;
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
-  const int nblk = ((T + 7) / 8) * 8;
+  const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
   auto kern = depth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,

@@ -211,3 +211,18 @@ def default_case(P, W, H, seed=0, sh_degree=3, fovy=60.0):
     scene = synth.make_scene(P, cam, seed=seed, sh_degree=sh_degree)
     gc, gd = synth.upstream_grads(H, W)
     return cam, scene, gc, gd
+
+
+def chain_to_raw(raw, og, opacity_activation="sigmoid"):
+    """The oracle's gradients w.r.t. the ACTIVATED attributes chained, in float64, through the activations of
+    scene/gaussian_model.py:108-128 (exp, normalize, sigmoid or abs, cat of features_dc / features_rest) to the model's
+    raw parameters.  raw: dict of float tensors (xyz, scaling, rotation, opacity, features_dc, features_rest); og: the
+    gradient dict of ``run_oracle``.  Returns {name: gradient w.r.t. raw[name]} (float64)."""
+    leaf = {k: v.detach().double().clone().requires_grad_(True) for k, v in raw.items()}
+    act = dict(means3D=leaf["xyz"], scales=torch.exp(leaf["scaling"]),
+               rotations=torch.nn.functional.normalize(leaf["rotation"]),
+               opacities=torch.sigmoid(leaf["opacity"]) if opacity_activation == "sigmoid" else torch.abs(leaf["opacity"]),
+               shs=torch.cat((leaf["features_dc"], leaf["features_rest"]), dim=1))
+    keys = [k for k in act if k in og]
+    torch.autograd.backward([act[k] for k in keys], [og[k].double().reshape(act[k].shape) for k in keys])
+    return {k: v.grad for k, v in leaf.items()}

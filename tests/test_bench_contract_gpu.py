@@ -76,3 +76,7 @@ def test_bench_two_ranks_as_the_driver_launches_them(gpu):
     ex = d["exchange"]
     assert ex["backend"] == "gloo" and len(ex["exchange_ms_per_rank"]) == 2 and all(t > 0 for t in ex["exchange_ms_per_rank"])
     assert ex["bytes_per_step"] == 20000 * 59 * 4 and ex["busbw_GBps"] > 0
+    # north_star's own partition beside it: one view per rank per step, the bucket exchanged every step
+    pv = d["per_view_dp"]
+    assert pv["global_batch"] == 2 and pv["views_per_step_per_gpu"] == 1 and pv["value"] > 0
+    assert abs(pv["value"] - 2 * 1e3 / pv["ms_per_step"]) <= 1e-6 * pv["value"] and 0 < pv["exchange_share_of_step"]

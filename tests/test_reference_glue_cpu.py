@@ -112,6 +112,24 @@ def test_render_render_post_render_coarse_run_unmodified(glue):
     assert pkg["viewspace_points"].grad is not None and pkg["viewspace_points"].grad.shape == (40, 3)
     assert pkg["viewspace_points"].grad[:, :2].abs().sum() > 0          # densification statistic is alive
 
+    # every gradient the glue produces against the oracle chained (float64) through the activations it applied
+    # (scene/gaussian_model.py:108-128); the twin of tests/test_reference_on_gpu.py, where the op is the HIP one
+    import parity as pa
+    pc = _PC(scene)
+    with torch.no_grad():
+        act = synth.Scene(pc.get_xyz.clone(), pc.get_scaling.clone(), pc.get_rotation.clone(), pc.get_opacity.clone(),
+                          pc.get_features.clone(), 3)
+    gc, gd = synth.upstream_grads(32, 48)
+    oo, og = pa.run_oracle(act, cam, bg, gc, gd, mask_fragile=False)
+    pkg = glue.render(_viewpoint(cam), pc, pipe, bg)
+    ((pkg["render"] * gc).sum() + (pkg["depth"] * gd).sum()).backward()
+    raw = dict(xyz=pc._xyz, scaling=pc._scaling, rotation=pc._rotation, opacity=pc._opacity,
+               features_dc=pc._features_dc, features_rest=pc._features_rest)
+    want = pa.chain_to_raw({k: v.detach() for k, v in raw.items()}, og)
+    for k, v in raw.items():
+        st = pa.err_stats(v.grad, want[k])
+        assert st["maxrel"] <= 1e-5 and st["l2"] <= 1e-5, (k, st)
+
     # --- render_coarse (train_coarse.py:94): debug forced True, do_depth False
     pc = _PC(scene)
     pkg = glue.render_coarse(_viewpoint(cam), pc, pipe, bg)

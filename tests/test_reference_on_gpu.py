@@ -90,7 +90,15 @@ def test_render_glue_on_the_hip_op_matches_the_oracle(gpu, monkeypatch):
     ok = torch.from_numpy(~oo.fragile)
     err = pa.err_stats(pkg["render"].detach().cpu()[:, ok], oo.color.detach()[:, ok])
     assert err["maxrel"] <= 1e-5, err
-    assert pa.err_stats(pc._xyz.grad.cpu(), og["means3D"])["maxrel"] <= 1e-5
+    # EVERY gradient the glue produces: the oracle's, chained in float64 through the activations the glue applied
+    # (exp / normalize / sigmoid / cat, scene/gaussian_model.py:108-128)
+    raw = dict(xyz=pc._xyz, scaling=pc._scaling, rotation=pc._rotation, opacity=pc._opacity,
+               features_dc=pc._features_dc, features_rest=pc._features_rest)
+    want = pa.chain_to_raw({k: v.detach().cpu() for k, v in raw.items()}, og)
+    for k, v in raw.items():
+        st = pa.err_stats(v.grad.cpu(), want[k])
+        assert st["maxrel"] <= 1e-5 and st["l2"] <= 1e-5, (k, st)
+    assert pa.err_stats(pkg["viewspace_points"].grad.cpu(), og["means2D"])["maxrel"] <= 1e-5
     assert torch.equal(pkg["radii"].cpu(), oo.radii[pkg["visibility_filter"].cpu()] if pkg["radii"].shape[0] != scene.P
                        else oo.radii)
     # the other two entry points of the glue run and return what their callers expect
@@ -106,5 +114,30 @@ def test_render_glue_on_the_hip_op_matches_the_oracle(gpu, monkeypatch):
     kids = torch.full((scene.P,), 2, dtype=torch.int32, device=gpu)
     pkg = glue.render_post(_viewpoint(dcam), pc, pipe, bg.to(gpu), render_indices=ri, parent_indices=pi,
                            interpolation_weights=w, num_node_kids=kids)
-    pkg["render"].sum().backward()
+    # render_post's image against the oracle fed with the rows the glue builds (gaussian_renderer/__init__.py:199-218:
+    # lerp of node and parent rows, quaternion sign alignment, abs opacity), restated here in the same float32 arithmetic
+    with torch.no_grad():                                  # the same float32 expressions on the same device: the same bits
+        rg, pg = ri.long(), pi[:n].long()
+        tg = w[:n].unsqueeze(1); tig = (1 - w[:n]).unsqueeze(1)
+        par, rot = pc.get_rotation[pg], pc.get_rotation[rg]
+        par[torch.bmm(rot.unsqueeze(1), par.unsqueeze(2)).flatten() < 0] *= -1
+        rows = synth.Scene((tg * pc.get_xyz[rg] + tig * pc.get_xyz[pg]).cpu(),
+                           (tg * pc.get_scaling[rg] + tig * pc.get_scaling[pg]).cpu(), ((tg * rot) + tig * par).cpu(),
+                           (tg * pc.get_opacity[rg] + tig * pc.get_opacity[pg]).cpu(),
+                           (tg.unsqueeze(2) * pc.get_features[rg] + tig.unsqueeze(2) * pc.get_features[pg]).cpu(), 3)
+    r_, p_ = rg.cpu(), pg.cpu()
+    t = w[:n].cpu().double().unsqueeze(1); ti = 1 - t
+    gcp, gdp = synth.upstream_grads(96, 160, seed=9)
+    oo2, og2 = pa.run_oracle(rows, cam, bg, gcp, gdp, interpolation_weights=w[:n].cpu(), num_node_kids=kids[:n].cpu(),
+                             do_depth=False)
+    ok2 = torch.from_numpy(~oo2.fragile)
+    err2 = pa.err_stats(pkg["render"].detach().cpu()[:, ok2], oo2.color.detach()[:, ok2])
+    assert err2["maxrel"] <= 1e-5, err2
+    (pkg["render"] * (gcp.to(gpu) * oo2.grad_mask.to(gpu))).sum().backward()
     assert pkg["visibility_filter"].shape == (n,) and pc._xyz.grad[:n].abs().sum() > 0
+    # the gradient reaching the node AND parent rows of _xyz: sum of the row gradients weighted by t / 1 - t
+    want_xyz = torch.zeros(scene.P, 3, dtype=torch.float64)
+    want_xyz.index_add_(0, r_, t * og2["means3D"].double())
+    want_xyz.index_add_(0, p_, ti * og2["means3D"].double())
+    st = pa.err_stats(pc._xyz.grad.cpu(), want_xyz)
+    assert st["maxrel"] <= 1e-5 and st["l2"] <= 1e-5, st
