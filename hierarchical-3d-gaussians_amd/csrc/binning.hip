@@ -167,12 +167,10 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
         tot += x;
         pre += (s0 + lane < sb) ? x : 0u;
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        pre += __shfl_xor(pre, off, 64);
-        tot += __shfl_xor(tot, off, 64);
-      }
-      if (lane == 0) { pre9[a] = pre; tot9[a] = tot; }
+      // (DPP scans, the total in lane 63: six register-file adds each instead of six trips through the LDS crossbar)
+      pre = wave_scan_incl(pre);
+      tot = wave_scan_incl(tot);
+      if (lane == 63) { pre9[a] = pre; tot9[a] = tot; }
     }
   }
   const uint32_t cnt = rect_count(myrect);

@@ -927,17 +927,19 @@ __device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
 // 0 .. 9 fold the 64 partials of one component each) and the ten sums are stored, as doubles, OVER THE RUN'S FIRST TWO
 // RECORDS -- the run is consumed, nobody else reads it.  K8a then takes a long run's sums from there.
 constexpr uint32_t kK8LongRun = 48;
+constexpr int kPresumPerWave = 8;        // Gaussians per wave: a hierarchy cut lists its big (interior) nodes side by side --
+                                         // 64 long runs behind one another in one wave made K8 0.96 ms on such a cut
 __global__ __launch_bounds__(kPreBlock) void k8_presum_long_kernel(int P, const uint32_t* __restrict__ tiles_touched,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    float* __restrict__ inst) {
   __shared__ double red_all[kPreBlock / 64][640];
-  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = (blockIdx.x * (kPreBlock / 64) + wave) * kPresumPerWave + lane;      // lanes 0 .. 7: the wave's Gaussians
+  const uint32_t n = (lane < kPresumPerWave && idx < P) ? tiles_touched[idx] : 0u;
   unsigned long long todo = __ballot(n > kK8LongRun);
   if (todo == 0ull) return;
   const uint32_t off_mine = n > kK8LongRun ? offsets[idx] : 0u;
-  double* red = red_all[threadIdx.x >> 6];
+  double* red = red_all[wave];
   while (todo) {                                                         // (wave-uniform)
     const int owner = __ffsll((long long)todo) - 1;
     todo &= todo - 1ull;
@@ -1874,8 +1876,9 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
     static const char* force = getenv("HGS_K8_PRESUM");
     const bool presum = force ? force[0] == '1' : (uint64_t)L > 6ull * (uint64_t)a.P;
     if (presum) {
-      hipLaunchKernelGGL(k8_presum_long_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.tiles_touched, g.offsets,
-                         const_cast<float*>(inst_grads));
+      const int per_wg = (kPreBlock / 64) * kPresumPerWave;
+      hipLaunchKernelGGL(k8_presum_long_kernel, dim3((a.P + per_wg - 1) / per_wg), dim3(kPreBlock), 0, s, a.P,
+                         g.tiles_touched, g.offsets, const_cast<float*>(inst_grads));
       HGS_LAUNCH_CHECK("preprocess_bwd_long_runs", s, a.debug);
     }
     auto k8a = a.lod_render_indices ? preprocess_bwd_kernel<false, true>      // (accumulation is refused with lod, abi.cpp)
