@@ -232,8 +232,15 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   p.fly.y = stop1 ? kBig : p.fly.y;      // is finished is checked once per batch, not per stop event
 }
 
+// Tuning aid: HGS_K6_WPE = waves per SIMD the register allocation is held to (default: what the kernel needs, 6 at 78
+// registers).  8 160 one-wave tiles on 1 024 SIMDs are 1.33 rounds at 6 waves per SIMD, 2 rounds at 4, one round at 8.
+#ifdef HGS_K6_WPE
+#define HGS_K6_OCC __attribute__((amdgpu_waves_per_eu(HGS_K6_WPE, HGS_K6_WPE)))
+#else
+#define HGS_K6_OCC
+#endif
 template <bool DEPTH>
-__global__ __launch_bounds__(64) void render_fwd_quad_kernel(
+__global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
@@ -752,13 +759,21 @@ static int render_grid_limit(int nblk) {
   return n > 0 && n < nblk ? n : nblk;
 }
 
+// Tuning aid: HGS_K6_DYN_LDS / HGS_K7_DYN_LDS = bytes of (unused) dynamic LDS per workgroup -- caps the workgroups a
+// compute unit holds (160 KB / (static + dynamic)) without touching the code: occupancy against the number of rounds.
+static size_t env_bytes(const char* name) {
+  const char* e = getenv(name);
+  return e ? (size_t)atoi(e) : 0;
+}
+
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, hipStream_t s) {
+  static const size_t dyn = env_bytes("HGS_K6_DYN_LDS");
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth;
   auto kern = depth ? render_fwd_quad_kernel<true> : render_fwd_quad_kernel<false>;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
                      out_invdepth, im.final_T, im.n_contrib, b.tile_order);
   HGS_LAUNCH_CHECK("render_fwd_quad", s, a.debug);
@@ -769,11 +784,12 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s) {
   (void)out_color;
+  static const size_t dyn = env_bytes("HGS_K7_DYN_LDS");
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
   auto kern = depth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
                      im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order);
   HGS_LAUNCH_CHECK("render_bwd_quad", s, a.debug);
