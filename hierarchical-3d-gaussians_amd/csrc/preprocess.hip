@@ -377,6 +377,77 @@ __device__ __forceinline__ void sh48_row_from_global(const float* __restrict__ s
 #undef HGS_SH48_Q
 }
 
+// ---- the same block as whole ROWS, in row groups (HGS_K1_LAYOUT) ----------------------------------------------------------
+// The half-row image above fetches a Gaussian's 192 bytes as two 96-byte pieces, a double-precision chain apart: every
+// 128-byte line of the block is requested twice, and the counters say the second request is not served on chip (K1's
+// FETCH_SIZE 174 MB against 115 MB of the round-4 kernel that loaded the block with consecutive 16-byte loads,
+// profiles/r05_final_pmc.json).  Layout 1 keeps the 24 KB image but fills it with the WHOLE rows of half the
+// workgroup's Gaussians at a time -- rows 0 .. 127 while all four waves run the chain, evaluated by waves 0 and 1; then
+// rows 128 .. 255 for waves 2 and 3 -- so that every line is requested once, by one DMA burst.  Layout 2: all 256 rows at
+// once (48 KB: three workgroups per compute unit).  A row = 12 chunks of 16 bytes at row * 192, unpadded; row r keeps chunk
+// c in slot (c + f(r)) mod 12, f(r) = bits 2..3 of r: the 16 rows of a ds_read_b128 lane group then cover all 16 bank
+// groups (192 r mod 256 takes four values).  Only the chunks the active degree needs are fetched.
+// Measured on one box (profiles/r05_k1_layouts.txt, metric configuration, K1 in the frame): half rows 96.4 us, two row
+// groups 92.4 us (FETCH_SIZE back at 115 MB), all rows at once 88.9 us -- one DMA burst, one barrier, every wave busy in
+// the one evaluation phase; three workgroups per compute unit are enough because the DMA keeps 48 KB per workgroup in
+// flight without a register.  Default: 2.
+#ifndef HGS_K1_LAYOUT
+#define HGS_K1_LAYOUT 2
+#endif
+constexpr int kK1Groups = HGS_K1_LAYOUT == 1 ? 2 : 1;
+constexpr int kK1GroupRows = kPreBlock / kK1Groups;
+constexpr int kK1ImageBytes = HGS_K1_LAYOUT == 0 ? kHalfBytes : kK1GroupRows * 192;
+
+__device__ __forceinline__ void sh48_issue_rows(const float* __restrict__ shs, int block_first, int P, int group,
+                                                int nchunks, float* lds) {
+  const int count = min(kPreBlock, P - block_first);
+  const char* src = reinterpret_cast<const char*>(shs + (size_t)block_first * 48);
+  const int wave_base = (int)(threadIdx.x & ~63u);
+  constexpr int kPer = kK1GroupRows * 12 / kPreBlock;          // DMA instructions per lane and group: 6 or 12
+#pragma unroll
+  for (int k = 0; k < kPer; ++k) {
+    const int slot = k * kPreBlock + (int)threadIdx.x;          // linear 16-byte slot of the LDS image
+    const int row_l = slot / 12, cs = slot - row_l * 12;
+    int c = cs - ((row_l >> 2) & 3);                             // the logical chunk this slot keeps
+    c = c < 0 ? c + 12 : c;
+    const int row = group * kK1GroupRows + row_l;
+    char* dst = reinterpret_cast<char*>(lds) + (size_t)(k * kPreBlock + wave_base) * 16;   // wave-uniform
+    if (row < count && c < nchunks)
+      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * 192 + c * 16), (lptr_t)dst, 16, 0, 0);
+  }
+}
+// row `row_l` of the image, coefficients [4 Q, 4 Q + 4): 12 floats
+template <int Q>
+__device__ __forceinline__ void sh48_read_row_quarter(const float* lds, int row_l, float v[12]) {
+  const int f = (row_l >> 2) & 3;
+  const float* row = lds + row_l * 48;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int sl = Q * 3 + c + f;
+    sl = sl >= 12 ? sl - 12 : sl;
+    const float4 t = *reinterpret_cast<const float4*>(row + sl * 4);
+    v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+  }
+}
+template <bool JAC>
+__device__ __forceinline__ void sh48_row_from_lds(const float* lds, int row_l, bool vis, int deg, float dx, float dy,
+                                                  float dz, float rgb[3], float J[9]) {
+  const int nb = (deg + 1) * (deg + 1);
+  float sh[12];
+  sh48_read_row_quarter<0>(lds, row_l, sh);
+  if (vis) sh48_accumulate4<JAC, 0>(deg, dx, dy, dz, sh, rgb, J);
+  if (nb > 4) {                                                  // (uniform)
+    sh48_read_row_quarter<1>(lds, row_l, sh);
+    if (vis) sh48_accumulate4<JAC, 4>(deg, dx, dy, dz, sh, rgb, J);
+    if (nb > 8) {
+      sh48_read_row_quarter<2>(lds, row_l, sh);
+      if (vis) sh48_accumulate4<JAC, 8>(deg, dx, dy, dz, sh, rgb, J);
+      sh48_read_row_quarter<3>(lds, row_l, sh);
+      if (vis) sh48_accumulate4<JAC, 12>(deg, dx, dy, dz, sh, rgb, J);
+    }
+  }
+}
+
 // ---- the per-workgroup sums of K1 and their scan -----------------------------------------------------------------------
 // Every workgroup of K1 leaves nine sums (its instances, and its instances per tile band); K3 needs their exclusive scans
 // over the workgroups.  Rounds 1-4 ran a scan launch between K1 and K3 (6.6 us + a kernel boundary for 140 KB).  With
@@ -606,7 +677,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     coop = nvis * 2 >= kPreBlock;
     if (coop) {
       if constexpr (H48) {
+#if HGS_K1_LAYOUT == 0
         if (!K1X(4)) sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
+#else
+        if (!K1X(4)) sh48_issue_rows(a.shs, blockIdx.x * kPreBlock, a.P, 0, ((a.sh_degree + 1) * (a.sh_degree + 1) * 3 + 3) / 4, lds_sh);
+#endif
       } else if (lod) {
         coop_gather_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
       } else if (a.shs_rest) {
@@ -656,6 +731,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     unit_dir(p, cam.cam, dx, dy, dz);
     float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (coop && !K1X(4)) {
+#if HGS_K1_LAYOUT == 0
       // (the barrier above waited for the DMA of half 0)
       const bool second = a.sh_degree > 1;               // coefficients 8 .. 15 belong to degrees 2 and 3
       sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
@@ -666,6 +742,19 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
         __syncthreads();
         sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
       }
+#else
+      // (the barrier above waited for the DMA of row group 0)
+      const int my_group = (int)threadIdx.x / kK1GroupRows, row_l = (int)threadIdx.x - my_group * kK1GroupRows;
+      if (my_group == 0) sh48_row_from_lds<JAC>(lds_sh, row_l, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+      if (kK1Groups > 1) {
+        __syncthreads();                                 // group 0's rows are in registers: the image may be replaced
+        sh48_issue_rows(a.shs, blockIdx.x * kPreBlock, a.P, 1, ((a.sh_degree + 1) * (a.sh_degree + 1) * 3 + 3) / 4, lds_sh);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (my_group == 1) sh48_row_from_lds<JAC>(lds_sh, row_l, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+        __syncthreads();                                 // (the store staging below takes the image over)
+      }
+#endif
     } else if (vis && !K1X(4)) {
       sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, Jt);
     }
@@ -719,9 +808,11 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) | ((uint32_t)(pr.maxx - pr.minx) << 20);
   bool rows_stored = false;
   if constexpr (H48 && HGS_K1_COALESCED_STORES) {
-    if ((GEOM_ONLY || coop) && !K1X(4)) {  // (uniform; the wave's 6 KB of the half-row image are its own by now)
+    if ((GEOM_ONLY || coop) && !K1X(4)) {  // (uniform; the wave's own part of the image -- or, after the last barrier of
+                                           // the row groups, anybody's -- is free by now)
       rows_stored = true;
-      float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) + (threadIdx.x >> 6) * (kHalfBytes / (kPreBlock / 64)));
+      float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) +
+                                             (threadIdx.x >> 6) * ((GEOM_ONLY ? kHalfBytes : kK1ImageBytes) / (kPreBlock / 64)));
       const unsigned long long vmask = __ballot(vis);
       const size_t row0 = (size_t)blockIdx.x * kPreBlock + (threadIdx.x & ~63u);
       if (!K1X(1)) {
@@ -1819,7 +1910,8 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
     const bool h48 = plain && a.M == 16;
     const bool defer = plain && !h48;
     if (geometry_only && !h48) { set_error("launch_preprocess_fwd: the geometry-only kernel needs the plain M = 16 layout"); return HGS_ERR_INVALID; }
-    const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)kHalfBytes : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
+    const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)(geometry_only ? kHalfBytes : kK1ImageBytes)
+                                              : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
     if (geometry_only) {
       hipLaunchKernelGGL(preprocess_geom_h48_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
     } else {

@@ -19,9 +19,9 @@ pytestmark = pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") and s
 FRAME = {
     "render_fwd_quad_kernel<true>": (80, 6),
     "render_bwd_quad_kernel<true>": (128, 4),
-    # K1 at M = 16: the SH block in two halves straight into LDS (24 KB per workgroup), round 5; was (144, 3)
-    "preprocess_fwd_h48_kernel<true>": (96, 5),
-    "preprocess_fwd_h48_kernel<false>": (96, 5),
+    # K1 at M = 16: the SH block straight into LDS by DMA (whole rows, 48 KB per workgroup), round 5; was 144 registers
+    "preprocess_fwd_h48_kernel<true>": (96, 3),
+    "preprocess_fwd_h48_kernel<false>": (96, 3),
     "preprocess_bwd_kernel<false, false>": (160, 3),
     "sh_bwd_kernel<false, true, false>": (72, 3),
     "duplicate_tiles_banded_kernel": (40, 8),
