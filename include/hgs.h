@@ -161,11 +161,14 @@ int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws,
 /* Single-call forward for callers that can bound L in advance (the Python host uses 1.25 x the previous
  * frame's count): bin_ws / bwd scratch are sized with L_cap, every kernel is enqueued before the host reads
  * L, so the GPU never idles between the stages (the two-stage path leaves a ~50 us bubble).  The call still
- * returns the exact L: the scan kernel stores it into a pinned, device-mapped host word and the host polls the event
+ * returns the exact L: the kernel that completes the scans of K1's workgroup sums (K3's last workgroup; the scan launch
+ * on the fallback routes) stores it into a pinned, device-mapped host word and the host polls the event
  * recorded behind that kernel (no copy command in the stream; HGS_COUNT_BY_COPY / HGS_BLOCKING_WAIT in the environment
  * select a copy / a sleeping wait instead -- same results).  If L > L_cap it returns HGS_ERR_CAPACITY,
  * the outputs are invalid and the caller continues with hgs_raster_fwd_stage2 on an exactly sized bin_ws
- * (geom_ws / radii from this call stay valid).  Later calls (backward, views) must pass the same L_cap as L. */
+ * (geom_ws / radii from this call stay valid).  Later calls (backward, views) must pass the same L_cap as L.
+ * Library state: this entry point keeps, per (device, stream), 36 KB of zeroed device memory between calls (K1 adds its
+ * workgroup sums there, a later kernel of the same call clears them; INTEGRATION.md "What the library keeps"). */
 int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L_cap,
                    int32_t* radii, float* out_color, float* out_invdepth, uint32_t* L_out_host,
                    hgs_stream_t stream, int device);
