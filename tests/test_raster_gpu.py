@@ -839,3 +839,40 @@ def test_large_footprints_take_the_long_run_route(gpu):
     assert hip["L"] > 6 * P and int(tt.max()) > 48 * 2, (hip["L"], int(tt.max()))
     assert int(((tt > 0) & (tt <= 48)).sum()) > 0             # short runs next to long ones
     pa.assert_stats("large footprints", pa.compare(hip, oo, og))
+
+
+def test_forwards_on_two_streams_keep_their_own_superblock_totals(gpu):
+    """K1 adds its workgroup sums to zeroed superblock totals the library keeps PER (device, stream) (preprocess.hip): two
+    streams rendering different scenes in turns -- the speculative single-call path on both -- must each see only their own
+    sums: sorted lists and ranges of every frame equal to the first frame of its scene (checked against the oracle)."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W, H = 400, 240
+    cam = synth.make_camera(W, H)
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    scenes, refs = [], []
+    for k, P in enumerate((9000, 14000)):
+        sc = synth.make_scene(P, cam, seed=60 + k)
+        geom = ro.geometry_spec(sc.means3D.numpy(), sc.scales.numpy(), sc.rotations.numpy(), None,
+                                cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                                cam.tanfovx, cam.tanfovy, 1.0)
+        b = ro.binning_spec(geom)
+        scenes.append(sc.to(gpu))
+        refs.append((int(b.num_rendered), torch.from_numpy(b.ranges.astype(np.int64)).to(gpu),
+                     torch.from_numpy(b.point_list.astype(np.int64)).to(gpu)))
+    torch.cuda.synchronize()
+    bad = 0
+    for it in range(40):
+        k = it % 2 if it % 5 else (it // 5) % 2              # mostly alternating, sometimes twice on one stream
+        sc = scenes[k]
+        with torch.cuda.stream(streams[k]):
+            L, color, radii, _, _, _, invd, call = dgr._C.rasterize_gaussians(
+                rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+                rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+                rs.interpolation_weights, rs.num_node_kids, False)
+            v = dgr._C.raster_views(call)
+            assert L == refs[k][0], (it, k, L)
+            bad += int((v["ranges"].to(torch.int64) != refs[k][1]).sum()) + int((v["point_list"].to(torch.int64) != refs[k][2]).sum())
+    torch.cuda.synchronize()
+    assert bad == 0
