@@ -9,8 +9,9 @@
 // and every kernel here runs band x's workgroups on XCD x (workgroup b -> XCD b % 8, so band = blockIdx.x % 8):
 //   count   : a workgroup histograms its chunk of its band's stream over the band's tiles in LDS and writes the counts
 //                                                                                       table[band][chunk][tile]
-//   colscan : per tile, exclusive scan of the chunk counts inside each of kGroups chunk groups (in place); group sums and
-//             (atomically) the tile totals
+//             and -- same launch since round 5 (tb_count_kernel below) -- the workgroup that completes one of the band's
+//             kGroups chunk groups scans that group's counts per tile (exclusive, in place), stores the group sums and
+//             adds them to the tile totals
 //   scatter : every workgroup scans ITS BAND's tile totals itself (<= 4096 values in LDS: the tile bases are band-local --
 //             band begin + the totals of the band's earlier tiles) and adds the earlier groups' sums: pos = base[tile] +
 //             sum of gsum[g' < group][tile] + table[chunk][tile] + (LDS fetch-and-add); ids only.  The band's first
