@@ -353,7 +353,7 @@ def test_pmc_counters_to_bytes_per_launch():
 
 def test_live_pmc_collection_declines_under_a_profiler(monkeypatch):
     """bench.py's own counter passes (rocprofv3 child processes) are not started from a process that already runs under
-    rocprofv3 -- the driver's profile of the test suite, scripts/final_prof.sh: the reason goes into the line instead."""
+    rocprofv3 -- the driver's profile of the test suite, scripts/r05_final.sh: the reason goes into the line instead."""
     import sys
     import types
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
