@@ -29,6 +29,14 @@ namespace {
 
 constexpr int kTbThreads = 256;
 constexpr int kGroups = 8;
+#ifndef HGS_TB_BATCH
+#define HGS_TB_BATCH 16
+#endif
+#ifndef HGS_TB_STAGED
+#define HGS_TB_STAGED 1
+#endif
+constexpr bool kTbStaged = HGS_TB_STAGED != 0;   // 0: the scatter stores instance by instance (A/B runs)
+constexpr int kTbBatch = HGS_TB_BATCH;     // instances per lane whose loads are issued together (count and scatter)
 constexpr int kMaxTiles = 32768;
 
 struct BandStream {
@@ -92,7 +100,18 @@ __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __
   for (int t = threadIdx.x; t < per; t += kTbThreads) h[t] = 0u;
   __syncthreads();
   const uint32_t end = min(base + chunk, st.end);
-  for (uint32_t i = base + threadIdx.x; i < end; i += kTbThreads) atomicAdd(&h[keys[i]], 1u);
+  // kTbBatch loads in flight per lane, then their LDS adds (a load -> wait -> add loop pays the load latency once per
+  // 256 instances: a workgroup's 4096 took sixteen round trips, most of this kernel's time)
+  uint32_t i0 = base;
+  for (; i0 + kTbThreads * kTbBatch <= end; i0 += kTbThreads * kTbBatch) {       // whole batches (workgroup-uniform)
+    const uint32_t* kp = keys + i0 + threadIdx.x;
+    uint32_t k[kTbBatch];
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) k[j] = kp[j * kTbThreads];
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) atomicAdd(&h[k[j]], 1u);
+  }
+  for (uint32_t i = i0 + threadIdx.x; i < end; i += kTbThreads) atomicAdd(&h[keys[i]], 1u);   // the band's last chunk
   __syncthreads();
   uint32_t* row = table + ((size_t)band * max_chunks + c) * per;
   for (int t = threadIdx.x; t < per; t += kTbThreads) store_sc1(&row[t], h[t]);
@@ -111,21 +130,42 @@ __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __
   __syncthreads();
   if (!completes_group) return;
   uint32_t* tb0 = table + (size_t)band * max_chunks * per;
-  for (int t = threadIdx.x; t < per; t += kTbThreads) {
-    uint32_t* tb = tb0 + t;
-    uint32_t acc = 0;
-    for (int cb = c0; cb < c1; cb += 8) {           // 8 independent loads in flight, then the 8 prefix stores
-      uint32_t v[8];
+  // two tile columns x kRowBatch rows in flight per lane (a column at a time, eight rows at a time, was eight dependent
+  // round trips for a group of ten chunks at 1080p: the tail of this launch)
+  constexpr int kRowBatch = 16, kCols = 2;
+  for (int tb = threadIdx.x; tb - (int)threadIdx.x < per; tb += kCols * kTbThreads) {
+    uint32_t acc[kCols];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] = (cb + k < c1) ? tb[(size_t)(cb + k) * per] : 0u;
+    for (int u = 0; u < kCols; ++u) acc[u] = 0u;
+    for (int cb = c0; cb < c1; cb += kRowBatch) {
+      uint32_t v[kCols][kRowBatch];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        if (cb + k < c1) tb[(size_t)(cb + k) * per] = acc;
-        acc += v[k];
+      for (int u = 0; u < kCols; ++u)
+#pragma unroll
+        for (int k = 0; k < kRowBatch; ++k)       // clamped addresses: loads without branches, masked on use
+          v[u][k] = tb0[(size_t)min(cb + k, c1 - 1) * per + min(tb + u * kTbThreads, per - 1)];
+#pragma unroll
+      for (int u = 0; u < kCols; ++u) {
+        const int t = tb + u * kTbThreads;
+        if (t < per) {
+#pragma unroll
+          for (int k = 0; k < kRowBatch; ++k) {
+            if (cb + k < c1) {
+              tb0[(size_t)(cb + k) * per + t] = acc[u];
+              acc[u] += v[u][k];
+            }
+          }
+        }
       }
     }
-    gsum[(size_t)g * Tp + band * per + t] = acc;
-    if (acc) atomicAdd(&totals[band * per + t], acc);
+#pragma unroll
+    for (int u = 0; u < kCols; ++u) {
+      const int t = tb + u * kTbThreads;
+      if (t < per) {
+        gsum[(size_t)g * Tp + band * per + t] = acc[u];
+        if (acc[u]) atomicAdd(&totals[band * per + t], acc[u]);
+      }
+    }
   }
 }
 
@@ -174,6 +214,14 @@ __device__ __forceinline__ void band_tile_order(const uint32_t* __restrict__ tot
 // LDS holds one absolute output cursor per tile of the band: one LDS fetch-and-add per instance and no dependent global
 // reads.  The cursor = (band begin + exclusive scan of the band's tile totals, done here by every workgroup: a lane owns
 // `each` consecutive tiles) + the sums of the chunk groups before this chunk's + the chunk's row of the scanned table.
+// STAGED (chunk = kTbThreads * kTbBatch: one batch per workgroup; T <= 12288): the chunk's instances are first grouped
+// by tile in LDS -- a second LDS array counts the chunk's instances per tile (the fetch-and-add returns the rank inside
+// (chunk, tile)), its exclusive scan gives every tile's place inside the chunk, (output position, id) pairs are parked
+// there -- and then written out in chunk order: neighbouring lanes store to neighbouring words of a tile's list (runs of
+// ~4 at 1080p) instead of 64 unrelated words per store.  2.7 M XCD-local four-byte stores: 17.5 us one by one, 8.9 us in
+// runs of four (scripts/microbench/atomics.hip).  The order inside a tile's list differs from the unstaged kernel's; the
+// depth sort that follows makes both the same list.
+template <bool STAGED>
 __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* __restrict__ keys,
                                                                 const uint32_t* __restrict__ vals, uint32_t cap,
                                                                 const uint32_t* __restrict__ band_totals, int col, int per,
@@ -199,10 +247,31 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
   const bool first = c == 0;                                // writes the band's tile ranges (also of an empty band)
   if (base >= st.end && !first) return;
   const int tiles = max(0, min(per, T - band * per));
+  // STAGED: the chunk's instances, requested before anything else (consumed after the cursors are built)
+  uint32_t s_tile[STAGED ? kTbBatch : 1], s_gid[STAGED ? kTbBatch : 1];
+  uint32_t* cnt = h + per;
+  if constexpr (STAGED) {
+    if (base < st.end) {
+#pragma unroll
+      for (int j = 0; j < kTbBatch; ++j) {
+        const uint32_t i = min(base + (uint32_t)(j * kTbThreads + tid), st.end - 1u);
+        s_tile[j] = keys[i];
+        s_gid[j] = vals[i];
+      }
+    }
+    for (int t = tid; t < per; t += kTbThreads) cnt[t] = 0u;
+  }
   // ---- tile bases of the band: exclusive scan of its totals ---------------------------------------------------
   const int each = (per + kTbThreads - 1) / kTbThreads;
   const uint32_t* tot = totals + band * per;
-  for (int t = tid; t < tiles; t += kTbThreads) h[t] = tot[t];                 // coalesced
+  for (int tb = tid; tb < tiles + tid; tb += kTbThreads * 4) {                 // coalesced, four loads in flight
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = tot[min(tb + j * kTbThreads, tiles - 1)];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (tb + j * kTbThreads < tiles) h[tb + j * kTbThreads] = v[j];
+  }
   __syncthreads();
   const int t0 = tid * each;
   uint32_t mine = 0;
@@ -235,21 +304,101 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
   const int g = c / cpg;
   const uint32_t* row = table + ((size_t)band * max_chunks + c) * per;
   const uint32_t* gs = gsum + band * per;
-  for (int t = tid; t < tiles; t += kTbThreads) {
-    uint32_t acc = h[t] + row[t];
-    for (int k = 0; k < g; ++k) acc += gs[(size_t)k * Tp + t];
-    h[t] = acc;
+  for (int tb = tid; tb - tid < tiles; tb += 2 * kTbThreads) {       // two tile columns' row + group sums in flight
+    uint32_t add[2][kGroups];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = min(tb + u * kTbThreads, tiles - 1);
+      add[u][kGroups - 1] = row[t];
+#pragma unroll
+      for (int k = 0; k < kGroups - 1; ++k) add[u][k] = gs[(size_t)min(k, max(g - 1, 0)) * Tp + t];
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int t = tb + u * kTbThreads;
+      if (t < tiles) {
+        uint32_t acc = h[t] + add[u][kGroups - 1];
+#pragma unroll
+        for (int k = 0; k < kGroups - 1; ++k) acc += (k < g) ? add[u][k] : 0u;
+        h[t] = acc;
+      }
+    }
   }
   __syncthreads();
   const uint32_t end = min(base + chunk, st.end);
-  for (uint32_t i = base + tid; i < end; i += kTbThreads) {
+  if constexpr (STAGED) {
+    const uint32_t n = end - base;                          // 1 .. kTbThreads * kTbBatch
+    uint2* stage = reinterpret_cast<uint2*>(cnt + per);
+    uint32_t rank[kTbBatch];
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) {
+      rank[j] = 0u;
+      if ((uint32_t)(j * kTbThreads + tid) < n) rank[j] = atomicAdd(&cnt[s_tile[j]], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the chunk's counts over the band's tiles (in place): a lane owns `each` consecutive tiles
+    uint32_t own = 0;
+    for (int i = 0; i < each; ++i)
+      if (t0 + i < tiles) own += cnt[t0 + i];
+    uint32_t inc2 = own;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t v = __shfl_up(inc2, off, 64);
+      if (lane >= off) inc2 += v;
+    }
+    if (lane == 63) wave_tot[wave] = inc2;                  // (its first use was read two barriers ago)
+    __syncthreads();
+    uint32_t at = inc2 - own;
+    for (int w = 0; w < wave; ++w) at += wave_tot[w];
+    for (int i = 0; i < each; ++i) {
+      if (t0 + i >= tiles) break;
+      const uint32_t c_t = cnt[t0 + i];
+      cnt[t0 + i] = at;
+      at += c_t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j)
+      if ((uint32_t)(j * kTbThreads + tid) < n)
+        stage[cnt[s_tile[j]] + rank[j]] = make_uint2(h[s_tile[j]] + rank[j], s_gid[j]);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) {
+      const uint32_t i = (uint32_t)(j * kTbThreads + tid);
+      if (i < n) {
+        const uint2 e = stage[i];
+        vals_out[e.x] = e.y;
+      }
+    }
+    return;
+  }
+  // batched as in the count kernel: the loads of kTbBatch instances per lane, their LDS fetch-and-adds, their stores
+  uint32_t i0 = base;
+  for (; i0 + kTbThreads * kTbBatch <= end; i0 += kTbThreads * kTbBatch) {
+    const uint32_t* kp = keys + i0 + tid;
+    const uint32_t* vp = vals + i0 + tid;
+    uint32_t t[kTbBatch], gid[kTbBatch], pos[kTbBatch];
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) {
+      t[j] = kp[j * kTbThreads];
+      gid[j] = vp[j * kTbThreads];
+    }
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) pos[j] = atomicAdd(&h[t[j]], 1u);
+#pragma unroll
+    for (int j = 0; j < kTbBatch; ++j) vals_out[pos[j]] = gid[j];
+  }
+  for (uint32_t i = i0 + tid; i < end; i += kTbThreads) {                  // the band's last chunk
     const uint32_t t = keys[i];
     const uint32_t gid = vals[i];
     vals_out[atomicAdd(&h[t], 1u)] = gid;
   }
 }
 
-inline uint32_t tb_chunk(int T) { return T <= 12288 ? 4096u : 16384u; }
+#ifndef HGS_TB_CHUNK
+#define HGS_TB_CHUNK 4096
+#endif
+inline uint32_t tb_chunk(int T) { return T <= 12288 ? (uint32_t)HGS_TB_CHUNK : 16384u; }
 
 }  // namespace
 
@@ -285,8 +434,16 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
                      chunk, max_chunks, t.table, t.gsum, t.totals, t.arrive, Tp, super,
                      super ? (int)(super_block_bytes() / sizeof(uint32_t)) : 0);
   HGS_LAUNCH_CHECK("tile_bin_count", s, debug);
-  hipLaunchKernelGGL(tb_scatter_kernel, dim3(kBands * max_chunks + kBands), dim3(kTbThreads), lds, s, keys, vals, L_cap,
-                     band_totals, col, per, chunk, max_chunks, T, Tp, t.table, t.gsum, t.totals, vals_out, ranges, big, tile_order);
+  // one batch per workgroup: the scatter groups its chunk by tile in LDS first (cursors + counts + 8 bytes per instance)
+  const bool staged = kTbStaged && chunk == (uint32_t)(kTbThreads * kTbBatch);
+  if (staged)
+    hipLaunchKernelGGL(tb_scatter_kernel<true>, dim3(kBands * max_chunks + kBands), dim3(kTbThreads),
+                       lds * 2 + (size_t)chunk * 8, s, keys, vals, L_cap, band_totals, col, per, chunk, max_chunks, T, Tp,
+                       t.table, t.gsum, t.totals, vals_out, ranges, big, tile_order);
+  else
+    hipLaunchKernelGGL(tb_scatter_kernel<false>, dim3(kBands * max_chunks + kBands), dim3(kTbThreads), lds, s, keys, vals,
+                       L_cap, band_totals, col, per, chunk, max_chunks, T, Tp, t.table, t.gsum, t.totals, vals_out, ranges,
+                       big, tile_order);
   HGS_LAUNCH_CHECK("tile_bin_scatter", s, debug);
   return HGS_OK;
 }

@@ -29,6 +29,14 @@ __global__ void store_xcd_kernel(uint32_t* out, uint32_t n, uint32_t span) {
   if (i < n) out[(blockIdx.x & 7) * part + hash(i) % part] = i;
 }
 
+// the XCD-local stores in RUNS: `run` neighbouring lanes write neighbouring words (what a scatter that first groups its
+// chunk's instances by tile in LDS would issue: a tile's entries of one chunk are contiguous)
+__global__ void store_xcd_runs_kernel(uint32_t* out, uint32_t n, uint32_t span, uint32_t run) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t part = span / 8;
+  if (i < n) out[(blockIdx.x & 7) * part + (hash(i / run) % (part / run)) * run + i % run] = i;
+}
+
 int main() {
   const uint32_t n = 2665429;
   uint32_t *cnt, *sink;
@@ -66,6 +74,17 @@ int main() {
       float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
     }
     printf("random 4B stores, XCD-local eighths n=%u span=%u : %.1f us\n", n, span, best * 1e3);
+  }
+  for (uint32_t run : {1u, 2u, 4u, 8u, 16u}) {
+    const uint32_t span = 2665429u;
+    float best = 1e9f;
+    for (int it = 0; it < 5; ++it) {
+      CK(hipEventRecord(a));
+      hipLaunchKernelGGL(store_xcd_runs_kernel, dim3((n + 255) / 256), dim3(256), 0, 0, cnt, n, span, run);
+      CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+      float ms; CK(hipEventElapsedTime(&ms, a, b)); if (ms < best) best = ms;
+    }
+    printf("XCD-local stores in runs of %u words n=%u span=%u : %.1f us\n", run, n, span, best * 1e3);
   }
   return 0;
 }

@@ -26,8 +26,8 @@ FRAME = {
     "sh_bwd_kernel<false, true, false>": (72, 3),
     "duplicate_tiles_banded_kernel": (40, 8),
     "tile_depth_sort_wave_kernel<false>": (72, 7),
-    "tb_count_kernel": (56, 8),             # count + column scan in one launch (round 5)
-    "tb_scatter_kernel": (40, 8),
+    "tb_count_kernel": (72, 7),             # count + column scan in one launch, 32 table words in flight per lane (round 5)
+    "tb_scatter_kernel<true>": (72, 3),     # 16 instances per lane in flight, the chunk staged in LDS by tile (round 5)
 }
 
 
@@ -58,7 +58,7 @@ def test_double_precision_stays_where_conditioning_needs_it(rows):
     """K6 / K7 / K8b and the binning kernels are float32 / integer only; K1 and K8a carry the double chain (recomputed
     forward and chain rule: tests/tools/k8a_float_chain_study.py says why it stays)."""
     for name in ("render_fwd_quad_kernel<true>", "render_bwd_quad_kernel<true>", "sh_bwd_kernel<false, true, false>",
-                 "duplicate_tiles_banded_kernel", "tb_scatter_kernel", "tile_depth_sort_wave_kernel<false>"):
+                 "duplicate_tiles_banded_kernel", "tb_scatter_kernel<true>", "tile_depth_sort_wave_kernel<false>"):
         assert rows[name]["mix"]["valu_f64"] == 0, name
     assert rows["preprocess_bwd_kernel<false, false>"]["mix"]["valu_f64"] > 0
     assert rows["preprocess_fwd_h48_kernel<true>"]["mix"]["valu_f64"] > 0
