@@ -159,20 +159,33 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
     // wave w: arrays w, w + 4, w + 8 (0 = all instances, 1 + b = band b).  prefix = superblock totals before this
     // workgroup's superblock + raw sums of the workgroups before it inside the superblock; total = all superblocks
     const int sb = (int)blockIdx.x / kSuper, nsb = ((int)gridDim.x + kSuper - 1) / kSuper;
-    for (int a = wave; a < 1 + kBands; a += kPreBlock / 64) {
+    // the wave's (up to) three arrays TOGETHER: their loads are issued before any of them is waited for (array by array,
+    // the loop was three dependent round trips in front of the first barrier)
+    constexpr int kWaves = kPreBlock / 64, kPer = (1 + kBands + kWaves - 1) / kWaves;
+    uint32_t pre[kPer], x0[kPer];
+    const int j = min(sb * kSuper + lane, (int)blockIdx.x);          // clamped: loads without branches, masked on use
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int a = min(wave + u * kWaves, kBands);                   // (waves 1-3's third array: array 8 once more)
       const uint32_t* raw = a == 0 ? g.block_sums : g.block_band + (size_t)(a - 1) * col;
-      const int j = sb * kSuper + lane;
-      uint32_t pre = (j < (int)blockIdx.x) ? raw[j] : 0u;
-      uint32_t tot = 0;
-      for (int s0 = 0; s0 < nsb; s0 += 64) {
+      pre[u] = raw[j];
+      x0[u] = super[a * kMaxSuper + min(lane, nsb - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int a = min(wave + u * kWaves, kBands);
+      uint32_t p = (sb * kSuper + lane < (int)blockIdx.x) ? pre[u] : 0u;
+      uint32_t tot = (lane < nsb) ? x0[u] : 0u;
+      p += (lane < sb) ? tot : 0u;
+      for (int s0 = 64; s0 < nsb; s0 += 64) {                         // more than 64 superblocks: P > 1 M
         const uint32_t x = (s0 + lane < nsb) ? super[a * kMaxSuper + s0 + lane] : 0u;
         tot += x;
-        pre += (s0 + lane < sb) ? x : 0u;
+        p += (s0 + lane < sb) ? x : 0u;
       }
       // (DPP scans, the total in lane 63: six register-file adds each instead of six trips through the LDS crossbar)
-      pre = wave_scan_incl(pre);
+      p = wave_scan_incl(p);
       tot = wave_scan_incl(tot);
-      if (lane == 63) { pre9[a] = pre; tot9[a] = tot; }
+      if (lane == 63) { pre9[a] = p; tot9[a] = tot; }
     }
   }
   const uint32_t cnt = rect_count(myrect);

@@ -132,7 +132,7 @@ DYNAMIC_LDS = {"preprocess_fwd_kernel": 256 * (16 * 3 + 4) * 4, "preprocess_fwd_
                "preprocess_geom_h48_kernel": 256 * 6 * 16, "preprocess_color_h48_kernel": 256 * 6 * 16,
                "sh_bwd_kernel": 256 * (16 * 3 + 4) * 4,
                # 1080p: two arrays over a band's 1 020 tiles + 8 bytes per instance of a 4 096-instance chunk (staged scatter)
-               "tb_scatter_kernel": 2 * 1020 * 4 + 4096 * 8, "tb_count_kernel": 1020 * 4}
+               "tb_scatter_kernel": 2 * 1020 * 4 + 4096 * 8, "tb_scatter_kernel<false>": 1020 * 4, "tb_count_kernel": 1020 * 4}
 
 
 def collect(sources):
@@ -154,7 +154,7 @@ def collect(sources):
                 base = name.split("<")[0]
                 v, a = int(m.get("vgpr_count", 0)), int(m.get("agpr_count", 0))
                 lds, wg = int(m.get("group_segment_fixed_size", 0)), int(m.get("max_flat_workgroup_size", 256))
-                dyn = DYNAMIC_LDS.get(base, 0)
+                dyn = DYNAMIC_LDS.get(name, DYNAMIC_LDS.get(base, 0))
                 by_regs, by_lds = occupancy(v, a, lds, wg, dyn)
                 mix = k["mix"]
                 total = sum(mix.values()) or 1
