@@ -124,46 +124,79 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // workgroup builds its nine exclusive prefixes and the nine grand totals itself; the last workgroup stores the totals
 // (entry nblk of each array) and the instance count into `total_mirror` (mapped host word, may be null).
 // `zero_words`: n_zero words cleared for the counting kernels that follow (their arrival counters and tile totals).
-__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P, int gx, int T, int per, GeomWs g,
-                                                                           uint32_t cap,
-                                                                           uint32_t* __restrict__ tile_keys,
-                                                                           uint32_t* __restrict__ vals,
-                                                                           uint32_t* __restrict__ ranges, int n_ranges,
-                                                                           const uint32_t* __restrict__ super,
-                                                                           uint32_t* __restrict__ total_mirror,
-                                                                           uint32_t* __restrict__ zero_words, int n_zero) {
-  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
-  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_zero; r += gridDim.x * kPreBlock) zero_words[r] = 0u;
-  __shared__ uint32_t pre9[1 + kBands], tot9[1 + kBands];
-  __shared__ uint32_t excl[kPreBlock + 1];
-  __shared__ uint2 lrect[kPreBlock];
-  __shared__ uint32_t wave_tot[kPreBlock / 64][kBands + 1];   // [.][kBands]: all bands
-  __shared__ uint32_t bpos[kBands];                 // where this workgroup's part of each band's stream begins
-  __shared__ uint32_t rb[kBands][kPreBlock];        // per band and Gaussian: (earlier Gaussians' instances in the band) -
-                                                    // (own tiles below the band): position of instance k = bpos + rb + k
+// SHARING (round 5, after the reference's scripts at scale): a hierarchy cut lists its big nodes side by side, and one
+// workgroup's 256 Gaussians then emit a quarter of a million instances while the mean is a few thousand -- one compute
+// unit emitting for 0.25 ms after everybody else has finished.  Positions are closed-form, so ANY workgroup can emit any
+// slot of any block once it has rebuilt that block's prologue in its LDS.  K1 keeps every superblock's LARGEST workgroup
+// sum (row 1 + kBands of the superblock totals, a fire-and-forget atomic max); a K3 workgroup reads that row with its
+// prefix loads and, only if some sum exceeds  thr = max(kHeavyFloor, kHeavyFactor x the mean emission), takes the rare
+// path: every workgroup builds the same ordered list of the (at most share_max) heavy blocks from K1's raw sums, a
+// listed block's own workgroup emits its first thr slots, and the excess of all listed blocks is dealt out in equal
+// contiguous shares by blockIdx.  Static, no flags, nobody waits: the result does not depend on who emits a slot.
+constexpr uint32_t kHeavyFloor = 4096u, kHeavyFactor = 4u, kShareMin = 1024u;
+constexpr int kMaxHeavy = 256;
+
+struct K3Lds {
+  uint32_t pre9[1 + kBands], tot9[1 + kBands];
+  uint32_t excl[kPreBlock + 1];
+  uint2 lrect[kPreBlock];
+  uint32_t wave_tot[kPreBlock / 64][kBands + 1];   // [.][kBands]: all bands
+  uint32_t bpos[kBands];                 // where the block's part of each band's stream begins
+  uint32_t rb[kBands][kPreBlock];        // per band and Gaussian: (earlier Gaussians' instances in the band) -
+                                         // (own tiles below the band): position of instance k = bpos + rb + k
+  uint32_t hl_blk[kMaxHeavy], hl_pe[kMaxHeavy + 1];   // the rare path's list: block, exclusive prefix of the excesses
+  uint32_t scan_tmp[kPreBlock / 64];
+};
+
+// exclusive scan over the workgroup (two barriers); `total` = the sum
+__device__ __forceinline__ uint32_t k3_wg_scan_excl(uint32_t v, uint32_t* tmp, uint32_t& total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t inc = wave_scan_incl(v);
+  __syncthreads();
+  if (lane == 63) tmp[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0, t = 0;
+#pragma unroll
+  for (int w = 0; w < kPreBlock / 64; ++w) {
+    const uint32_t x = tmp[w];
+    base += (w < wave) ? x : 0u;
+    t += x;
+  }
+  total = t;
+  return base + inc - v;
+}
+
+// The prologue of block `blk` (a workgroup of K1's grid of nblk): fills l.excl / lrect / rb / bpos; ends with a barrier.
+// OWN: blk is this workgroup's own block -- it also stores its Gaussians' emission offsets, the last block stores the
+// totals, and `sbmax` returns (per lane) the largest workgroup sum of superblocks lane, lane + 64, ...
+template <bool OWN>
+__device__ __forceinline__ void k3_prologue(K3Lds& l, int blk, int nblk, int P, int gx, int T, int per, const GeomWs& g,
+                                            const uint32_t* __restrict__ super, uint32_t* __restrict__ total_mirror,
+                                            uint32_t& sbmax) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int i = blockIdx.x * kPreBlock + tid;
+  const int i = blk * kPreBlock + tid;
   const uint32_t gid = (uint32_t)i;
   // every global load of the prologue is issued here, together: the kernel is latency-bound (3 900 small workgroups)
   const uint2 myrect = (i < P) ? reinterpret_cast<const uint2*>(g.rects)[gid] : make_uint2(0u, 0u);
-  const int col = gridDim.x + 1;                          // column stride of g.block_band
+  const int col = nblk + 1;                               // column stride of g.block_band
   uint32_t block_base = 0;
-  uint32_t band_tot = 0, band_off = 0;                    // lanes 0..7 of wave 0: total of band `tid`, this workgroup's offset in it
+  uint32_t band_tot = 0, band_off = 0;                    // lanes 0..7 of wave 0: total of band `tid`, the block's offset in it
+  sbmax = 0u;
   if (!super) {
-    block_base = g.block_sums[blockIdx.x];
+    block_base = g.block_sums[blk];
     if (tid < kBands) {
-      band_tot = g.block_band[(size_t)tid * col + gridDim.x];
-      band_off = g.block_band[(size_t)tid * col + blockIdx.x];
+      band_tot = g.block_band[(size_t)tid * col + nblk];
+      band_off = g.block_band[(size_t)tid * col + blk];
     }
   } else {
-    // wave w: arrays w, w + 4, w + 8 (0 = all instances, 1 + b = band b).  prefix = superblock totals before this
-    // workgroup's superblock + raw sums of the workgroups before it inside the superblock; total = all superblocks
-    const int sb = (int)blockIdx.x / kSuper, nsb = ((int)gridDim.x + kSuper - 1) / kSuper;
+    // wave w: arrays w, w + 4, w + 8 (0 = all instances, 1 + b = band b).  prefix = superblock totals before the block's
+    // superblock + raw sums of the workgroups before it inside the superblock; total = all superblocks
+    const int sb = blk / kSuper, nsb = (nblk + kSuper - 1) / kSuper;
     // the wave's (up to) three arrays TOGETHER: their loads are issued before any of them is waited for (array by array,
     // the loop was three dependent round trips in front of the first barrier)
     constexpr int kWaves = kPreBlock / 64, kPer = (1 + kBands + kWaves - 1) / kWaves;
     uint32_t pre[kPer], x0[kPer];
-    const int j = min(sb * kSuper + lane, (int)blockIdx.x);          // clamped: loads without branches, masked on use
+    const int j = min(sb * kSuper + lane, blk);                       // clamped: loads without branches, masked on use
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int a = min(wave + u * kWaves, kBands);                   // (waves 1-3's third array: array 8 once more)
@@ -171,10 +204,15 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
       pre[u] = raw[j];
       x0[u] = super[a * kMaxSuper + min(lane, nsb - 1)];
     }
+    if constexpr (OWN) {
+      sbmax = (lane < nsb) ? super[(1 + kBands) * kMaxSuper + min(lane, nsb - 1)] : 0u;
+      for (int s0 = 64; s0 < nsb; s0 += 64)
+        if (s0 + lane < nsb) sbmax = max(sbmax, super[(1 + kBands) * kMaxSuper + s0 + lane]);
+    }
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int a = min(wave + u * kWaves, kBands);
-      uint32_t p = (sb * kSuper + lane < (int)blockIdx.x) ? pre[u] : 0u;
+      uint32_t p = (sb * kSuper + lane < blk) ? pre[u] : 0u;
       uint32_t tot = (lane < nsb) ? x0[u] : 0u;
       p += (lane < sb) ? tot : 0u;
       for (int s0 = 64; s0 < nsb; s0 += 64) {                         // more than 64 superblocks: P > 1 M
@@ -185,11 +223,11 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
       // (DPP scans, the total in lane 63: six register-file adds each instead of six trips through the LDS crossbar)
       p = wave_scan_incl(p);
       tot = wave_scan_incl(tot);
-      if (lane == 63) { pre9[a] = p; tot9[a] = tot; }
+      if (lane == 63) { l.pre9[a] = p; l.tot9[a] = tot; }
     }
   }
   const uint32_t cnt = rect_count(myrect);
-  lrect[tid] = myrect;
+  l.lrect[tid] = myrect;
   // own instances per band (as K1 counted them)
   uint32_t cb[kBands];
 #pragma unroll
@@ -221,64 +259,82 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
       }
     }
   }
-  // inclusive scans over the workgroup's Gaussians: all instances (emission offsets) and each band's
+  // inclusive scans over the block's Gaussians: all instances (emission offsets) and each band's
   const uint32_t inc = wave_scan_incl(cnt);
   uint32_t incb[kBands];
 #pragma unroll
   for (int b = 0; b < kBands; ++b) incb[b] = wave_scan_incl(cb[b]);
   if (lane == 63) {
-    wave_tot[wave][kBands] = inc;
+    l.wave_tot[wave][kBands] = inc;
 #pragma unroll
-    for (int b = 0; b < kBands; ++b) wave_tot[wave][b] = incb[b];
+    for (int b = 0; b < kBands; ++b) l.wave_tot[wave][b] = incb[b];
   }
   if (!super && wave == 0) {                              // band base = the totals of the bands before it
     const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
-    if (tid < kBands) bpos[tid] = incl - band_tot + band_off;
+    if (tid < kBands) l.bpos[tid] = incl - band_tot + band_off;
   }
   __syncthreads();
   if (super) {                                            // (pre9 / tot9 of all four waves are there now)
-    block_base = pre9[0];
+    block_base = l.pre9[0];
     if (wave == 0) {
-      if (tid < kBands) { band_tot = tot9[1 + tid]; band_off = pre9[1 + tid]; }
+      if (tid < kBands) { band_tot = l.tot9[1 + tid]; band_off = l.pre9[1 + tid]; }
       const uint32_t incl = wave_scan_incl(tid < kBands ? band_tot : 0u);
-      if (tid < kBands) bpos[tid] = incl - band_tot + band_off;       // (read after the barrier in front of the slot loop)
+      if (tid < kBands) l.bpos[tid] = incl - band_tot + band_off;     // (read after the barrier in front of the slot loop)
     }
-    if (blockIdx.x == gridDim.x - 1 && tid <= kBands) {   // the totals, where the scan launch used to leave them
+    if (OWN && blk == nblk - 1 && tid <= kBands) {        // the totals, where the scan launch used to leave them
       uint32_t* arr = tid == 0 ? g.block_sums : g.block_band + (size_t)(tid - 1) * col;
-      arr[gridDim.x] = tot9[tid];
-      if (tid == 0 && total_mirror) *total_mirror = tot9[0];
+      arr[nblk] = l.tot9[tid];
+      if (tid == 0 && total_mirror) *total_mirror = l.tot9[0];
     }
   }
   uint32_t wbase = 0;
-  for (int w = 0; w < wave; ++w) wbase += wave_tot[w][kBands];
+  for (int w = 0; w < wave; ++w) wbase += l.wave_tot[w][kBands];
   const uint32_t my_excl = wbase + inc - cnt;
-  excl[tid] = my_excl;
-  if (tid == kPreBlock - 1) excl[kPreBlock] = wbase + inc;
+  l.excl[tid] = my_excl;
+  if (tid == kPreBlock - 1) l.excl[kPreBlock] = wbase + inc;
   {
     uint32_t below = 0;                                   // own tiles in the bands before b
 #pragma unroll
     for (int b = 0; b < kBands; ++b) {
       uint32_t wb = 0;
-      for (int w = 0; w < wave; ++w) wb += wave_tot[w][b];
-      rb[b][tid] = wb + incb[b] - cb[b] - below;          // (may wrap: added to k >= below modulo 2^32)
+      for (int w = 0; w < wave; ++w) wb += l.wave_tot[w][b];
+      l.rb[b][tid] = wb + incb[b] - cb[b] - below;        // (may wrap: added to k >= below modulo 2^32)
       below += cb[b];
     }
   }
-  if (i < P && cnt) g.offsets[gid] = block_base + my_excl;     // emission offset of this Gaussian's run (K7 / K8 slots)
+  if (OWN && i < P && cnt) g.offsets[gid] = block_base + my_excl;   // emission offset of this Gaussian's run (K7 / K8 slots)
   __syncthreads();
-  const uint32_t total = excl[kPreBlock];
+}
+
+// The rare path's prologue of ANOTHER block, as a function of its own: inlined into the kernel a second time it doubled
+// the kernel's register count (82 for 36: 5 waves per SIMD for 8 in a latency-bound kernel); as a call it costs the
+// kernel 16 registers and nothing on the usual path.  Plain pointers: a struct by reference would go through scratch.
+__device__ __attribute__((noinline)) void k3_prologue_other(K3Lds* l, int blk, int nblk, int P, int gx, int T, int per,
+                                                            uint32_t* rects, uint32_t* block_sums, uint32_t* block_band,
+                                                            const uint32_t* super) {
+  GeomWs g{};
+  g.rects = rects;
+  g.block_sums = block_sums;
+  g.block_band = block_band;
+  uint32_t unused;
+  k3_prologue<false>(*l, blk, nblk, P, gx, T, per, g, super, nullptr, unused);
+}
+
+// slots [s_begin, s_end) of block `blk`, whose prologue is in l
+__device__ __forceinline__ void k3_emit(const K3Lds& l, int blk, uint32_t s_begin, uint32_t s_end, int gx, int per,
+                                        uint32_t cap, uint32_t* __restrict__ tile_keys, uint32_t* __restrict__ vals) {
   const float rcp_per = __builtin_amdgcn_rcpf((float)per);
-  for (uint32_t s = tid; s < total; s += kPreBlock) {
+  for (uint32_t s = s_begin + threadIdx.x; s < s_end; s += kPreBlock) {
     // largest j with excl[j] <= s (zero-count entries are skipped: the search lands on the LAST index whose start is <= s)
     int lo = 0, hi = kPreBlock;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int mid = (lo + hi) >> 1;
-      if (excl[mid] <= s) lo = mid; else hi = mid;
+      if (l.excl[mid] <= s) lo = mid; else hi = mid;
     }
-    const uint32_t gg = blockIdx.x * kPreBlock + lo;
-    const uint32_t k = s - excl[lo];
-    const uint2 rc = lrect[lo];
+    const uint32_t gg = (uint32_t)blk * kPreBlock + lo;
+    const uint32_t k = s - l.excl[lo];
+    const uint2 rc = l.lrect[lo];
     const uint32_t minx = rc.x & 0xffffu, miny = rc.x >> 16;
     const uint32_t w = (rc.y & 0xffffu) - minx;
     uint32_t kq, kr;
@@ -287,11 +343,81 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
     // band = tile / per by the same reciprocal trick (tile < 2^20; rcp_per is wave-uniform): three instructions for
     // the seven compare-and-add pairs of a boundary count
     const uint32_t band = (uint32_t)(((float)tile + 0.5f) * rcp_per);
-    const uint32_t pos = bpos[band] + rb[band][lo] + k;
+    const uint32_t pos = l.bpos[band] + l.rb[band][lo] + k;
     if (pos < cap) {       // cap < L only when a speculative capacity was too small (caller retries)
       tile_keys[pos] = tile - band * (uint32_t)per;
       vals[pos] = gg;
     }
+  }
+}
+
+__global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P, int gx, int T, int per, GeomWs g,
+                                                                           uint32_t cap,
+                                                                           uint32_t* __restrict__ tile_keys,
+                                                                           uint32_t* __restrict__ vals,
+                                                                           uint32_t* __restrict__ ranges, int n_ranges,
+                                                                           const uint32_t* __restrict__ super,
+                                                                           uint32_t* __restrict__ total_mirror,
+                                                                           uint32_t* __restrict__ zero_words, int n_zero,
+                                                                           int share_max) {
+  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
+  for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_zero; r += gridDim.x * kPreBlock) zero_words[r] = 0u;
+  __shared__ K3Lds l;
+  const int tid = threadIdx.x, nblk = (int)gridDim.x, own = (int)blockIdx.x;
+  uint32_t sbmax;
+  k3_prologue<true>(l, own, nblk, P, gx, T, per, g, super, total_mirror, sbmax);
+  const uint32_t total = l.excl[kPreBlock];
+  // heavy if above thr; every wave holds the whole row of superblock maxima, so the test is the same in all of them
+  const uint32_t L_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.tot9[0]);
+  const uint32_t thr = max(kHeavyFloor, kHeavyFactor * ((L_all + (uint32_t)nblk - 1u) / (uint32_t)nblk));
+  const bool any_heavy = super && share_max > 0 && __ballot(sbmax > thr) != 0ull;
+  if (!any_heavy) {
+    k3_emit(l, own, 0u, total, gx, per, cap, tile_keys, vals);
+    return;
+  }
+  // ---- rare path: the ordered list of heavy blocks (the same in every workgroup), at most share_max of them ----------------
+  const int per_t = (nblk + kPreBlock - 1) / kPreBlock;
+  const int b0 = min(tid * per_t, nblk), b1 = min(b0 + per_t, nblk);
+  uint32_t c = 0;
+#pragma nounroll
+  for (int b = b0; b < b1; ++b) c += g.block_sums[b] > thr ? 1u : 0u;
+  uint32_t nh_all;
+  uint32_t at = k3_wg_scan_excl(c, l.scan_tmp, nh_all);
+#pragma nounroll
+  for (int b = b0; b < b1; ++b) {
+    const uint32_t sum = g.block_sums[b];
+    if (sum > thr) {
+      if (at < (uint32_t)share_max) { l.hl_blk[at] = (uint32_t)b; l.hl_pe[at] = sum - thr; }
+      ++at;
+    }
+  }
+  __syncthreads();
+  const int nh = (int)min(nh_all, (uint32_t)share_max);
+  const uint32_t e = tid < nh ? l.hl_pe[tid] : 0u;
+  const bool mine_listed = tid < nh && l.hl_blk[tid] == (uint32_t)own;
+  uint32_t E;
+  const uint32_t pe = k3_wg_scan_excl(e, l.scan_tmp, E);
+  if (tid < nh) l.hl_pe[tid] = pe;
+  if (tid == 0) l.hl_pe[nh] = E;
+  const bool own_listed = __syncthreads_or(mine_listed) != 0;          // (also orders the list for the loop below)
+  k3_emit(l, own, 0u, own_listed ? thr : total, gx, per, cap, tile_keys, vals);
+  // this workgroup's share of the excess: slots [lo, hi) of the listed blocks' excesses laid end to end
+  const uint64_t q = max((uint64_t)kShareMin, ((uint64_t)E + (uint64_t)nblk - 1u) / (uint64_t)nblk);
+  const uint64_t lo = (uint64_t)own * q, hi = min(lo + q, (uint64_t)E);
+  if (lo >= hi) return;
+#pragma nounroll
+  for (int i = 0; i < nh; ++i) {
+    // (LDS reads land in vector registers: readfirstlane tells the compiler that these are the same in every lane --
+    // with a per-lane block number the second prologue's address arithmetic doubled the kernel's register count)
+    const uint64_t p0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.hl_pe[i]);
+    const uint64_t p1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.hl_pe[i + 1]);
+    if (p1 <= lo) continue;
+    if (p0 >= hi) break;
+    const int blk = __builtin_amdgcn_readfirstlane((int)l.hl_blk[i]);
+    const uint32_t s0 = thr + (uint32_t)(max(lo, p0) - p0), s1 = thr + (uint32_t)(min(hi, p1) - p0);
+    __syncthreads();                                       // the previous emission has read its prologue
+    k3_prologue_other(&l, blk, nblk, P, gx, T, per, g.rects, g.block_sums, g.block_band, super);
+    k3_emit(l, blk, s0, s1, gx, per, cap, tile_keys, vals);
   }
 }
 
@@ -738,6 +864,15 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 }  // namespace
 
+// HGS_K3_SHARE: how many heavy blocks K3 shares out at most (0: off; default and maximum kMaxHeavy) -- tests and A/B runs
+static int k3_share_max() {
+  static const int v = [] {
+    const char* e = getenv("HGS_K3_SHARE");
+    const int x = e ? atoi(e) : kMaxHeavy;
+    return x < 0 ? 0 : (x > kMaxHeavy ? kMaxHeavy : x);
+  }();
+  return v;
+}
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
                            hipStream_t s, const uint32_t* super, uint32_t* total_mirror) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
@@ -747,7 +882,7 @@ int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinW
     if (banded)
       hipLaunchKernelGGL(duplicate_tiles_banded_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), T,
                          band_tiles(T), g, L_cap, b.keys_in, b.vals_in, b.ranges, T * 2, super, total_mirror,
-                         tile_bin_zero_words(b.sort_tmp, L_cap, T), tile_bin_zero_count(T));
+                         tile_bin_zero_words(b.sort_tmp, L_cap, T), tile_bin_zero_count(T), k3_share_max());
     else
       hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
                          b.keys_in, b.vals_in, b.ranges, T * 2);

@@ -197,7 +197,7 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
 bool preprocess_fwd_splits(const hgs_raster_args& a);
 int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream_t s);
 // Superblocks of K1's workgroup sums: kSuper consecutive workgroups; the library-owned block holds (1 + kBands) rows of
-// kMaxSuper totals per (device, stream).  acquire: nullptr = take the scan launch (more than kMaxSuper superblocks is
+// kMaxSuper totals per (device, stream) and one row of the superblocks' largest workgroup sums.  acquire: nullptr = take the scan launch (more than kMaxSuper superblocks is
 // the caller's check).  mark_dirty: an error return left totals behind, zero them before the next use.
 constexpr int kSuper = 64;
 constexpr int kMaxSuper = 1024;

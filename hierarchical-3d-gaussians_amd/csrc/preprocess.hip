@@ -669,6 +669,10 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     if (super && threadIdx.x <= kBands && mine)
       __hip_atomic_fetch_add(&super[threadIdx.x * kMaxSuper + (blockIdx.x / kSuper)], mine, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
+    // ... and the superblock's LARGEST workgroup sum (row 1 + kBands): K3 shares out the emission of outliers (binning.hip)
+    if (super && threadIdx.x == 0 && mine)
+      __hip_atomic_fetch_max(&super[(1 + kBands) * kMaxSuper + (blockIdx.x / kSuper)], mine, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
   }
   // Plain layout: the block's loads are ISSUED here and land while the double-precision chain below runs -- K1 is
   // bound by latency, not by its arithmetic or by HBM.
@@ -1862,7 +1866,7 @@ std::mutex g_sync_mu;
 SyncBlock g_sync[kMaxSyncBlocks];
 int g_sync_n = 0;
 }  // namespace
-size_t super_block_bytes() { return (size_t)(1 + kBands) * kMaxSuper * sizeof(uint32_t); }
+size_t super_block_bytes() { return (size_t)(2 + kBands) * kMaxSuper * sizeof(uint32_t); }   // 9 rows of totals + the maxima
 uint32_t* super_block_acquire(hipStream_t s) {
   static const bool off = getenv("HGS_SCAN_LAUNCH") != nullptr;
   if (off) return nullptr;

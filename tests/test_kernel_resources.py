@@ -24,7 +24,7 @@ FRAME = {
     "preprocess_fwd_h48_kernel<false>": (96, 3),
     "preprocess_bwd_kernel<false, false>": (160, 3),
     "sh_bwd_kernel<false, true, false>": (72, 3),
-    "duplicate_tiles_banded_kernel": (40, 8),
+    "duplicate_tiles_banded_kernel": (56, 8),      # + the call into the rare path (heavy blocks shared out)
     "tile_depth_sort_wave_kernel<false>": (72, 7),
     "tb_count_kernel": (72, 7),             # count + column scan in one launch, 32 table words in flight per lane (round 5)
     "tb_scatter_kernel<true>": (72, 3),     # 16 instances per lane in flight, the chunk staged in LDS by tile (round 5)

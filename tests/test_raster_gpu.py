@@ -4,6 +4,7 @@ Mirrors how the reference calls the op (gaussian_renderer/__init__.py:44-64,105-
 single-chunk path; :247-277 for the hierarchy path)."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -876,3 +877,64 @@ def test_forwards_on_two_streams_keep_their_own_superblock_totals(gpu):
             bad += int((v["ranges"].to(torch.int64) != refs[k][1]).sum()) + int((v["point_list"].to(torch.int64) != refs[k][2]).sum())
     torch.cuda.synchronize()
     assert bad == 0
+
+
+_CLUSTERED_BIG = r"""
+import os, sys
+root, out = sys.argv[1], sys.argv[2]
+for p in (root, os.path.join(root, "hierarchical-3d-gaussians_amd"), os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+import parity as pa
+from hgs import synth
+import diff_gaussian_rasterization as dgr
+W, H = 640, 384
+cam = synth.make_camera(W, H)
+sc = synth.make_scene(12000, cam, seed=77)
+sc.scales[:300] *= 40.0                  # the first 300 rows cover hundreds of tiles each: workgroups 0 and 1 of K1 / K3
+sc = sc.to("cuda:0")
+rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device="cuda:0"))
+for it in range(3):                      # the first call sizes the workspaces; the later ones take the single-call path
+    L, color, radii, _, _, _, invd, call = dgr._C.rasterize_gaussians(
+        rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+        rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+        rs.interpolation_weights, rs.num_node_kids, False)
+    v = dgr._C.raster_views(call)
+torch.cuda.synchronize()
+np.savez(out, L=np.int64(L), ranges=v["ranges"].cpu().numpy(), point_list=v["point_list"].cpu().numpy(),
+         speculative=np.int64(dgr._C.stats["speculative_calls"]))
+"""
+
+
+def test_clustered_big_gaussians_are_shared_out(gpu, tmp_path):
+    """A hierarchy cut lists its big nodes side by side: one workgroup of K3 then has a hundred times the mean emission.
+    K3 shares the excess of such blocks out over all workgroups (binning.hip, the rare path); HGS_K3_SHARE=1 lists one
+    heavy block only (the second emits all of its own), HGS_K3_SHARE=0 turns the sharing off.  Ranges and sorted lists of
+    the single-call path against the oracle's binning, each setting in a process of its own (read once)."""
+    import subprocess
+    from oracle import raster_oracle as ro
+    W, H = 640, 384
+    cam = synth.make_camera(W, H)
+    sc = synth.make_scene(12000, cam, seed=77)
+    sc.scales[:300] *= 40.0
+    geom = ro.geometry_spec(sc.means3D.numpy(), sc.scales.numpy(), sc.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            cam.tanfovx, cam.tanfovy, 1.0)
+    b = ro.binning_spec(geom)
+    tt = geom.tiles_touched.astype(np.int64)
+    blocks = np.add.reduceat(tt, np.arange(0, len(tt), 256))
+    thr = max(4096, 4 * -(-int(tt.sum()) // len(blocks)))
+    assert int((blocks > thr).sum()) >= 2 and blocks[0] > 20 * np.median(blocks), (blocks[:3], thr)   # the case is the case
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name, env in (("default", {}), ("one", {"HGS_K3_SHARE": "1"}), ("off", {"HGS_K3_SHARE": "0"})):
+        out = str(tmp_path / f"{name}.npz")
+        r = subprocess.run([sys.executable, "-c", _CLUSTERED_BIG, root, out], env={**os.environ, **env},
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        d = np.load(out)
+        assert int(d["speculative"]) >= 2, name
+        assert int(d["L"]) == int(b.num_rendered), (name, int(d["L"]), int(b.num_rendered))
+        assert np.array_equal(d["ranges"].astype(np.int64).reshape(-1), b.ranges.astype(np.int64).reshape(-1)), name
+        assert np.array_equal(d["point_list"].astype(np.int64)[:int(d["L"])], b.point_list.astype(np.int64)), name
+
