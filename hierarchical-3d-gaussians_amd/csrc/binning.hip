@@ -135,6 +135,7 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // contiguous shares by blockIdx.  Static, no flags, nobody waits: the result does not depend on who emits a slot.
 constexpr uint32_t kHeavyFloor = 4096u, kHeavyFactor = 4u, kShareMin = 1024u;
 constexpr int kMaxHeavy = 256;
+constexpr int kShareMaxBlocks = 4096;   // 1 M rows
 
 struct K3Lds {
   uint32_t pre9[1 + kBands], tot9[1 + kBands];
@@ -367,10 +368,17 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
   uint32_t sbmax;
   k3_prologue<true>(l, own, nblk, P, gx, T, per, g, super, total_mirror, sbmax);
   const uint32_t total = l.excl[kPreBlock];
-  // heavy if above thr; every wave holds the whole row of superblock maxima, so the test is the same in all of them
-  const uint32_t L_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.tot9[0]);
-  const uint32_t thr = max(kHeavyFloor, kHeavyFactor * ((L_all + (uint32_t)nblk - 1u) / (uint32_t)nblk));
-  const bool any_heavy = super && share_max > 0 && __ballot(sbmax > thr) != 0ull;
+  // heavy if above thr; every wave holds the whole row of superblock maxima, so the test is the same in all of them.
+  // (The benchmark's frames stop at the floor: no division on the usual path.  Grids of more than kShareMaxBlocks
+  // workgroups are left alone: every workgroup reads all raw sums to build the list, 2 x nblk / 256 dependent loads per
+  // lane -- at 61 000 workgroups, the budgeted 50 M-node cut, that read alone took 12 ms.)
+  uint32_t thr = 0u;
+  bool any_heavy = false;
+  if (super && share_max > 0 && nblk <= kShareMaxBlocks && __ballot(sbmax > kHeavyFloor) != 0ull) {
+    const uint32_t L_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.tot9[0]);
+    thr = max(kHeavyFloor, kHeavyFactor * ((L_all + (uint32_t)nblk - 1u) / (uint32_t)nblk));
+    any_heavy = __ballot(sbmax > thr) != 0ull;
+  }
   if (!any_heavy) {
     k3_emit(l, own, 0u, total, gx, per, cap, tile_keys, vals);
     return;
