@@ -362,3 +362,33 @@ def test_live_pmc_collection_declines_under_a_profiler(monkeypatch):
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     t, v, why = bench.measure_pmc_live(types.SimpleNamespace(gaussians=1000, width=64, height=64), 64 * 64, 100)
     assert t is None and v is None and "under a profiler" in why
+
+
+def test_k3_share_partition_covers_every_excess_slot_exactly_once():
+    """The arithmetic of K3's rare path (csrc/binning.hip, duplicate_tiles_banded_kernel), restated: heavy blocks = raw
+    workgroup sums above thr = max(4096, 4 x the mean), in block order, at most `share_max` of them; a listed block's own
+    workgroup emits slots [0, thr), the listed blocks' excesses laid end to end are dealt out in contiguous shares of
+    q = max(1024, ceil(E / nblk)) by blockIdx.  Every slot of every block must be emitted exactly once whatever the
+    sums and whatever share_max."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    for nblk, share_max in ((47, 256), (47, 1), (1467, 256), (300, 7), (5, 256)):
+        sums = rng.integers(0, 1500, nblk).astype(np.int64)
+        heavy = rng.choice(nblk, size=min(nblk, 12), replace=False)
+        sums[heavy] = rng.integers(20_000, 300_000, len(heavy))
+        thr = max(4096, 4 * -(-int(sums.sum()) // nblk))
+        listed = [b for b in range(nblk) if sums[b] > thr][:share_max]
+        pe = np.concatenate([[0], np.cumsum([sums[b] - thr for b in listed])]).astype(np.int64)
+        E = int(pe[-1])
+        emitted = [np.zeros(int(n), dtype=np.int32) for n in sums]
+        q = max(1024, -(-E // nblk))
+        for wg in range(nblk):
+            emitted[wg][:(thr if wg in listed else sums[wg])] += 1                     # its own block
+            lo, hi = wg * q, min(wg * q + q, E)
+            for i, b in enumerate(listed):
+                if lo >= hi or pe[i + 1] <= lo or pe[i] >= hi:
+                    continue
+                s0, s1 = thr + max(lo, pe[i]) - pe[i], thr + min(hi, pe[i + 1]) - pe[i]
+                emitted[b][s0:s1] += 1
+        assert all((e == 1).all() for e in emitted), (nblk, share_max)
+
