@@ -830,6 +830,11 @@ def measure_exchange(dp, params, dev, rank, world, rccl_log, reps=8):
                         seen.add(key)
                         keep.append(key)
             out["rccl_trace"] = keep[:24]
+            # RCCL's own count of the communicator ("... nranks 8 ..." on its INIT lines) and the GPUs it names there
+            import re
+            nr = sorted({int(m.group(1)) for ln in lines for m in [re.search(r"nranks (\d+)", ln)] if m})
+            bus = sorted({m.group(1) for ln in lines for m in [re.search(r"busId ([0-9a-fA-F]+)", ln)] if m})
+            out["ranks_seen"] = {"nranks": nr, "bus_ids": bus[:16]}
             out["rccl_trace_note"] = ("unique lines of RCCL's INFO log (INIT, TUNING) that name an algorithm / protocol / "
                                       "channel count; algo 0 Tree 1 Ring, proto 0 LL 1 LL128 2 Simple in RCCL 2.2x")
         except OSError as e:
@@ -878,10 +883,30 @@ def main():
         print(json.dumps(cpu_baseline(scene, cam, torch.zeros(3), gc, gd, args.cpu_baseline_only)))
         return
 
+    # `--gpus N` means N ranks.  Launched plainly (no torchrun environment) with N > 1, the bench launches itself as the
+    # driver would: one process per GPU under torch.distributed.run on 127.0.0.1.  It refuses a node with fewer GPUs than
+    # ranks -- unless HGS_DP_BACKEND=gloo says the ranks are meant to share a GPU (the functional test of the N > 1 path).
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if torch.cuda.device_count() < args.gpus and os.environ.get("HGS_DP_BACKEND") != "gloo":
+            raise SystemExit(f"bench.py --gpus {args.gpus}: this node shows {torch.cuda.device_count()} GPU(s); "
+                             "one rank per GPU is the measured configuration (HGS_DP_BACKEND=gloo lets ranks share a GPU "
+                             "for a functional run)")
+        import socket
+        import subprocess
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} launched with WORLD_SIZE={os.environ['WORLD_SIZE']}: the two must agree")
+
     from hgs import _lib, dp, synth
     import diff_gaussian_rasterization as dgr
 
     rccl_log = None
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the first exchanges of the direct (peer-pointer) route check themselves against torch.distributed's all-reduce
+        os.environ.setdefault("HGS_P2P_VERIFY", "2")
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and os.environ.get("HGS_BENCH_RCCL_TRACE", "1") != "0":
         # the first SCALE record should explain itself: RCCL's own account of the algorithm / protocol it picked for the
         # bucket goes to a per-process file (never to stdout: the line below stays the only one) and is quoted in the line

@@ -163,8 +163,7 @@ hipError_t wait_event(hipEvent_t e) {
 
 // 1024-thread workgroups of the chained scan that are certainly resident together = compute units of the device -- as far
 // as this process can tell: the attribute does not see a CU mask (HSA_CU_MASK, ROC_GLOBAL_CU_MASK), so with one of them
-// in the environment the answer is 1 (a single chunk per array never looks back; larger jobs are refused with a
-// message).  The scan launch itself is the fallback route since round 5 (preprocess.hip: superblock totals).
+// in the environment the answer is 1 (the scans then run one chunk per launch: slow and correct).  The scan launch itself is the fallback route since round 5 (preprocess.hip: superblock totals).
 int scan_resident_workgroups() {
   static std::atomic<int> cus[kMaxDevices];
   static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
@@ -409,8 +408,14 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   }
   hipEvent_t colours_done = nullptr;
   if (split) {
-    HGS_HIP(hipEventRecord(th->fork[device], s));
-    HGS_HIP(hipStreamWaitEvent(aux, th->fork[device], 0));
+    // (K1 has added its sums to `super` by now: every error exit from here on marks the block dirty)
+    hipError_t fe = hipEventRecord(th->fork[device], s);
+    if (fe == hipSuccess) fe = hipStreamWaitEvent(aux, th->fork[device], 0);
+    if (fe != hipSuccess) {
+      set_error("hgs_raster_fwd: fork of the colour kernel failed: %s", hipGetErrorString(fe));
+      if (super) super_block_mark_dirty(super);
+      return HGS_ERR_HIP;
+    }
     rc = HGS_TIMED(ST_PREPROCESS_COLOR, aux, launch_preprocess_color(*a, g, aux));
     if (rc == HGS_OK && hipEventRecord(th->join[device], aux) != hipSuccess) { set_error("hgs_raster_fwd: event record failed"); rc = HGS_ERR_HIP; }
     if (rc) {                 // whatever did get enqueued on the second stream finishes before the caller's stream goes on
@@ -453,6 +458,8 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   }
   return HGS_OK;
 }
+
+int hgs_release_device_state(int device) { return super_block_release(device); }
 
 int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bin_ws, const void* img_ws,
                    void* bwd_ws, uint32_t L, const float* out_color, const float* out_invdepth,

@@ -112,17 +112,20 @@ __host__ __device__ inline int scan_chunks(size_t n) { return (int)((n + kScanCh
 // the look-back cannot deadlock whatever fits on the chip.  HIP does not PROMISE that dispatch order, so the launchers
 // do not lean on it: a grid of at most scan_resident_workgroups() workgroups is resident all at once (every compute unit
 // holds one 1024-thread workgroup of this kernel) and then no order matters; larger jobs are split into one launch per
-// array, and an array of more chunks than that (5e8 rows on 256 compute units) is refused.  `chain` must be ZERO when
+// array and per `resident` chunks of it (c_off: the look-back then reaches into launches that have completed).  `chain` must be ZERO when
 // the launch starts (the kernel that produces the sums clears it).  One workgroup walking the array 1024 entries per round cost 0.13 ms at the 96 k
 // sums of a 24.7 M-row view and 0.24 ms at the 195 k of a 50 M-node cut (one memory round trip + three barriers per
 // round, nothing to overlap them with); the 24 chunk workgroups take one round each.
 // Returns the grand total in the LAST chunk's threads (0 elsewhere).
+// c / chunks: this workgroup's chunk and the number of chunks (default: blockIdx.x of gridDim.x; a launch of `resident`
+// workgroups at a time passes its offset -- the chunks of earlier launches have published their totals long ago).
 __device__ __forceinline__ uint32_t chained_scan_inplace(uint32_t* __restrict__ sums, int n,
-                                                         unsigned long long* __restrict__ chain) {
+                                                         unsigned long long* __restrict__ chain, int c_off = 0,
+                                                         int chunks_all = 0) {
   __shared__ uint32_t scan_wave_tot[16];
   __shared__ uint32_t scan_prefix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c = blockIdx.x, chunks = gridDim.x;
+  const int c = (int)blockIdx.x + c_off, chunks = chunks_all ? chunks_all : (int)gridDim.x;
   const int i0 = c * kScanChunk + tid * kScanPer;
   // all loads are issued before the first is waited for (clamped index + select, no branch per load)
   uint32_t v[kScanPer], mine = 0;
@@ -204,6 +207,7 @@ constexpr int kMaxSuper = 1024;
 uint32_t* super_block_acquire(hipStream_t s);
 size_t super_block_bytes();
 void super_block_mark_dirty(const uint32_t* words);
+int super_block_release(int device);   // frees the blocks of a device (< 0: all); returns how many
 // scans block_sums and the kBands columns of block_band (one launch while the grid is resident at once, else one per array)
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror = nullptr);
 // banded: one instance stream per tile band (b.keys_in = band-local tile ids), else one stream of global tile ids

@@ -132,8 +132,9 @@ __global__ __launch_bounds__(256) void lod_block_sums_kernel(const uint32_t* __r
 }
 
 __global__ __launch_bounds__(1024) void lod_scan_sums_kernel(uint32_t* __restrict__ sums, int n,
-                                                             unsigned long long* __restrict__ chain) {
-  (void)chained_scan_inplace(sums, n, chain);
+                                                             unsigned long long* __restrict__ chain, int c_off,
+                                                             int chunks) {
+  (void)chained_scan_inplace(sums, n, chain, c_off, chunks);
 }
 
 __global__ __launch_bounds__(256) void lod_emit_kernel(const int32_t* __restrict__ nodes,
@@ -242,13 +243,13 @@ static int expand_finish(const int32_t* nodes, const ExpandTmp& t, int32_t N, in
                          int32_t* parent_indices, int32_t* nodes_for_render_indices, int32_t capacity,
                          int32_t* count_out_host, hipStream_t s) {
   const int nblk = (N + 255) / 256;
-  if (scan_chunks(nblk) > scan_resident_workgroups()) {
-    set_error("expand_to_size: %d nodes need %d scan workgroups, the device holds %d at once", N, scan_chunks(nblk),
-              scan_resident_workgroups());
-    return HGS_ERR_INVALID;
+  // (at most `resident` chunk workgroups per launch: common.h, chained_scan_inplace)
+  const int chunks = scan_chunks(nblk), resident = scan_resident_workgroups();
+  for (int c0 = 0; c0 < chunks; c0 += resident) {
+    hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(min(resident, chunks - c0)), dim3(1024), 0, s, t.block_sums, nblk, t.chain,
+                       c0, chunks);
+    HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
   }
-  hipLaunchKernelGGL(lod_scan_sums_kernel, dim3(scan_chunks(nblk)), dim3(1024), 0, s, t.block_sums, nblk, t.chain);
-  HGS_LAUNCH_CHECK("lod_scan_sums", s, false);
   hipLaunchKernelGGL(lod_emit_kernel, dim3(nblk), dim3(256), 0, s, nodes, t.emit_cnt, N, t.block_sums,
                      render_indices, parent_indices, nodes_for_render_indices, capacity);
   HGS_LAUNCH_CHECK("lod_emit", s, false);

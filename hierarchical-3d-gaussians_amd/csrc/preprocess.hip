@@ -966,10 +966,11 @@ __global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_geom_h
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(uint32_t* __restrict__ sums0,
                                                                uint32_t* __restrict__ bands, int n,
                                                                unsigned long long* __restrict__ chain,
-                                                               uint32_t* __restrict__ total_mirror) {
+                                                               uint32_t* __restrict__ total_mirror, int c_off,
+                                                               int chunks) {
   uint32_t* __restrict__ sums = blockIdx.y == 0 ? sums0 : bands + (size_t)(blockIdx.y - 1) * (n + 1);
-  const uint32_t total = chained_scan_inplace(sums, n, chain + (size_t)blockIdx.y * gridDim.x);
-  if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x == gridDim.x - 1 && total_mirror) *total_mirror = total;
+  const uint32_t total = chained_scan_inplace(sums, n, chain + (size_t)blockIdx.y * chunks, c_off, chunks);
+  if (threadIdx.x == 0 && blockIdx.y == 0 && (int)blockIdx.x + c_off == chunks - 1 && total_mirror) *total_mirror = total;
 }
 
 // ---------------------------------------------------------------------------
@@ -1870,6 +1871,13 @@ size_t super_block_bytes() { return (size_t)(2 + kBands) * kMaxSuper * sizeof(ui
 uint32_t* super_block_acquire(hipStream_t s) {
   static const bool off = getenv("HGS_SCAN_LAUNCH") != nullptr;
   if (off) return nullptr;
+  // hipStreamPerThread is ONE handle for a different stream in every host thread: two threads' frames would share a block
+  // and interleave their sums.  A capturing stream must not see the allocation / memset of a first use.  Both take the
+  // scan launch.
+  if (s == hipStreamPerThread) return nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (cap != hipStreamCaptureStatusNone) return nullptr;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   std::lock_guard<std::mutex> lk(g_sync_mu);
@@ -1888,6 +1896,24 @@ uint32_t* super_block_acquire(hipStream_t s) {
   if (hipMemsetAsync(w, 0, super_block_bytes(), s) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(w); return nullptr; }
   g_sync[g_sync_n++] = {dev, s, w, false};
   return w;
+}
+// Frees the blocks of `device` (all devices: < 0).  The caller guarantees that no call of this library is in flight there.
+int super_block_release(int device) {
+  std::lock_guard<std::mutex> lk(g_sync_mu);
+  int kept = 0, freed = 0;
+  for (int i = 0; i < g_sync_n; ++i) {
+    if (device < 0 || g_sync[i].device == device) {
+      int cur = 0;
+      const bool sw = hipGetDevice(&cur) == hipSuccess && cur != g_sync[i].device && hipSetDevice(g_sync[i].device) == hipSuccess;
+      (void)hipFree(g_sync[i].words);
+      if (sw) (void)hipSetDevice(cur);
+      ++freed;
+    } else {
+      g_sync[kept++] = g_sync[i];
+    }
+  }
+  g_sync_n = kept;
+  return freed;
 }
 void super_block_mark_dirty(const uint32_t* words) {
   std::lock_guard<std::mutex> lk(g_sync_mu);
@@ -1943,22 +1969,22 @@ int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream
 int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug, uint32_t* total_mirror) {
   const int nblk = (P + kPreBlock - 1) / kPreBlock;
   const int chunks = scan_chunks(nblk), resident = scan_resident_workgroups();
-  if (chunks > resident) {
-    set_error("scan_block_sums: %d rows need %d scan workgroups per array, the device holds %d at once", P, chunks, resident);
-    return HGS_ERR_INVALID;
-  }
   if (chunks * (1 + kBands) <= resident && !scan_split_forced()) {
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(chunks, 1 + kBands), dim3(1024), 0, s, g.block_sums, g.block_band,
-                       nblk, g.scan_chain, total_mirror);
+                       nblk, g.scan_chain, total_mirror, 0, chunks);
     HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
     return HGS_OK;
   }
-  // one launch per array (the kernel's row 0 scans its first pointer); above 58.7 M rows on 256 compute units
+  // one launch per array (the kernel's row 0 scans its first pointer) and per `resident` chunks of it: a chunk only looks
+  // back at chunks of its own launch -- resident together with it -- or of launches that have completed.  (A CU mask in
+  // the environment makes `resident` 1: one launch per chunk, slow and correct.)
   for (int y = 0; y < 1 + kBands; ++y) {
     uint32_t* sums = y == 0 ? g.block_sums : g.block_band + (size_t)(y - 1) * (nblk + 1);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(chunks, 1), dim3(1024), 0, s, sums, g.block_band, nblk,
-                       g.scan_chain + (size_t)y * chunks, y == 0 ? total_mirror : nullptr);
-    HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+    for (int c0 = 0; c0 < chunks; c0 += resident) {
+      hipLaunchKernelGGL(scan_block_sums_kernel, dim3(min(resident, chunks - c0), 1), dim3(1024), 0, s, sums, g.block_band,
+                         nblk, g.scan_chain + (size_t)y * chunks, y == 0 ? total_mirror : nullptr, c0, chunks);
+      HGS_LAUNCH_CHECK("scan_block_sums", s, debug);
+    }
   }
   return HGS_OK;
 }

@@ -32,6 +32,9 @@ constexpr int kGroups = 8;
 #ifndef HGS_TB_BATCH
 #define HGS_TB_BATCH 16
 #endif
+#ifndef HGS_TB_STRICT
+#define HGS_TB_STRICT 0
+#endif
 #ifndef HGS_TB_STAGED
 #define HGS_TB_STAGED 1
 #endif
@@ -80,8 +83,8 @@ __device__ __forceinline__ void store_sc1(uint32_t* p, uint32_t v) {      // wri
 // on the group's arrival counter -- scans the group's rows per tile (exclusive, in place), stores the group sums and
 // adds them to the tile totals.  Nobody waits for anybody.  Hand-over = recipe R1 of cdna_hip_programming.md Guideline
 // 16: the rows are stored WRITE-THROUGH (sc1), every storing wave drains its stores, then one lane arrives (agent-scope
-// atomic); the finishing workgroup runs one agent-scope acquire (its vector L1; its L2 never held these lines: sc1 stores
-// do not leave them there) before it reads the rows with plain loads.  Placement only decides speed (a band's
+// atomic); every wave of the finishing workgroup runs an agent-scope acquire (its vector L1; its L2 never held these lines: sc1
+// stores do not leave them there) before it reads the rows with plain loads.  Placement only decides speed (a band's
 // workgroups share an XCD), never the result.  `totals` and `arrive` are zero on entry (cleared by K3).
 // `super` (may be null): K1's superblock totals, consumed by K3 -- zeroed here for the next frame on this stream.
 __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __restrict__ keys, uint32_t cap,
@@ -122,13 +125,15 @@ __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its row stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t before = __hip_atomic_fetch_add(&arrive[band * kGroups + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t done = before == (uint32_t)(c1 - c0 - 1);
-    if (done) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    completes_group = done;
+    // (HGS_TB_STRICT: the arrival as a RELEASE in the language's memory model -- on gfx950 an L2 write-back in front of
+    // the atomic; the rows were stored write-through and drained above, which is what the hardware needs)
+    const uint32_t before = __hip_atomic_fetch_add(&arrive[band * kGroups + g], 1u,
+                                                   HGS_TB_STRICT ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    completes_group = before == (uint32_t)(c1 - c0 - 1);
   }
   __syncthreads();
   if (!completes_group) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // EVERY wave of the scanning workgroup, before its first load
   uint32_t* tb0 = table + (size_t)band * max_chunks * per;
   // two tile columns x kRowBatch rows in flight per lane (a column at a time, eight rows at a time, was eight dependent
   // round trips for a group of ten chunks at 1080p: the tail of this launch)

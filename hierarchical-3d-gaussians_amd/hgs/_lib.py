@@ -95,6 +95,7 @@ SIGNATURES = {
     "hgs_raster_fwd_stage2": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, C.c_uint32, _P, _P, _P, C.c_int]),
     "hgs_raster_fwd": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, C.c_uint32, _P, _P, _P, C.POINTER(C.c_uint32), _P,
                                  C.c_int]),
+    "hgs_release_device_state": (C.c_int, [C.c_int]),
     "hgs_raster_bwd": (C.c_int, [C.POINTER(RasterArgs), _P, _P, _P, _P, C.c_uint32, _P, _P, _P, _P,
                                  C.POINTER(RasterGrads), _P, C.c_int]),
     "hgs_raster_views_get": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_uint32, _P, _P, _P,

@@ -167,11 +167,17 @@ int hgs_raster_fwd_stage2(const hgs_raster_args* a, void* geom_ws, void* bin_ws,
  * select a copy / a sleeping wait instead -- same results).  If L > L_cap it returns HGS_ERR_CAPACITY,
  * the outputs are invalid and the caller continues with hgs_raster_fwd_stage2 on an exactly sized bin_ws
  * (geom_ws / radii from this call stay valid).  Later calls (backward, views) must pass the same L_cap as L.
- * Library state: this entry point keeps, per (device, stream), 36 KB of zeroed device memory between calls (K1 adds its
- * workgroup sums there, a later kernel of the same call clears them; INTEGRATION.md "What the library keeps"). */
+ * Library state: this entry point keeps, per (device, stream), 40 KB of zeroed device memory between calls (K1 adds its
+ * workgroup sums there, a later kernel of the same call clears them; INTEGRATION.md "What the library keeps").  Not for
+ * hipStreamPerThread (one handle, one stream per host thread) and not for a capturing stream: both take the scan launch.
+ * hgs_release_device_state frees the blocks. */
 int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* img_ws, uint32_t L_cap,
                    int32_t* radii, float* out_color, float* out_invdepth, uint32_t* L_out_host,
                    hgs_stream_t stream, int device);
+
+/* Frees what hgs_raster_fwd keeps per (device, stream) for `device` (< 0: every device); returns the number of blocks
+ * freed.  No call of the library may be in flight on that device.  The next forward on a stream creates its block again. */
+int hgs_release_device_state(int device);
 
 typedef struct hgs_raster_grads {
   float* dL_dmeans3D;   /* [P,3] */

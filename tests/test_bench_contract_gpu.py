@@ -80,3 +80,27 @@ def test_bench_two_ranks_as_the_driver_launches_them(gpu):
     pv = d["per_view_dp"]
     assert pv["global_batch"] == 2 and pv["views_per_step_per_gpu"] == 1 and pv["value"] > 0
     assert abs(pv["value"] - 2 * 1e3 / pv["ms_per_step"]) <= 1e-6 * pv["value"] and 0 < pv["exchange_share_of_step"]
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_launched_plainly_means_two_ranks(gpu):
+    """`python bench.py --gpus 2` with no torchrun environment launches itself under torch.distributed.run: the line says
+    n_gpus 2.  (Two ranks on the one GPU over gloo, as above; without HGS_DP_BACKEND=gloo a node with fewer GPUs than
+    ranks is refused with a non-zero exit and no line.)"""
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    small = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--gaussians", "20000", "--width", "320", "--height", "192",
+             "--views-per-step", "2"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT, env=dict(env, HGS_DP_BACKEND="gloo"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["exchange"]["backend"] == "gloo"
+    if torch.cuda.device_count() < 2:
+        env.pop("HGS_DP_BACKEND", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + small, capture_output=True, text=True,
+                           timeout=300, cwd=ROOT, env=env)
+        assert r.returncode != 0 and not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+        assert "GPU" in r.stderr
