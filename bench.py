@@ -34,6 +34,8 @@ At N = 1 the same JSON line carries ``extra``: the other BASELINE.json configura
 the same schema (value, ms_per_step, stages_ms, roofline from THAT run's P / V / L):
   config2_300k            300 k Gaussians at 1080p, the train_single.py call shape (configs[1])
   heavy_1m                1 M Gaussians with s_px in [1, 8] (SURVEY App. C "heavy": L ~ 4.9 M, ~600 instances per tile)
+  trained_like_10m        375 k Gaussians with the statistics of a scene train_single.py trained at 1080p (L ~ 10 M, lists > 3 000)
+  trained_cut_10m         the same in the row order of a hierarchy cut (big nodes side by side)
   config3_train_post      train_post.py-shaped step on a merged 2-chunk hierarchy (configs[2])
   config5_50m_4k_render   50 M-node hierarchy, cut + weights + 3840x2160 render per frame as render_hierarchy.py (configs[4])
 Prints ONE JSON line on rank 0.
@@ -708,6 +710,15 @@ def run_extras(args, dev, measure):
         "heavy_1m": lambda: extra_dropin("heavy_1m", synth.make_scene(1_000_000, cam, seed=0, s_px=(1.0, 8.0)), W, H, dev,
                                          measure, 40, 8, "the metric configuration with heavier footprints: 1 M Gaussians, "
                                          "s_px in [1, 8] (SURVEY App. C 'heavy 1 M'), 1080p, fwd+bwd"),
+        # what the reference's scripts hand to the op after training at 1080p (profiles/r05_config2_config3_scripts.log)
+        "trained_like_10m": lambda: extra_dropin("trained_like_10m", synth.make_scene_trained_scale(375_000, cam, seed=0), W, H,
+                                                 dev, measure, 30, 8, "the statistics of a scene train_single.py trained at "
+                                                 "1080p (train_single.py:97-176): 375 k Gaussians, ~28 tile instances per "
+                                                 "Gaussian, L ~ 10 M, lists of ~1 300 on average and > 3 000 at most, fwd+bwd"),
+        "trained_cut_10m": lambda: extra_dropin("trained_cut_10m", synth.make_scene_trained_scale(375_000, cam, seed=0, order="clustered"),
+                                                W, H, dev, measure, 30, 8, "the same scene in the row order of a hierarchy cut "
+                                                "(train_post.py:91-142): the cut's big nodes side by side, one K1 workgroup's "
+                                                "rows emitting 840 k instances against a mean of 7 k, fwd+bwd"),
         "config3_train_post": lambda: extra_train_post(dev, measure, 40, 8),
         "config5_50m_4k_render": lambda: extra_config5(dev, *C5_STEPS),
         "config5_budgeted_6gb": lambda: extra_config5_budgeted(dev, 32, 8),
@@ -866,7 +877,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the `extra` objects (BASELINE configs 2 / 3 / 5 and the heavy 1 M variant)")
-    ap.add_argument("--extras", default="config2_300k,heavy_1m,config3_train_post,config5_50m_4k_render,config5_budgeted_6gb")
+    ap.add_argument("--extras", default="config2_300k,heavy_1m,trained_like_10m,trained_cut_10m,config3_train_post,config5_50m_4k_render,config5_budgeted_6gb")
     ap.add_argument("--no-stage-timing", action="store_true")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="do not collect the PMC counters of the roofline object in this run (rocprofv3 child processes, "

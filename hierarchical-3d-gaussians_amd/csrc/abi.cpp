@@ -502,7 +502,8 @@ int hgs_raster_bwd(const hgs_raster_args* a, const void* geom_ws, const void* bi
     HGS_HIP(hipMemsetAsync(lod_flag, 0, sizeof(uint32_t), s));
     if ((rc = launch_lod_monotone(a->lod_parent_indices, a->lod_n, lod_flag, s))) return rc;
   }
-  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, bwd_ws_dmean(bwd_ws, L, a->P), lod_flag, gr, L, s));
+  return HGS_TIMED(ST_PREPROCESS_BWD, s, launch_preprocess_bwd(*a, g, inst, drgb, bwd_ws_dmean(bwd_ws, L, a->P), lod_flag, gr, L,
+                                                             bwd_ws_work(bwd_ws, L, a->P), bwd_ws_work_counter(bwd_ws, L, a->P), s));
 }
 
 int hgs_raster_sh_bwd_batched(const hgs_sh_bwd_view* views, int32_t n_views, int32_t P, int32_t M, int32_t sh_degree,

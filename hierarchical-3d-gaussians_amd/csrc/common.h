@@ -231,11 +231,11 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s);
 // dmean_rows / lod_flag: scratch of the in-kernel LOD scatter (hgs_raster_args.lod_scatter): the per-row mean gradient
 // K8a hands to K8b, and the "parent indices are not non-decreasing" word (set by launch_lod_monotone)
-// L: the frame's instance count (a frame of long runs sums them with a kernel of its own in front of K8a; inst_grads is
-// consumed: that kernel leaves a long run's sums over the run's first records)
+// L: the frame's instance count (a frame of long runs sums them with kernels of their own in front of K8a; inst_grads is
+// consumed: they leave every segment's sums over the segment's first records); work / work_counter: bwd_ws_work*
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, uint32_t L,
-                          hipStream_t s);
+                          uint2* work, uint32_t* work_counter, hipStream_t s);
 int launch_lod_monotone(const int32_t* parent_indices, int32_t n, uint32_t* flag, hipStream_t s);
 // Per-view device pointers of the batched SH kernels.  Kept small (24 pointers): they are kernel arguments and must
 // stay in scalar registers across the view loop.
@@ -268,8 +268,18 @@ inline float* bwd_ws_dmean(void* bwd_ws, uint32_t L, int32_t P) {
 inline uint32_t* bwd_ws_lod_flag(void* bwd_ws, uint32_t L, int32_t P) {
   return reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(bwd_ws_dmean(bwd_ws, L, P)) + align_up((size_t)(P > 0 ? P : 1) * 3 * 4));
 }
+// behind the flag word (same 256-byte block): the counter of the long-run worklist of K8, and the worklist itself -- one
+// (Gaussian, segment) pair per kK8Seg records of every run of more than kK8LongRun records (preprocess.hip)
+constexpr uint32_t kK8LongRun = 48;
+constexpr uint32_t kK8Seg = 512;
+inline uint32_t* bwd_ws_work_counter(void* bwd_ws, uint32_t L, int32_t P) { return bwd_ws_lod_flag(bwd_ws, L, P) + 16; }
+inline uint2* bwd_ws_work(void* bwd_ws, uint32_t L, int32_t P) {
+  return reinterpret_cast<uint2*>(reinterpret_cast<char*>(bwd_ws_lod_flag(bwd_ws, L, P)) + kAlign);
+}
+inline size_t bwd_ws_work_items(uint32_t L) { return (size_t)(L ? L : 1) / kK8LongRun + 2; }   // a run of n > 48 records has <= n / 48 segments
 inline size_t bwd_ws_bytes(uint32_t L, int32_t P) {
-  return align_up((size_t)(L ? L : 1) * kInstStride * 4) + 2 * align_up((size_t)(P > 0 ? P : 1) * 3 * 4) + 2 * kAlign;
+  return align_up((size_t)(L ? L : 1) * kInstStride * 4) + 2 * align_up((size_t)(P > 0 ? P : 1) * 3 * 4) + 2 * kAlign +
+         align_up(bwd_ws_work_items(L) * sizeof(uint2));
 }
 // tile binning without a sort (tile_bin.hip); tmp shares BinWs::sort_tmp
 bool tile_bin_supported(int32_t T);

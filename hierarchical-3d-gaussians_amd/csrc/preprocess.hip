@@ -1017,36 +1017,75 @@ __device__ __forceinline__ void lod_add(float* dst, float v, bool atomic) {
 // K8a sums each Gaussian's run of instance records (one lane per Gaussian).  Benchmark scenes have 2.7 records per
 // Gaussian; a TRAINED scene at 1080p has 28 on average and Gaussians that cover thousands of tiles (the 1080p run of
 // profiles/r05_config2_config3_scripts_run1.log: K8 1.9 ms of a 3.6 ms frame, 11.7 ms on a hierarchy cut -- one lane
-// walking 3 000 records while 63 wait).  When the frame's mean run is long (launch_preprocess_bwd) this kernel runs in
-// front of K8a: one wave per 64 Gaussians, every run of more than kK8LongRun records is summed by the WHOLE wave
-// (lane i takes records i, i + 64, ...: consecutive 40-byte records, coalesced; double-precision partial sums; lanes
-// 0 .. 9 fold the 64 partials of one component each) and the ten sums are stored, as doubles, OVER THE RUN'S FIRST TWO
-// RECORDS -- the run is consumed, nobody else reads it.  K8a then takes a long run's sums from there.
-constexpr uint32_t kK8LongRun = 48;
-constexpr int kPresumPerWave = 8;        // Gaussians per wave: a hierarchy cut lists its big (interior) nodes side by side --
-                                         // 64 long runs behind one another in one wave made K8 0.96 ms on such a cut
-__global__ __launch_bounds__(kPreBlock) void k8_presum_long_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+// walking 3 000 records while 63 wait).  When the frame's mean run is long (launch_preprocess_bwd) two kernels run in
+// front of K8a.  Round 5 gave a wave 8 consecutive Gaussians whatever their runs; a hierarchy cut lists its big nodes side
+// by side (4 096 rows holding a third of the frame's records), so a few hundred waves on a few compute units did all the
+// work: 0.47 ms.  Now the RECORDS are dealt out:
+//   k8_worklist_kernel   every run of more than kK8LongRun records is cut into segments of kK8Seg records and one
+//                        (Gaussian, segment) pair per segment goes onto a worklist (a workgroup reserves its pairs' places
+//                        with one atomic add: the ORDER of the list is not deterministic, what a pair stands for is);
+//   k8_presum_work_kernel a fixed grid of waves takes the pairs in turn: lane i sums records i, i + 64, ... of the segment
+//                        (consecutive 40-byte records, coalesced; double-precision partial sums), the 64 partials of each of
+//                        the ten components are folded in a fixed order and the ten sums are stored, as doubles, OVER THE
+//                        SEGMENT'S FIRST TWO RECORDS -- the segment is consumed, nobody else reads it.
+// K8a then adds a long run's segment sums in segment order.  Every sum is a fixed tree: bit-reproducible.
+__device__ __forceinline__ uint32_t k8_nseg(uint32_t n) {        // n > kK8LongRun; the last segment holds >= 2 records
+  uint32_t c = (n + kK8Seg - 1u) / kK8Seg;
+  if (c > 1u && n - (c - 1u) * kK8Seg < 2u) --c;
+  return c;
+}
+__global__ __launch_bounds__(kPreBlock) void k8_worklist_kernel(int P, const uint32_t* __restrict__ tiles_touched,
+                                                                uint2* __restrict__ work, uint32_t* __restrict__ counter) {
+  __shared__ uint32_t wave_tot[kPreBlock / 64];
+  __shared__ uint32_t base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
+  const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
+  const uint32_t c = n > kK8LongRun ? k8_nseg(n) : 0u;
+  uint32_t inc = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kPreBlock / 64; ++w) {
+    const uint32_t t = wave_tot[w];
+    before += w < wave ? t : 0u;
+    total += t;
+  }
+  if (total == 0u) return;                                               // (workgroup-uniform)
+  if (threadIdx.x == 0) base_s = atomicAdd(counter, total);
+  __syncthreads();
+  uint2* dst = work + base_s + before + inc - c;
+  for (uint32_t j = 0; j < c; ++j) dst[j] = make_uint2((uint32_t)idx, j);
+}
+
+constexpr int kPresumGrid = 2048;        // workgroups of four waves: every wave takes pairs w, w + 8192, ...
+__global__ __launch_bounds__(kPreBlock) void k8_presum_work_kernel(const uint2* __restrict__ work,
+                                                                   const uint32_t* __restrict__ counter,
+                                                                   const uint32_t* __restrict__ tiles_touched,
                                                                    const uint32_t* __restrict__ offsets,
                                                                    float* __restrict__ inst) {
-  __shared__ double red_all[kPreBlock / 64][640];
+  __shared__ double red_all[kPreBlock / 64][640 + 40];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int idx = (blockIdx.x * (kPreBlock / 64) + wave) * kPresumPerWave + lane;      // lanes 0 .. 7: the wave's Gaussians
-  const uint32_t n = (lane < kPresumPerWave && idx < P) ? tiles_touched[idx] : 0u;
-  unsigned long long todo = __ballot(n > kK8LongRun);
-  if (todo == 0ull) return;
-  const uint32_t off_mine = n > kK8LongRun ? offsets[idx] : 0u;
+  const uint32_t n_work = *counter;
   double* red = red_all[wave];
-  while (todo) {                                                         // (wave-uniform)
-    const int owner = __ffsll((long long)todo) - 1;
-    todo &= todo - 1ull;
-    const uint32_t rn = (uint32_t)__shfl((int)n, owner, 64);
-    const size_t rbase = (size_t)__shfl(off_mine, owner, 64);
+  for (uint32_t item = blockIdx.x * (kPreBlock / 64) + wave; item < n_work; item += gridDim.x * (kPreBlock / 64)) {   // (wave-uniform)
+    const uint2 w = work[item];
+    const uint32_t n = tiles_touched[w.x];
+    const uint32_t r0 = w.y * kK8Seg;
+    const uint32_t r1 = (w.y + 1u == k8_nseg(n)) ? n : r0 + kK8Seg;
+    const size_t rbase = (size_t)offsets[w.x] + r0;
     const float2* ip = reinterpret_cast<const float2*>(inst) + rbase * 5;
     double t[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) t[i] = 0.0;
 #pragma unroll 4
-    for (uint32_t k = (uint32_t)lane; k < rn; k += 64u) {
+    for (uint32_t k = (uint32_t)lane; k < r1 - r0; k += 64u) {
       const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
       t[0] += v0.x; t[1] += v0.y; t[2] += v1.x; t[3] += v1.y;
       t[4] += v2.x; t[5] += v2.y; t[6] += v3.x; t[7] += v3.y;
@@ -1057,14 +1096,23 @@ __global__ __launch_bounds__(kPreBlock) void k8_presum_long_kernel(int P, const 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (lane < 10) {
+    // fold in two fixed stages: lane 4 c + q sums partials 16 q .. 16 q + 15 of component c, lane c the four quarter sums
+    if (lane < 40) {
       double acc = 0.0;
-#pragma unroll 8
-      for (int j = 0; j < 64; ++j) acc += red[lane * 64 + j];
-      reinterpret_cast<double*>(inst + rbase * kInstStride)[lane] = acc;   // (40-byte records: 8-byte aligned)
+      const double* src = red + (lane >> 2) * 64 + (lane & 3) * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc += src[j];
+      red[640 + lane] = acc;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();                                     // (the next long run overwrites the scratch)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < 10) {
+      const double* q = red + 640 + lane * 4;
+      reinterpret_cast<double*>(inst + rbase * kInstStride)[lane] = ((q[0] + q[1]) + q[2]) + q[3];   // (40-byte records: 8-byte aligned)
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                     // (the next pair overwrites the scratch)
   }
 }
 
@@ -1100,8 +1148,9 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
   // Two routes per wave:
   //   * (always in frames of short runs, launch_preprocess_bwd) the wave streams its contiguous range of records through
   //     LDS, each lane sums its own run from there;
-  //   * `presummed` and a run of more than kK8LongRun records in the wave: k8_presum_long_kernel left that run's ten sums
-  //     at its start; the other lanes walk their short runs in global memory (the wave's range is mostly the long run).
+  //   * `presummed` and a run of more than kK8LongRun records in the wave: k8_presum_work_kernel left every segment's ten
+  //     sums at the segment's start; the other lanes walk their short runs in global memory (the wave's range is mostly
+  //     the long run).
   {
     constexpr uint32_t kStageRec = 256;                                  // records per wave and pass: 10 KB
     __shared__ float2 stage[kPreBlock / 64][kStageRec * 5];
@@ -1168,9 +1217,12 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
     } else if (n != 0u) {
       const size_t off = (size_t)g.offsets[idx];
       if (n > kK8LongRun) {
-        const double* ps = reinterpret_cast<const double*>(inst + off * kInstStride);
+        const uint32_t nseg = k8_nseg(n);
+        for (uint32_t j = 0; j < nseg; ++j) {                              // segment sums, in segment order
+          const double* ps = reinterpret_cast<const double*>(inst + (off + (size_t)j * kK8Seg) * kInstStride);
 #pragma unroll
-        for (int i = 0; i < 10; ++i) s[i] = ps[i];
+          for (int i = 0; i < 10; ++i) s[i] += ps[i];
+        }
       } else {
         const float2* ip = reinterpret_cast<const float2*>(inst) + off * 5;
 #pragma unroll 2
@@ -1991,16 +2043,19 @@ int launch_scan_block_sums(const GeomWs& g, int32_t P, hipStream_t s, bool debug
 
 int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float* inst_grads, float* drgb,
                           float* dmean_rows, const uint32_t* lod_flag, const hgs_raster_grads& out, uint32_t L,
-                          hipStream_t s) {
+                          uint2* work, uint32_t* work_counter, hipStream_t s) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     // long runs first, when the frame has them: mean run above 6 records (L > 6 P; HGS_K8_PRESUM=0 / 1 forces)
     static const char* force = getenv("HGS_K8_PRESUM");
     const bool presum = force ? force[0] == '1' : (uint64_t)L > 6ull * (uint64_t)a.P;
     if (presum) {
-      const int per_wg = (kPreBlock / 64) * kPresumPerWave;
-      hipLaunchKernelGGL(k8_presum_long_kernel, dim3((a.P + per_wg - 1) / per_wg), dim3(kPreBlock), 0, s, a.P,
-                         g.tiles_touched, g.offsets, const_cast<float*>(inst_grads));
+      HGS_HIP(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s));
+      hipLaunchKernelGGL(k8_worklist_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.tiles_touched, work, work_counter);
+      HGS_LAUNCH_CHECK("preprocess_bwd_worklist", s, a.debug);
+      const int want = (int)(((size_t)L / 64 + 3) / 4);                   // no more workgroups than a pair each could use
+      hipLaunchKernelGGL(k8_presum_work_kernel, dim3(want < 1 ? 1 : (want < kPresumGrid ? want : kPresumGrid)), dim3(kPreBlock), 0,
+                         s, work, work_counter, g.tiles_touched, g.offsets, const_cast<float*>(inst_grads));
       HGS_LAUNCH_CHECK("preprocess_bwd_long_runs", s, a.debug);
     }
     auto k8a = a.lod_render_indices ? preprocess_bwd_kernel<false, true>      // (accumulation is refused with lod, abi.cpp)

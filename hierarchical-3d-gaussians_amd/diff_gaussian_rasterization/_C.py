@@ -101,6 +101,46 @@ def _plan(lib, P, W, H, L_ws):
     return pl
 
 
+def size_class(n, steps_per_octave=4, floor=1 << 20):
+    """``n`` rounded up to the next size class: 2^(k / steps_per_octave) above ``floor`` (19 % steps: 9 % over-allocation on
+    average).  The workspace arena of a frame and the row capacity of its gradient tensors change with every view and
+    every cut (train_post.py renders another cut per iteration); asked for byte-exact sizes, torch's caching allocator
+    kept splitting and re-requesting 100 MB-blocks -- 11.0 GB reserved for a 3.1 GB peak in the round-5 run of
+    train_post.py at 1080p, and a hipMalloc inside one step in three of the trained-scale bench.  A handful of classes per
+    octave makes every request an exact fit of a cached block."""
+    n = int(n)
+    if n <= floor:
+        return n
+    e = (n - 1).bit_length() - 1                      # 2^e < n <= 2^(e + 1)
+    for k in range(1, steps_per_octave + 1):
+        c = int(round(2.0 ** (e + k / steps_per_octave)))
+        c = (c + _ALIGN - 1) // _ALIGN * _ALIGN
+        if c >= n:
+            return c
+    return 1 << (e + 1)
+
+
+arena_stats = {"requested_bytes": 0, "class_bytes": 0, "arenas": 0}
+
+
+def _arena(nbytes, dev):
+    c = size_class(nbytes)
+    arena_stats["requested_bytes"] += nbytes
+    arena_stats["class_bytes"] += c
+    arena_stats["arenas"] += 1
+    return torch.empty(c, dtype=torch.uint8, device=dev)
+
+
+def _rows_empty(P, inner, dev):
+    """A fresh [P, *inner] float32 tensor whose STORAGE holds a size class of rows (see size_class): the gradient tensors
+    of a cut of another size then reuse the cached block of the last one."""
+    per = 4
+    for d in inner:
+        per *= int(d)
+    cap = max(P, size_class(P * per) // max(per, 1))
+    return torch.empty((cap,) + tuple(inner), dtype=torch.float32, device=dev)[:P]
+
+
 # Instance count of the previous forward per (device, width, height, Gaussians): lets the next forward of the same
 # shape size its binning workspace speculatively (1.25 x) and enqueue the whole pipeline without waiting for the host
 # (hgs_raster_fwd).  A render at another resolution (the viewer's, train_single.py:76-78) has its own entry.
@@ -108,6 +148,7 @@ _last_L = {}
 SPECULATIVE = True
 SPEC_GROWTH = 1.25       # speculative instance capacity = SPEC_GROWTH * (previous L of this shape) + SPEC_SLACK
 SPEC_SLACK = 65536
+SPEC_DECAY = 0.97        # what the remembered count (per shape) / instances per row (per resolution) keeps of its maximum per call
 stats = {"speculative_calls": 0, "capacity_misses": 0, "last_L": 0}     # counters (bench.py reports them)
 
 
@@ -229,9 +270,9 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         # (gaussian_renderer/__init__.py:199-235 gathers the rows before the call), densification changes P every 300:
         # scale the last frame's instance count of this resolution by the ratio of the row counts instead of falling
         # back to the two-stage path with its host round trip (1080p run of round 5: 92 % of train_post's calls did)
-        near = _last_L.get(any_key)
+        near = _last_L.get(any_key)             # (rows of the last frame, decaying maximum of instances per row)
         if near is not None and near[0] > 0 and 0.25 <= P / near[0] <= 4.0:
-            prev = int(near[1] * (P / near[0])) + 1
+            prev = int(near[1] * P) + 1
     L_ws = 0
     done = False
     if prev is not None and P > 0:
@@ -244,7 +285,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         stats["speculative_calls"] += 1
         pl = _plan(lib, P, W, H, L_ws)
         n_g, n_i, n_b, n_w = pl["geom"], pl["img"], pl["bin"], (pl["bwd"] if want_bwd else 0)
-        arena = torch.empty(n_g + n_i + n_b + n_w, **u8)
+        arena = _arena(n_g + n_i + n_b + n_w, dev)
         base = arena.data_ptr()
         call.bufs = [arena]
         call.p_geom, call.n_geom = base, n_g
@@ -263,7 +304,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     else:
         pl = _plan(lib, P, W, H, 0)
         n_g, n_i = pl["geom"], pl["img"]
-        arena = torch.empty(n_g + n_i, **u8)
+        arena = _arena(n_g + n_i, dev)
         base = arena.data_ptr()
         call.bufs = [arena]
         call.p_geom, call.n_geom, call.p_img, call.n_img = base, n_g, base + n_g, n_i
@@ -273,19 +314,21 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         L_ws = L.value
         pl = _plan(lib, P, W, H, L_ws)
         n_b, n_w = pl["bin"], (pl["bwd"] if want_bwd else 0)
-        arena2 = torch.empty(n_b + n_w, **u8)
+        arena2 = _arena(n_b + n_w, dev)
         call.bufs.append(arena2)
         call.p_bin, call.n_bin = arena2.data_ptr(), n_b
         call.p_bwd, call.n_bwd = (call.p_bin + n_b, n_w) if want_bwd else (0, 0)
         _lib.check(lib.hgs_raster_fwd_stage2(C.byref(a), call.p_geom, call.p_bin, call.p_img, L_ws,
                                              _lib.ptr(color), _lib.ptr(invdepth) if do_depth else None,
                                              _stream(dev), devi), "hgs_raster_fwd_stage2")
-    # a cut that shrank must not make the next, larger one overflow the speculative capacity: decay slowly
-    _last_L.pop(shape_key, None)                       # (re-inserted at the end: the dict is kept in order of last use)
-    _last_L[shape_key] = L.value if lod is None else max(L.value, int(0.9 * (prev or 0)))
+    # a view (a cut) that shrank must not make the next, larger one overflow the speculative capacity: a DECAYING
+    # MAXIMUM, per shape and -- as instances per row -- per resolution (train_post.py at 1080p, round 5: 78 of 1 000
+    # calls outgrew a capacity taken from the last call alone, each a full retry)
+    stored = _last_L.pop(shape_key, None)              # (re-inserted at the end: the dict is kept in order of last use)
+    _last_L[shape_key] = max(L.value, int(SPEC_DECAY * (stored or 0)))
     if lod is None and P > 0:
-        _last_L.pop(any_key, None)
-        _last_L[any_key] = (P, L.value)
+        near = _last_L.pop(any_key, None)
+        _last_L[any_key] = (P, max(L.value / P, SPEC_DECAY * (near[1] if near else 0.0)))
     while len(_last_L) > 64:                           # forget the shape that was used longest ago
         _last_L.pop(next(iter(_last_L)))
     stats["last_L"] = L.value
@@ -325,7 +368,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
             if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != int(torch.Size(shape).numel()):
                 raise RuntimeError(f"gradient buffer for {name} must be a contiguous float32 GPU tensor of shape {tuple(shape)}")
             return t.view(*shape)
-        return torch.empty(*shape, **f32)
+        return _rows_empty(shape[0], shape[1:], dev)
 
     # In-op LOD interpolation: the backward's per-Gaussian kernels scatter node / parent gradients themselves into
     # FULL-size, zero-filled arrays (hgs_raster_args.lod_scatter); only with 3M % 4 != 0 do the row gradients go
@@ -362,7 +405,7 @@ def rasterize_gaussians_backward(call, color, invdepth, dL_dcolor, dL_dinvdepth,
     p_bwd = call.p_bwd
     if not p_bwd:
         n_w = _plan(lib, P, call.W, call.H, call.L_ws)["bwd"]
-        extra = torch.empty(n_w, dtype=torch.uint8, device=dev)
+        extra = _arena(n_w, dev)
         call.bufs.append(extra)
         p_bwd, call.p_bwd, call.n_bwd = extra.data_ptr(), extra.data_ptr(), n_w
     _lib.check(lib.hgs_raster_bwd(C.byref(a), call.p_geom, call.p_bin, call.p_img, p_bwd, call.L_ws,

@@ -159,6 +159,52 @@ def make_scene_trained_like(P, cam: Camera, seed=0, sh_degree=3, median_px=2.0, 
     return Scene(base.means3D, scales.contiguous(), base.rotations, opac.contiguous(), base.shs, sh_degree)
 
 
+def make_scene_trained_scale(P, cam: Camera, seed=0, sh_degree=3, median_px=3.5, sigma=1.2, max_px=300.0, aniso=0.05,
+                             clustered_frac=0.5, n_clusters=10, cluster_px=100.0, order="index",
+                             z_range=(2.0, 20.0)) -> Scene:
+    """The statistics of a scene the reference's own scripts TRAINED at 1080p (profiles/r05_config2_config3_scripts.log:
+    train_single.py, 375 k Gaussians: 28 tile instances per Gaussian, L = 10.7 M, lists of 1 300 on average and 3 155 at
+    most) from a seed: make_scene_trained_like's footprints (log-normal screen sigma, needles and discs, bimodal opacity)
+    at a larger median, and a NON-UNIFORM screen density -- ``clustered_frac`` of the Gaussians sit in ``n_clusters``
+    blobs of ``cluster_px`` pixels (objects), the rest fills the frustum -- so that the longest tile list is well above
+    twice the mean (defaults at P = 375 000, seed 0, 1920x1080: L = 10.43 M, 27.8 per Gaussian, lists of 1 278 on average
+    and 3 740 at most, 1 149 Gaussians of more than 1 000 tiles).  ``order``:
+      "index"      rows in generation order (a trained chunk: big and small Gaussians interleaved);
+      "clustered"  what a hierarchy CUT hands to the op (train_post.py:91-119, render_hierarchy.py:58-92): the cut's big
+                   (interior) nodes lie side by side -- rows sorted by footprint in blocks of 4 096, the biggest block
+                   first, so that a few hundred consecutive rows emit hundreds of thousands of instances."""
+    base = make_scene_trained_like(P, cam, seed=seed, sh_degree=sh_degree, median_px=median_px, sigma=sigma, max_px=max_px,
+                                   aniso=aniso, z_range=z_range)
+    g = torch.Generator().manual_seed(seed + 104729)
+    wv = cam.world_view_transform.double()
+    cs = torch.cat([base.means3D.double(), torch.ones(P, 1, dtype=torch.float64)], 1) @ wv          # camera space
+    z = cs[:, 2]
+    n_cl = int(P * clustered_frac)
+    centres = torch.rand(n_clusters, 2, generator=g, dtype=torch.float64) * 1.6 - 0.8                # NDC
+    which = torch.randint(0, n_clusters, (n_cl,), generator=g)
+    fx = cam.image_width / (2.0 * cam.tanfovx)
+    fy = cam.image_height / (2.0 * cam.tanfovy)
+    off = torch.randn(n_cl, 2, generator=g, dtype=torch.float64) * cluster_px
+    ndc = centres[which] + off / torch.tensor([0.5 * cam.image_width, 0.5 * cam.image_height], dtype=torch.float64)
+    sel = torch.randperm(P, generator=g)[:n_cl]
+    cs[sel, 0] = ndc[:, 0] * z[sel] * cam.tanfovx
+    cs[sel, 1] = ndc[:, 1] * z[sel] * cam.tanfovy
+    means = (cs @ wv.inverse())[:, :3].float().contiguous()
+    sc = Scene(means, base.scales, base.rotations, base.opacities, base.shs, sh_degree)
+    if order == "clustered":
+        size = sc.scales.max(dim=1).values / z.float()                      # screen footprint, up to the focal length
+        blocks = (P + 4095) // 4096
+        key = torch.argsort(size, descending=True, stable=True)
+        # the biggest block first, the others in generation order behind it (their rows keep their relative order)
+        big = key[:4096 if blocks > 1 else P]
+        rest_mask = torch.ones(P, dtype=torch.bool); rest_mask[big] = False
+        perm = torch.cat([big, torch.nonzero(rest_mask).flatten()])
+        sc = Scene(*(t[perm].contiguous() for t in (sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs)), sh_degree)
+    elif order != "index":
+        raise ValueError(order)
+    return sc
+
+
 def upstream_grads(H, W, seed=1):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g)

@@ -261,3 +261,25 @@ def test_config3_merged_two_chunk_hierarchy_1080p(gpu):
     kids = torch.ones(G, dtype=torch.int32); kids[:n] = torch.from_numpy(k_o)
     _run_case("config3_merged_2chunk_hierarchy_1080p", gpu, n, W, H, 96, do_depth=False, seed=21, bg=(0.0, 0.0, 0.0),
               prepared=(rows, weights, kids))
+
+
+def test_trained_scale_10m_1080p(gpu):
+    """The workload the reference's own scripts produce (train_single.py:97-176 at 1080p: 375 k Gaussians, 28 instances
+    per Gaussian, L ~ 10 M, lists beyond 3 000): pixels and EVERY gradient on the frame's most crowded tiles -- the
+    long-run route of K8, the multi-wave classes of the per-tile depth sort and 3 000-entry lists in K6 / K7."""
+    cam = synth.make_camera(1920, 1080)
+    scene = synth.make_scene_trained_scale(375_000, cam, seed=0)
+    _run_case("trained_scale_10m_1080p", gpu, scene.P, 1920, 1080, 64, seed=11, prepared=(scene, None, None))
+
+
+def test_trained_scale_cut_order_1080p(gpu):
+    """The same scene in the row order of a hierarchy cut (train_post.py:91-142, render_hierarchy.py:58-92: the cut's big
+    nodes side by side -- one K1 workgroup's rows emit 840 000 instances while the mean is 7 000), render_post's call
+    shape (do_depth False, LOD tensors): K3's shared emission and K8's dealt-out long runs against the oracle."""
+    cam = synth.make_camera(1920, 1080)
+    scene = synth.make_scene_trained_scale(375_000, cam, seed=0, order="clustered")
+    g = torch.Generator().manual_seed(5)
+    w = torch.rand(scene.P, generator=g)
+    kids = torch.randint(1, 5, (scene.P,), generator=g, dtype=torch.int32)
+    _run_case("trained_scale_cut_order_1080p", gpu, scene.P, 1920, 1080, 64, do_depth=False, seed=12, bg=(0.0, 0.0, 0.0),
+              prepared=(scene, w, kids))
