@@ -402,7 +402,7 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   // K1 in two kernels where the layout allows: geometry here, colour on the library's second stream next to the binning
   hipStream_t aux = nullptr;
   const bool split = preprocess_fwd_splits(*a) && aux_resources(device, th, &aux);
-  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s, super, split)))) {
+  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s, super, split, super ? k3_heavy_threshold(L_cap, a->P) : 0u)))) {
     if (super) super_block_mark_dirty(super);
     return rc;
   }

@@ -127,15 +127,16 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
 // SHARING (round 5, after the reference's scripts at scale): a hierarchy cut lists its big nodes side by side, and one
 // workgroup's 256 Gaussians then emit a quarter of a million instances while the mean is a few thousand -- one compute
 // unit emitting for 0.25 ms after everybody else has finished.  Positions are closed-form, so ANY workgroup can emit any
-// slot of any block once it has rebuilt that block's prologue in its LDS.  K1 keeps every superblock's LARGEST workgroup
-// sum (row 1 + kBands of the superblock totals, a fire-and-forget atomic max); a K3 workgroup reads that row with its
-// prefix loads and, only if some sum exceeds  thr = max(kHeavyFloor, kHeavyFactor x the mean emission), takes the rare
-// path: every workgroup builds the same ordered list of the (at most share_max) heavy blocks from K1's raw sums, a
-// listed block's own workgroup emits its first thr slots, and the excess of all listed blocks is dealt out in equal
-// contiguous shares by blockIdx.  Static, no flags, nobody waits: the result does not depend on who emits a slot.
-constexpr uint32_t kHeavyFloor = 4096u, kHeavyFactor = 4u, kShareMin = 1024u;
-constexpr int kMaxHeavy = 256;
-constexpr int kShareMaxBlocks = 4096;   // 1 M rows
+// slot of any block once it has rebuilt that block's prologue in its LDS.  The HOST hands K1 and K3 the same threshold
+// (k3_heavy_threshold: a multiple of the mean emission the frame's capacity allows, at least kHeavyFloor); a K1 workgroup
+// whose sum exceeds it files (block, sum) into the HEAVY LIST that lives in the last row of the superblock totals (one
+// atomic add reserves the place: the list's ORDER differs from run to run, no result depends on it).  A K3 workgroup
+// reads the list's length with its prefix loads and, only if it is not zero, takes the rare path: the (at most share_max)
+// listed blocks' own workgroups emit their first thr slots, and the excess of all listed blocks is dealt out in equal
+// contiguous shares by blockIdx.  Static inside a launch, no flags, nobody waits: the result does not depend on who emits
+// a slot.  (Round 5 had every workgroup rebuild the list from all raw sums -- 2 x nblk / 256 dependent loads per lane, 12 ms
+// per frame at the 61 000 workgroups of a 50 M-node cut, so grids above 4 096 workgroups went without sharing.)
+constexpr uint32_t kHeavyFloor = 4096u, kHeavyFactor = 2u, kShareMin = 1024u;
 
 struct K3Lds {
   uint32_t pre9[1 + kBands], tot9[1 + kBands];
@@ -169,11 +170,11 @@ __device__ __forceinline__ uint32_t k3_wg_scan_excl(uint32_t v, uint32_t* tmp, u
 
 // The prologue of block `blk` (a workgroup of K1's grid of nblk): fills l.excl / lrect / rb / bpos; ends with a barrier.
 // OWN: blk is this workgroup's own block -- it also stores its Gaussians' emission offsets, the last block stores the
-// totals, and `sbmax` returns (per lane) the largest workgroup sum of superblocks lane, lane + 64, ...
+// totals, and `heavy_n` returns the length of K1's heavy list (uniform)
 template <bool OWN>
 __device__ __forceinline__ void k3_prologue(K3Lds& l, int blk, int nblk, int P, int gx, int T, int per, const GeomWs& g,
                                             const uint32_t* __restrict__ super, uint32_t* __restrict__ total_mirror,
-                                            uint32_t& sbmax) {
+                                            uint32_t& heavy_n) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = blk * kPreBlock + tid;
   const uint32_t gid = (uint32_t)i;
@@ -182,7 +183,7 @@ __device__ __forceinline__ void k3_prologue(K3Lds& l, int blk, int nblk, int P, 
   const int col = nblk + 1;                               // column stride of g.block_band
   uint32_t block_base = 0;
   uint32_t band_tot = 0, band_off = 0;                    // lanes 0..7 of wave 0: total of band `tid`, the block's offset in it
-  sbmax = 0u;
+  heavy_n = 0u;
   if (!super) {
     block_base = g.block_sums[blk];
     if (tid < kBands) {
@@ -205,11 +206,7 @@ __device__ __forceinline__ void k3_prologue(K3Lds& l, int blk, int nblk, int P, 
       pre[u] = raw[j];
       x0[u] = super[a * kMaxSuper + min(lane, nsb - 1)];
     }
-    if constexpr (OWN) {
-      sbmax = (lane < nsb) ? super[(1 + kBands) * kMaxSuper + min(lane, nsb - 1)] : 0u;
-      for (int s0 = 64; s0 < nsb; s0 += 64)
-        if (s0 + lane < nsb) sbmax = max(sbmax, super[(1 + kBands) * kMaxSuper + s0 + lane]);
-    }
+    if constexpr (OWN) heavy_n = super[kHeavyRow];           // (a scalar load, issued with the others)
 #pragma unroll
     for (int u = 0; u < kPer; ++u) {
       const int a = min(wave + u * kWaves, kBands);
@@ -360,47 +357,25 @@ __global__ __launch_bounds__(kPreBlock) void duplicate_tiles_banded_kernel(int P
                                                                            const uint32_t* __restrict__ super,
                                                                            uint32_t* __restrict__ total_mirror,
                                                                            uint32_t* __restrict__ zero_words, int n_zero,
-                                                                           int share_max) {
+                                                                           int share_max, uint32_t thr) {
   for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_ranges; r += gridDim.x * kPreBlock) ranges[r] = 0u;
   for (int r = blockIdx.x * kPreBlock + threadIdx.x; r < n_zero; r += gridDim.x * kPreBlock) zero_words[r] = 0u;
   __shared__ K3Lds l;
   const int tid = threadIdx.x, nblk = (int)gridDim.x, own = (int)blockIdx.x;
-  uint32_t sbmax;
-  k3_prologue<true>(l, own, nblk, P, gx, T, per, g, super, total_mirror, sbmax);
+  uint32_t heavy_n;
+  k3_prologue<true>(l, own, nblk, P, gx, T, per, g, super, total_mirror, heavy_n);
   const uint32_t total = l.excl[kPreBlock];
-  // heavy if above thr; every wave holds the whole row of superblock maxima, so the test is the same in all of them.
-  // (The benchmark's frames stop at the floor: no division on the usual path.  Grids of more than kShareMaxBlocks
-  // workgroups are left alone: every workgroup reads all raw sums to build the list, 2 x nblk / 256 dependent loads per
-  // lane -- at 61 000 workgroups, the budgeted 50 M-node cut, that read alone took 12 ms.)
-  uint32_t thr = 0u;
-  bool any_heavy = false;
-  if (super && share_max > 0 && nblk <= kShareMaxBlocks && __ballot(sbmax > kHeavyFloor) != 0ull) {
-    const uint32_t L_all = (uint32_t)__builtin_amdgcn_readfirstlane((int)l.tot9[0]);
-    thr = max(kHeavyFloor, kHeavyFactor * ((L_all + (uint32_t)nblk - 1u) / (uint32_t)nblk));
-    any_heavy = __ballot(sbmax > thr) != 0ull;
-  }
-  if (!any_heavy) {
+  if (!(super && share_max > 0 && thr != 0u && heavy_n != 0u)) {        // (uniform; the benchmark's frames list nothing)
     k3_emit(l, own, 0u, total, gx, per, cap, tile_keys, vals);
     return;
   }
-  // ---- rare path: the ordered list of heavy blocks (the same in every workgroup), at most share_max of them ----------------
-  const int per_t = (nblk + kPreBlock - 1) / kPreBlock;
-  const int b0 = min(tid * per_t, nblk), b1 = min(b0 + per_t, nblk);
-  uint32_t c = 0;
-#pragma nounroll
-  for (int b = b0; b < b1; ++b) c += g.block_sums[b] > thr ? 1u : 0u;
-  uint32_t nh_all;
-  uint32_t at = k3_wg_scan_excl(c, l.scan_tmp, nh_all);
-#pragma nounroll
-  for (int b = b0; b < b1; ++b) {
-    const uint32_t sum = g.block_sums[b];
-    if (sum > thr) {
-      if (at < (uint32_t)share_max) { l.hl_blk[at] = (uint32_t)b; l.hl_pe[at] = sum - thr; }
-      ++at;
-    }
+  // ---- rare path: K1's list of heavy blocks (the same in every workgroup), at most share_max of them ----------------------
+  const int nh = (int)min(min(heavy_n, (uint32_t)kMaxHeavy), (uint32_t)share_max);
+  if (tid < nh) {
+    l.hl_blk[tid] = super[kHeavyRow + 1 + 2 * tid];
+    l.hl_pe[tid] = super[kHeavyRow + 2 + 2 * tid] - thr;                 // the block's excess (K1 listed it: sum > thr)
   }
   __syncthreads();
-  const int nh = (int)min(nh_all, (uint32_t)share_max);
   const uint32_t e = tid < nh ? l.hl_pe[tid] : 0u;
   const bool mine_listed = tid < nh && l.hl_blk[tid] == (uint32_t)own;
   uint32_t E;
@@ -872,7 +847,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(const uint32_t* __rest
 
 }  // namespace
 
-// HGS_K3_SHARE: how many heavy blocks K3 shares out at most (0: off; default and maximum kMaxHeavy) -- tests and A/B runs
+// HGS_K3_SHARE: how many heavy blocks K3 shares out at most (0: off, K1 then lists nothing; default and maximum kMaxHeavy) -- tests and A/B runs
 static int k3_share_max() {
   static const int v = [] {
     const char* e = getenv("HGS_K3_SHARE");
@@ -880,6 +855,12 @@ static int k3_share_max() {
     return x < 0 ? 0 : (x > kMaxHeavy ? kMaxHeavy : x);
   }();
   return v;
+}
+uint32_t k3_heavy_threshold(uint32_t L_cap, int32_t P) {
+  const uint32_t nblk = (uint32_t)((P + kPreBlock - 1) / kPreBlock);
+  if (nblk == 0u || k3_share_max() == 0) return 0u;
+  const uint64_t t = (uint64_t)kHeavyFactor * (((uint64_t)L_cap + nblk - 1u) / nblk);
+  return (uint32_t)(t > 0x7fffffffull ? 0x7fffffffull : (t < kHeavyFloor ? kHeavyFloor : t));
 }
 int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, uint32_t L_cap, bool banded,
                            hipStream_t s, const uint32_t* super, uint32_t* total_mirror) {
@@ -890,7 +871,8 @@ int launch_duplicate_tiles(const hgs_raster_args& a, const GeomWs& g, const BinW
     if (banded)
       hipLaunchKernelGGL(duplicate_tiles_banded_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), T,
                          band_tiles(T), g, L_cap, b.keys_in, b.vals_in, b.ranges, T * 2, super, total_mirror,
-                         tile_bin_zero_words(b.sort_tmp, L_cap, T), tile_bin_zero_count(T), k3_share_max());
+                         tile_bin_zero_words(b.sort_tmp, L_cap, T), tile_bin_zero_count(T), k3_share_max(),
+                         super ? k3_heavy_threshold(L_cap, a.P) : 0u);
     else
       hipLaunchKernelGGL(duplicate_tiles_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, grid_x(a.width), g, L_cap,
                          b.keys_in, b.vals_in, b.ranges, T * 2);

@@ -195,8 +195,9 @@ bool scan_split_forced();
 // g.block_band keep the RAW sums, no scan launch follows and K3 builds its prefixes itself (preprocess.hip, binning.hip)
 // geometry_only (preprocess_fwd_splits(a) only): everything but the colour; launch_preprocess_color completes the records
 // (colour, clamp bits of g.flags, Jacobian rows) -- on another stream, next to the binning, any time before K6
+// heavy_thr (with super): workgroups whose instance sum exceeds it are filed into the heavy list (0: none)
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s,
-                          uint32_t* super = nullptr, bool geometry_only = false);
+                          uint32_t* super = nullptr, bool geometry_only = false, uint32_t heavy_thr = 0);
 bool preprocess_fwd_splits(const hgs_raster_args& a);
 int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream_t s);
 // Superblocks of K1's workgroup sums: kSuper consecutive workgroups; the library-owned block holds (1 + kBands) rows of
@@ -204,6 +205,12 @@ int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream
 // the caller's check).  mark_dirty: an error return left totals behind, zero them before the next use.
 constexpr int kSuper = 64;
 constexpr int kMaxSuper = 1024;
+// the block's last row: [0] = length of the HEAVY LIST, then (block, instance sum) pairs of the K1 workgroups whose sum
+// exceeds the threshold the host handed to K1 and K3 (binning.hip: k3_heavy_threshold; at most kMaxHeavy are filed)
+constexpr int kMaxHeavy = 256;
+constexpr int kHeavyRow = (1 + kBands) * kMaxSuper;
+static_assert(1 + 2 * kMaxHeavy <= kMaxSuper, "the heavy list fits the row");
+uint32_t k3_heavy_threshold(uint32_t L_cap, int32_t P);     // 0: no sharing
 uint32_t* super_block_acquire(hipStream_t s);
 size_t super_block_bytes();
 void super_block_mark_dirty(const uint32_t* words);

@@ -591,7 +591,7 @@ template <bool JAC, bool LOD, bool DEFER, bool H48, bool GEOM_ONLY = false>
                                 // H48): everything but the colour -- the record's colour slots are left zero and
                                 // preprocess_color_h48_kernel (below) fills them in, concurrently with the binning
 __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, const GeomWs& g,
-                                                    int32_t* __restrict__ radii, uint32_t* __restrict__ super) {
+                                                    int32_t* __restrict__ radii, uint32_t* __restrict__ super, uint32_t heavy_thr) {
   static_assert(!(H48 && (LOD || DEFER)), "the half-row route is the plain layout's");
   static_assert(!GEOM_ONLY || (H48 && !JAC), "the geometry-only kernel is the half-row route's first part");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -669,10 +669,14 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     if (super && threadIdx.x <= kBands && mine)
       __hip_atomic_fetch_add(&super[threadIdx.x * kMaxSuper + (blockIdx.x / kSuper)], mine, __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
-    // ... and the superblock's LARGEST workgroup sum (row 1 + kBands): K3 shares out the emission of outliers (binning.hip)
-    if (super && threadIdx.x == 0 && mine)
-      __hip_atomic_fetch_max(&super[(1 + kBands) * kMaxSuper + (blockIdx.x / kSuper)], mine, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+    // ... and an outlier files itself into the heavy list: K3 shares out its emission (binning.hip)
+    if (super && threadIdx.x == 0 && heavy_thr != 0u && mine > heavy_thr) {
+      const uint32_t slot = __hip_atomic_fetch_add(&super[kHeavyRow], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (slot < (uint32_t)kMaxHeavy) {
+        super[kHeavyRow + 1 + 2 * slot] = blockIdx.x;
+        super[kHeavyRow + 2 + 2 * slot] = mine;
+      }
+    }
   }
   // Plain layout: the block's loads are ISSUED here and land while the double-precision chain below runs -- K1 is
   // bound by latency, not by its arithmetic or by HBM.
@@ -867,8 +871,8 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
 
 template <bool JAC, bool LOD, bool DEFER>
 __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_args a, GeomWs g,
-                                                                   int32_t* __restrict__ radii, uint32_t* __restrict__ super) {
-  preprocess_fwd_body<JAC, LOD, DEFER, false>(a, g, radii, super);
+                                                                   int32_t* __restrict__ radii, uint32_t* __restrict__ super, uint32_t heavy_thr) {
+  preprocess_fwd_body<JAC, LOD, DEFER, false>(a, g, radii, super, heavy_thr);
 }
 // The half-row route: 24 KB of LDS per workgroup allow five workgroups per compute unit; the registers are held to what
 // HGS_K1_H48_WAVES waves per SIMD leave (128 at 4).
@@ -878,8 +882,8 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
 template <bool JAC>
 __global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_fwd_h48_kernel(hgs_raster_args a, GeomWs g,
                                                                                          int32_t* __restrict__ radii,
-                                                                                         uint32_t* __restrict__ super) {
-  preprocess_fwd_body<JAC, false, false, true>(a, g, radii, super);
+                                                                                         uint32_t* __restrict__ super, uint32_t heavy_thr) {
+  preprocess_fwd_body<JAC, false, false, true>(a, g, radii, super, heavy_thr);
 }
 
 // ---- K1 in two kernels (M = 16, plain layout, single-call forward) -------------------------------------------------------
@@ -953,8 +957,8 @@ __global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_color_
 }
 __global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_geom_h48_kernel(hgs_raster_args a, GeomWs g,
                                                                                           int32_t* __restrict__ radii,
-                                                                                          uint32_t* __restrict__ super) {
-  preprocess_fwd_body<false, false, false, true, true>(a, g, radii, super);
+                                                                                          uint32_t* __restrict__ super, uint32_t heavy_thr) {
+  preprocess_fwd_body<false, false, false, true, true>(a, g, radii, super, heavy_thr);
 }
 
 // Exclusive scan of the per-workgroup sums (nblk = P/256): grid row 0 scans block_sums, rows 1..kBands the columns of
@@ -1919,7 +1923,7 @@ std::mutex g_sync_mu;
 SyncBlock g_sync[kMaxSyncBlocks];
 int g_sync_n = 0;
 }  // namespace
-size_t super_block_bytes() { return (size_t)(2 + kBands) * kMaxSuper * sizeof(uint32_t); }   // 9 rows of totals + the maxima
+size_t super_block_bytes() { return (size_t)(2 + kBands) * kMaxSuper * sizeof(uint32_t); }   // 9 rows of totals + the heavy list
 uint32_t* super_block_acquire(hipStream_t s) {
   static const bool off = getenv("HGS_SCAN_LAUNCH") != nullptr;
   if (off) return nullptr;
@@ -1984,7 +1988,7 @@ bool preprocess_fwd_splits(const hgs_raster_args& a) {
 }
 
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super,
-                          bool geometry_only) {
+                          bool geometry_only, uint32_t heavy_thr) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     const bool jac = a.prepare_backward && a.shs;
@@ -1995,13 +1999,13 @@ int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* ra
     const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)(geometry_only ? kHalfBytes : kK1ImageBytes)
                                               : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
     if (geometry_only) {
-      hipLaunchKernelGGL(preprocess_geom_h48_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
+      hipLaunchKernelGGL(preprocess_geom_h48_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super, heavy_thr);
     } else {
       auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
                 : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
                 : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
                         : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
-      hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super);
+      hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super, heavy_thr);
     }
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
   }
