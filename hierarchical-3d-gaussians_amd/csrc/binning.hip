@@ -416,9 +416,10 @@ constexpr uint32_t kLargeCap = 16384;   // 1024-thread workgroup, 128 KiB LDS
 // A network kept in LDS pays a workgroup barrier per stage (45 stages for 512 keys) and is latency-bound; here the
 // stages of a wave simply follow each other.  Keys are unique ((depth bits << 32) | id), so the unstable network
 // yields the stable (depth, id) order.
-__device__ __forceinline__ void cmp_swap(uint64_t& a, uint64_t& b, bool up) {
+template <typename T>
+__device__ __forceinline__ void cmp_swap(T& a, T& b, bool up) {
   const bool sw = (a > b) == up;
-  const uint64_t lo = sw ? b : a, hi = sw ? a : b;
+  const T lo = sw ? b : a, hi = sw ? a : b;
   a = lo;
   b = hi;
 }
@@ -449,9 +450,15 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
   return ((uint64_t)lane_xor32<LX>((uint32_t)(v >> 32), lane) << 32) | lane_xor32<LX>((uint32_t)v, lane);
 }
 
+template <int LX>
+__device__ __forceinline__ uint64_t lane_xor(uint64_t v, int lane) { return lane_xor64<LX>(v, lane); }
+template <int LX>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane) { return lane_xor32<LX>(v, lane); }
+
 // One compare-exchange stage (K = bitonic block size, J = partner distance) of the network over i = lane * E + e.
-template <int E, int K, int J>
-__device__ __forceinline__ void wave_sort_stage(uint64_t (&key)[E], int lane, uint32_t base) {
+// T: uint64_t ((depth bits, id) keys) or uint32_t (the depth bits of a sample, below).
+template <int E, int K, int J, typename T>
+__device__ __forceinline__ void wave_sort_stage(T (&key)[E], int lane, uint32_t base) {
   if constexpr (J >= E) {                             // partner in lane ^ (J / E)
     constexpr int LX = J / E;
     const bool lower = (lane & LX) == 0;
@@ -459,7 +466,7 @@ __device__ __forceinline__ void wave_sort_stage(uint64_t (&key)[E], int lane, ui
     const bool keep_min = lower == up;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const uint64_t other = lane_xor64<LX>(key[e], lane);
+      const T other = lane_xor<LX>(key[e], lane);
       const bool other_less = other < key[e];
       key[e] = (other_less == keep_min) ? other : key[e];
     }
@@ -474,13 +481,13 @@ __device__ __forceinline__ void wave_sort_stage(uint64_t (&key)[E], int lane, ui
     }
   }
 }
-template <int E, int K, int J>
-__device__ __forceinline__ void wave_sort_block(uint64_t (&key)[E], int lane, uint32_t base) {
+template <int E, int K, int J, typename T>
+__device__ __forceinline__ void wave_sort_block(T (&key)[E], int lane, uint32_t base) {
   wave_sort_stage<E, K, J>(key, lane, base);
   if constexpr (J > 1) wave_sort_block<E, K, J / 2>(key, lane, base);
 }
-template <int E, int K>
-__device__ __forceinline__ void wave_sort_network(uint64_t (&key)[E], int lane, uint32_t base) {
+template <int E, int K, typename T>
+__device__ __forceinline__ void wave_sort_network(T (&key)[E], int lane, uint32_t base) {
   wave_sort_block<E, K, K / 2>(key, lane, base);
   if constexpr (K < 64 * E) wave_sort_network<E, K * 2>(key, lane, base);
 }
@@ -508,6 +515,203 @@ __device__ __forceinline__ void wave_sort_tile(const float* __restrict__ depths,
     const uint32_t i = base + (uint32_t)e;
     if (i < n) vals[r0 + i] = (uint32_t)key[e];
   }
+}
+
+// ---- sample sort (round 6) -----------------------------------------------------------------------------------------------
+// The network above costs 3.5 vector instructions per key at 1 024 keys and 4.5 at 4 096, pads every list to a power of
+// two, and on frames of long lists its pair / quad classes serialise a workgroup: 0.27 ms of a 1.5 ms frame on a trained
+// scene (lists of 1 300 on average, profiles/r05_config2_config3_scripts.log).  A tile's depths have no structure a
+// radix digit could use, but they have QUANTILES, and between two quantiles they are smooth:
+//   * 64 keys taken at equal strides of the list are sorted by one wave (a 32-bit network over the lanes, 21 stages) and,
+//     with the list's smallest and largest depth at the ends, cut the depth axis into 64 COARSE buckets of about n / 64 keys
+//     whatever the distribution is;
+//   * a key finds its coarse bucket by a six-step binary search over the splitters in LDS and its FINE bucket -- one of F
+//     per coarse bucket -- by interpolating between the two splitters: fine buckets hold one to three keys;
+//   * an LDS fetch-and-add per key counts the fine bucket and hands the key a place inside it; one scan of the 64 F counts
+//     later the keys are parked bucket by bucket in LDS, and every key counts the keys of ITS bucket that are smaller --
+//     its exact rank -- and stores its id there.
+// Exact for any input: the fine bucket is a monotone function of the depth bits, equal depths share a bucket, inside a
+// bucket the full (depth bits, id) keys are compared.  A bucket of more than kSsMaxBucket keys (hundreds of equal depths)
+// sends the tile to the network instead.
+//   NW   waves that sort one tile together (1: the wave's own tile, no workgroup barrier; 4: the workgroup)
+//   KPL  keys per lane (n <= 64 NW KPL)
+//   F    fine buckets per coarse bucket; 64 F / (64 NW) counters per thread in the scan
+// area: 64 NW KPL keys of LDS; ext: 65 words (+ 8 for NW = 4); start: 64 F + 2 HALF words (counts and places stay below
+// 65 536: two counters share a word, the fetch-and-add goes to the word); tmp: scan scratch (NW = 4).
+// Returns false (uniform over the group, nothing written) when a bucket is too full.
+constexpr uint32_t kSsMaxBucket = 64;
+__device__ __forceinline__ uint32_t sort_depth_bits(const float* __restrict__ depths, uint32_t gid) {
+  return __float_as_uint(depths[gid]);       // (the gather costs 6 - 13 % of the kernel: profiles/r06_depth_sort.md)
+}
+template <int NW>
+__device__ __forceinline__ void group_barrier() {
+  if constexpr (NW == 1) {                       // (the DS operations of one wave execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = min(v, (uint32_t)__shfl_xor((int)v, off, 64));
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, off, 64));
+  return v;
+}
+template <int NW, int KPL, int F>
+__device__ __forceinline__ bool sample_sort_tile(uint64_t* __restrict__ area, uint32_t* __restrict__ ext,
+                                                 uint16_t* __restrict__ start, uint32_t* __restrict__ tmp,
+                                                 const float* __restrict__ depths, uint32_t* __restrict__ vals,
+                                                 uint32_t r0, uint32_t n, int wv) {
+  constexpr int NT = 64 * NW, NB = 64 * F, CPT = NB / NT;
+  static_assert(NW == 1 || NW == 4, "one wave, or the workgroup's four");
+  static_assert(CPT >= 2 && CPT % 2 == 0 && CPT * NT == NB, "whole words of counters per thread");
+  const int lane = threadIdx.x & 63, tg = wv * 64 + lane;
+  uint32_t kd[KPL], kg[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {               // coalesced; the sample's id is requested with them
+    const uint32_t i = (uint32_t)(e * NT + tg);
+    kg[e] = vals[r0 + min(i, n - 1u)];
+  }
+  uint32_t sg = 0u;
+  if (wv == 0) sg = vals[r0 + ((uint32_t)lane * n) / 64u];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) kd[e] = sort_depth_bits(depths, kg[e]);     // (slots past n repeat the last key: harmless)
+  // smallest / largest depth of the list: the outer ends of the first and the last coarse bucket
+  uint32_t dmin = kd[0], dmax = kd[0];
+#pragma unroll
+  for (int e = 1; e < KPL; ++e) { dmin = min(dmin, kd[e]); dmax = max(dmax, kd[e]); }
+  dmin = wave_min_u32(dmin);
+  dmax = wave_max_u32(dmax);
+  if constexpr (NW > 1) {
+    if (lane == 0) { ext[65 + 2 * wv] = dmin; ext[66 + 2 * wv] = dmax; }
+  }
+  if (wv == 0) {
+    uint32_t sd[1] = {sort_depth_bits(depths, sg)};
+    wave_sort_network<1, 2>(sd, lane, (uint32_t)lane);
+    if (lane < 63) ext[lane + 1] = sd[0];      // ext[1 .. 63]: the 63 splitters in use
+  }
+  uint32_t* start32 = reinterpret_cast<uint32_t*>(start);
+  for (int t = tg; t <= NB / 2; t += NT) start32[t] = 0u;
+  group_barrier<NW>();
+  if constexpr (NW > 1) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) { dmin = min(dmin, ext[65 + 2 * w]); dmax = max(dmax, ext[66 + 2 * w]); }
+  }
+  // ---- coarse bucket = number of splitters below the key's depth (all keys of the lane step through the search TOGETHER:
+  // one LDS round trip per step); fine bucket by interpolation between the bucket's two ends; place from the counter ----
+  uint32_t fb[KPL], rk[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) fb[e] = 0u;
+#pragma unroll
+  for (int step = 32; step >= 1; step >>= 1) {
+    uint32_t sv[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) sv[e] = ext[fb[e] + step];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) fb[e] += (sv[e] < kd[e]) ? (uint32_t)step : 0u;
+  }
+  {
+    uint32_t lo[KPL], hi[KPL];
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      lo[e] = ext[fb[e]];                       // (entries 0 and 64 are never written: the list's ends stand in below)
+      hi[e] = ext[fb[e] + 1];
+    }
+#pragma unroll
+    for (int e = 0; e < KPL; ++e) {
+      const uint32_t l = fb[e] == 0u ? dmin : lo[e], h = fb[e] == 63u ? dmax : hi[e];
+      // monotone in the depth bits: conversion, product with a positive factor and truncation all are
+      const float t = (float)(kd[e] - l) * ((float)F * __builtin_amdgcn_rcpf((float)(h - l) + 1.0f));
+      const uint32_t sub = min((uint32_t)t, (uint32_t)(F - 1));
+      fb[e] = fb[e] * (uint32_t)F + sub;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    rk[e] = 0u;
+    if ((uint32_t)(e * NT + tg) < n) {
+      const uint32_t sh = (fb[e] & 1u) << 4;
+      rk[e] = (atomicAdd(&start32[fb[e] >> 1], 1u << sh) >> sh) & 0xffffu;
+    }
+  }
+  group_barrier<NW>();
+  // ---- counts -> first places; a bucket that is too full sends the tile to the network ------------------------------------
+  bool heavy;
+  {
+    uint32_t c[CPT], sum = 0u;
+    bool big = false;
+#pragma unroll
+    for (int q = 0; q < CPT; q += 2) {
+      const uint32_t w = start32[(tg * CPT + q) >> 1];
+      c[q] = w & 0xffffu;
+      c[q + 1] = w >> 16;
+      sum += c[q] + c[q + 1];
+      big = big || c[q] > kSsMaxBucket || c[q + 1] > kSsMaxBucket;
+    }
+    uint32_t run;
+    if constexpr (NW == 1) {
+      run = wave_scan_incl(sum) - sum;
+      heavy = __ballot(big) != 0ull;
+    } else {
+      uint32_t total;
+      run = k3_wg_scan_excl(sum, tmp, total);
+      heavy = __syncthreads_or(big) != 0;
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; q += 2) {
+      start32[(tg * CPT + q) >> 1] = run | ((run + c[q]) << 16);
+      run += c[q] + c[q + 1];
+    }
+    if (tg == NT - 1) start[NB] = (uint16_t)run;
+  }
+  group_barrier<NW>();
+  if (heavy) return false;
+  // ---- park the keys bucket by bucket ------------------------------------------------------------------------------------------
+  uint32_t s0[KPL], s1[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    s0[e] = start[fb[e]];
+    s1[e] = start[fb[e] + 1];
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e)
+    if ((uint32_t)(e * NT + tg) < n) area[s0[e] + rk[e]] = ((uint64_t)kd[e] << 32) | kg[e];
+  group_barrier<NW>();
+  // ---- exact rank = first place of the bucket + the bucket's keys below this one (buckets of one to three keys: the
+  // lane's keys step through their buckets together) ------------------------------------------------------------------------
+  uint32_t c[KPL];
+#pragma unroll
+  for (int e = 0; e < KPL; ++e) {
+    c[e] = s0[e];
+    if ((uint32_t)(e * NT + tg) >= n) s1[e] = s0[e];
+  }
+  // keys that step together (registers: G 64-bit members in flight): the largest divisor of KPL up to 8
+  constexpr int G = KPL <= 8 ? KPL : (KPL % 8 == 0 ? 8 : (KPL % 6 == 0 ? 6 : (KPL % 5 == 0 ? 5 : 4)));
+  static_assert(KPL % G == 0, "whole groups");
+#pragma unroll
+  for (int g0 = 0; g0 < KPL; g0 += G) {
+    uint32_t len = 0u;
+#pragma unroll
+    for (int e = g0; e < g0 + G; ++e) len = max(len, s1[e] - s0[e]);
+    for (uint32_t k = 0; k < len; ++k) {
+      uint64_t m[G];
+#pragma unroll
+      for (int e = 0; e < G; ++e) m[e] = area[min(s0[g0 + e] + k, (uint32_t)(NT * KPL - 1))];
+#pragma unroll
+      for (int e = 0; e < G; ++e)
+        c[g0 + e] += (s0[g0 + e] + k < s1[g0 + e] && m[e] < (((uint64_t)kd[g0 + e] << 32) | kg[g0 + e])) ? 1u : 0u;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < KPL; ++e)
+    if ((uint32_t)(e * NT + tg) < n) vals[r0 + c[e]] = kg[e];
+  return true;
 }
 
 constexpr uint32_t kWaveCap = 1024;     // one wave, 16 keys per lane
@@ -690,14 +894,24 @@ __device__ __forceinline__ void radix_sort_tile(RadixLds<NW>& l, uint32_t r0, ui
 #define HGS_SORT_OCC
 #endif
 template <bool QUAD>
-__global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
-                                                                   const float* __restrict__ depths,
-                                                                   uint32_t* __restrict__ vals, uint32_t* big, int T,
-                                                                   uint32_t* __restrict__ tile_ids,
-                                                                   uint32_t* __restrict__ scratch_k,
-                                                                   uint32_t* __restrict__ scratch_v,
-                                                                   uint32_t* __restrict__ scratch_k2) {
-  __shared__ uint64_t lk[QUAD ? kQuadCap : 1];
+__device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __restrict__ ranges,
+                                                          const float* __restrict__ depths,
+                                                          uint32_t* __restrict__ vals, uint32_t* big, int T,
+                                                          uint32_t* __restrict__ tile_ids,
+                                                          uint32_t* __restrict__ scratch_k,
+                                                          uint32_t* __restrict__ scratch_v,
+                                                          uint32_t* __restrict__ scratch_k2) {
+  // the sample sort's key area: kOwn keys per wave for the waves' own tiles; QUAD: the same 32 KB hold a tile of up to
+  // kQuadCap keys that the four waves sort together (and the cross-wave stages of the network, when a tile falls back);
+  // light frames: the radix fallback's arrays lie over it (it runs when the waves are done with their own tiles)
+  constexpr uint32_t kOwn = QUAD ? kWaveCap : 512u;
+  constexpr size_t kAreaBytes = 4 * kOwn * sizeof(uint64_t);
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[QUAD ? kAreaBytes : (kAreaBytes > sizeof(RadixLds<4>) ? kAreaBytes : sizeof(RadixLds<4>))];
+  uint64_t* lk = reinterpret_cast<uint64_t*>(lds_raw);
+  constexpr int kFOwn = 8, kFCoop = 32;                   // fine buckets per coarse one: 512 per wave, 2 048 per workgroup
+  __shared__ uint32_t ss_ext[4 * 80], ss_tmp[4];
+  __shared__ __attribute__((aligned(4))) uint16_t ss_start[64 * kFCoop + 8];
+  static_assert(4 * (64 * kFOwn + 2) <= 64 * kFCoop + 8, "the waves' own counters fit the workgroup's");
   __shared__ uint32_t quad_n[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int tile = blockIdx.x * 4 + wave;
@@ -720,43 +934,53 @@ __global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(
       quad_n[wave] = n > kWaveCap ? n : 0u;
     }
   }
+  // ---- the wave's own tile: the network up to 128 keys, the sample sort above (the network where a bucket overflows) ----
   if (n > 1 && n <= kWaveCap) {
+    uint64_t* area = lk + wave * kOwn;
+    uint32_t* ex = ss_ext + wave * 80;
+    uint16_t* st = ss_start + wave * (64 * kFOwn + 2);
+    // keys per lane in steps of a third: a list fills at least three quarters of the lanes' slots
+    bool ok = true;
     if (n <= 128) wave_sort_tile<2>(depths, vals, r0, n, lane);
-    else if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
-    else if (n <= 512) wave_sort_tile<8>(depths, vals, r0, n, lane);
-    else wave_sort_tile<16>(depths, vals, r0, n, lane);
+    else if (n <= 192) ok = sample_sort_tile<1, 3, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    else if (n <= 256) ok = sample_sort_tile<1, 4, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    else if (n <= 384) ok = sample_sort_tile<1, 6, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    else if (n <= 512) ok = sample_sort_tile<1, 8, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    else if (!QUAD) wave_sort_tile<16>(depths, vals, r0, n, lane);      // (rare in a light frame)
+    else if (n <= 768) ok = sample_sort_tile<1, 12, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    else ok = sample_sort_tile<1, 16, kFOwn>(area, ex, st, nullptr, depths, vals, r0, n, 0);
+    if (!ok) {                                            // a bucket overflowed: the network
+      if (lane == 0) atomicAdd(&big[2], 1u);
+      if (n <= 256) wave_sort_tile<4>(depths, vals, r0, n, lane);
+      else if (n <= 512) wave_sort_tile<8>(depths, vals, r0, n, lane);
+      else wave_sort_tile<16>(depths, vals, r0, n, lane);
+    }
   }
   if constexpr (QUAD) {
     __syncthreads();
-    // the workgroup's tiles of 1025 .. 2048 (two at a time, one per pair of waves) and of 2049 .. 4096 (one after the
-    // other, all four waves): uniform control flow, every wave meets every barrier
-    uint32_t pair_mask = 0, quad_mask = 0;
-#pragma unroll
+    // the workgroup's tiles of 1025 .. 4096, one after the other, all four waves: uniform control flow, every wave meets
+    // every barrier
+#pragma unroll 1
     for (int w = 0; w < 4; ++w) {
-      const uint32_t qn = quad_n[w];
-      if (qn > 2048u) quad_mask |= 1u << w;
-      else if (qn != 0u) pair_mask |= 1u << w;
-    }
-    while (pair_mask) {
-      const int w0 = __builtin_ctz(pair_mask);
-      pair_mask &= pair_mask - 1u;
-      int w1 = -1;
-      if (pair_mask) { w1 = __builtin_ctz(pair_mask); pair_mask &= pair_mask - 1u; }
-      const int pair = wave >> 1;
-      const int wsel = pair ? w1 : w0;
-      uint32_t pr0 = 0, pn = 0;
-      if (wsel >= 0) { pr0 = ranges[(blockIdx.x * 4 + wsel) * 2 + 0]; pn = quad_n[wsel]; }
-      coop_sort_tile<2>(lk + pair * 2048, depths, vals, pr0, pn, wave & 1);
-      __syncthreads();
-    }
-    while (quad_mask) {
-      const int w = __builtin_ctz(quad_mask);
-      quad_mask &= quad_mask - 1u;
-      coop_sort_tile<4>(lk, depths, vals, ranges[(blockIdx.x * 4 + w) * 2 + 0], quad_n[w], wave);
+      const uint32_t qn = quad_n[w];                      // (uniform)
+      if (qn == 0u) continue;
+      const uint32_t qr0 = ranges[(blockIdx.x * 4 + w) * 2 + 0];
+      bool ok;
+      if (qn <= 1280u) ok = sample_sort_tile<4, 5, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      else if (qn <= 1536u) ok = sample_sort_tile<4, 6, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      else if (qn <= 2048u) ok = sample_sort_tile<4, 8, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      else if (qn <= 2560u) ok = sample_sort_tile<4, 10, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      else if (qn <= 3072u) ok = sample_sort_tile<4, 12, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      else ok = sample_sort_tile<4, 16, kFCoop>(lk, ss_ext, ss_start, ss_tmp, depths, vals, qr0, qn, wave);
+      if (!ok) {
+        if (threadIdx.x == 0) atomicAdd(&big[2], 1u);
+        __syncthreads();
+        coop_sort_tile<4>(lk, depths, vals, qr0, qn, wave);
+      }
       __syncthreads();
     }
   } else {
-    __shared__ RadixLds<4> rl;
+    RadixLds<4>& rl = *reinterpret_cast<RadixLds<4>*>(lds_raw);
     __syncthreads();
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
@@ -764,6 +988,29 @@ __global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(
       if (cn) radix_sort_tile<4>(rl, ranges[(blockIdx.x * 4 + w) * 2 + 0], cn, depths, vals, scratch_k, scratch_v, scratch_k2);
     }
   }
+}
+
+// (two kernels for the two bodies: the register budgets differ -- 32 KB of LDS per workgroup hold the QUAD kernel at
+// four waves per SIMD anyway, so it is told to fit them)
+#ifndef HGS_SORT_QUAD_WPE
+#define HGS_SORT_QUAD_WPE 4
+#endif
+template <bool QUAD>
+__global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
+                                                                   const float* __restrict__ depths,
+                                                                   uint32_t* __restrict__ vals, uint32_t* big, int T,
+                                                                   uint32_t* __restrict__ tile_ids,
+                                                                   uint32_t* __restrict__ scratch_k,
+                                                                   uint32_t* __restrict__ scratch_v,
+                                                                   uint32_t* __restrict__ scratch_k2) {
+  tile_depth_sort_wave_body<false>(ranges, depths, vals, big, T, tile_ids, scratch_k, scratch_v, scratch_k2);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SORT_QUAD_WPE, HGS_SORT_QUAD_WPE))) void
+tile_depth_sort_quad_kernel(const uint32_t* __restrict__ ranges, const float* __restrict__ depths,
+                            uint32_t* __restrict__ vals, uint32_t* big, int T, uint32_t* __restrict__ tile_ids,
+                            uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
+                            uint32_t* __restrict__ scratch_k2) {
+  tile_depth_sort_wave_body<true>(ranges, depths, vals, big, T, tile_ids, scratch_k, scratch_v, scratch_k2);
 }
 
 // The large class (kQuadCap < n <= kLargeCap, filed by the QUAD kernel): one workgroup of 64 GROUP lanes per listed tile,
@@ -908,12 +1155,18 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   // for the classes it files.  A light frame's rare crowded tile is sorted inside the one-wave kernel: one launch.
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   const bool quad = (uint64_t)L > (uint64_t)T * 512u;
-  auto kern = quad ? tile_depth_sort_wave_kernel<true> : tile_depth_sort_wave_kernel<false>;
+  auto kern = quad ? tile_depth_sort_quad_kernel : tile_depth_sort_wave_kernel<false>;
   static const char* dyn_env = getenv("HGS_SORT_DYN_LDS");      // tuning aid, as HGS_K6_DYN_LDS (render.hip)
   static const size_t dyn = dyn_env ? (size_t)atoi(dyn_env) : 0;
   hipLaunchKernelGGL(kern, dim3((T + 3) / 4), dim3(256), dyn, s, b.ranges, g.depths, b.vals_out, b.big_tiles, T,
                      fill_tile_ids ? b.keys_out : nullptr, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp));
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
+  static const bool dbg = getenv("HGS_SORT_DEBUG") != nullptr;       // diagnostic: tiles the sample sort handed to the network
+  if (dbg) {
+    uint32_t c[3] = {0, 0, 0};
+    if (hipMemcpyAsync(c, b.big_tiles, sizeof(c), hipMemcpyDeviceToHost, s) == hipSuccess && hipStreamSynchronize(s) == hipSuccess)
+      fprintf(stderr, "[hgs] tile_depth_sort: L %u T %d quad %d: large %u huge %u network fallbacks %u\n", L, T, (int)quad, c[0], c[1], c[2]);
+  }
   if (!quad) return HGS_OK;
   const int big_grid = T < 256 ? T : 256;
   const bool heavy = (uint64_t)L > (uint64_t)T * 1024u;
