@@ -370,6 +370,73 @@ def test_one_crowded_tile_in_a_light_frame(gpu, n, lo, hi):
     assert np.array_equal(v["point_list"].cpu().numpy(), binning.point_list)
 
 
+_SS_SIZES = [127, 129, 192, 193, 256, 257, 384, 385, 512, 513, 768, 769, 1024, 1025, 1280, 1281, 1536, 1537, 2048, 2049,
+             2560, 2561, 3072, 3073, 4096, 4097, 5000]
+
+
+@pytest.mark.parametrize("mode", ["uniform", "all_equal", "two_values", "outliers", "geometric", "runs_of_ties"])
+@pytest.mark.parametrize("grid", [8, 40])
+def test_sample_sort_list_sizes_and_depth_distributions(gpu, grid, mode):
+    """The per-tile depth sort (binning.hip: sample sort, round 6) on lists of every length at which it changes its keys
+    per lane, its group size or its route (127 .. 5 000 instances in one tile), with depth distributions that stress the
+    quantile sample and the interpolated fine buckets: uniform; ALL depths equal (every key in one bucket: the overflow
+    route to the network); two values; a tight cluster with a few far outliers (the skybox-behind-a-wall case); geometric;
+    runs of 40 equal depths.  grid 8 x 8 tiles: a frame of long lists (the four-wave kernel); 40 x 40: a light frame.
+    Ranges and sorted lists must equal the oracle's stable 64-bit sort bit for bit."""
+    import diff_gaussian_rasterization as dgr
+    from oracle import raster_oracle as ro
+    W = H = grid * 16
+    cam = synth.make_camera(W, H)
+    sizes = _SS_SIZES
+    P = sum(sizes)
+    g = torch.Generator().manual_seed(100 + grid)
+    scene = synth.make_scene(P, cam, seed=41, s_px=(0.3, 0.3))
+    fx = W / (2.0 * cam.tanfovx)
+    tiles = torch.randperm(grid * grid, generator=g)[:len(sizes)]
+    tile_of = torch.repeat_interleave(tiles, torch.tensor(sizes))
+    perm = torch.randperm(P, generator=g)                 # ids of a tile's instances are scattered over the index range
+    tile_of = tile_of[perm]
+    u = torch.rand(P, generator=g)
+    if mode == "uniform":
+        z = 2.0 + 18.0 * u
+    elif mode == "all_equal":
+        z = torch.full((P,), 5.0)
+    elif mode == "two_values":
+        z = torch.where(u < 0.5, torch.tensor(3.0), torch.tensor(7.5))
+    elif mode == "outliers":
+        z = 5.0 + 1e-3 * u
+        z[torch.rand(P, generator=g) < 0.01] = 90.0
+        z[torch.rand(P, generator=g) < 0.01] = 0.5
+    elif mode == "geometric":
+        z = 0.3 * torch.pow(300.0, u)
+    else:
+        z = 2.0 + torch.floor(u * P / 40.0) * (18.0 * 40.0 / P)
+    px = (tile_of % grid).float() * 16 + 6.0 + 4.0 * torch.rand(P, generator=g)
+    py = (tile_of // grid).float() * 16 + 6.0 + 4.0 * torch.rand(P, generator=g)
+    scene.means3D[:, 0] = (px + 0.5 - W / 2) / fx * z
+    scene.means3D[:, 1] = (py + 0.5 - H / 2) / fx * z
+    scene.means3D[:, 2] = z
+    scene.scales[:] = (z * 0.3 / fx)[:, None]
+    geom = ro.geometry_spec(scene.means3D.numpy(), scene.scales.numpy(), scene.rotations.numpy(), None,
+                            cam.world_view_transform.numpy(), cam.full_proj_transform.numpy(), W, H,
+                            cam.tanfovx, cam.tanfovy, 1.0)
+    binning = ro.binning_spec(geom)
+    per_tile = binning.ranges[:, 1] - binning.ranges[:, 0]
+    assert sorted(per_tile[per_tile > 0].tolist()) == sorted(sizes), "every Gaussian in exactly its own tile"
+    assert (binning.num_rendered > 512 * grid * grid) == (grid == 8)             # long-list frame / light frame
+    rs = dgr.GaussianRasterizationSettings(**pa.settings_kwargs(cam, torch.zeros(3), 3, device=gpu))
+    sc = scene.to(gpu)
+    for _ in range(2):                                    # (the second call takes the speculative single-call route)
+        L, color, radii, geomb, binb, img, invd, call = dgr._C.rasterize_gaussians(
+            rs.bg, sc.means3D, None, sc.opacities, sc.scales, sc.rotations, 1.0, None, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, H, W, sc.shs, 3, rs.campos, False, False, rs.render_indices, rs.parent_indices,
+            rs.interpolation_weights, rs.num_node_kids, True)
+        v = dgr._C.raster_views(call)
+        assert L == binning.num_rendered
+        assert np.array_equal(v["ranges"].cpu().numpy(), binning.ranges)
+        assert np.array_equal(v["point_list"].cpu().numpy(), binning.point_list), mode
+
+
 def test_gradient_accumulation_into_caller_buffers(gpu):
     """Data-parallel host path (RasterContext.grad_buffers): the backward writes straight into a flat bucket and
     ACCUMULATES the second view's gradients in place; the result must equal the sum of the two views' separately
