@@ -48,6 +48,7 @@ NEAR_Z = np.float32(0.2)
 ALPHA_MIN = 1.0 / 255.0
 ALPHA_MAX = 0.99
 T_EPS = 1e-4
+FRAGILE_FP32_K = 8.0 * 2.0 ** -24     # float32 roundings of the exponent's chain, per unit of its terms' magnitudes
 F = np.float32
 
 SH_C0 = 0.28209479177387814
@@ -336,7 +337,8 @@ class OracleOut:
 def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
               *, image_height, image_width, tanfovx, tanfovy, bg, scale_modifier, viewmatrix,
               projmatrix, sh_degree, campos, interpolation_weights=None, num_node_kids=None,
-              dtype=torch.float64, tiles=None, fragile_tol=1e-5, geom_dtype=None, lod_mode="opacity") -> OracleOut:
+              dtype=torch.float64, tiles=None, fragile_tol=1e-5, geom_dtype=None, lod_mode="opacity",
+              positive_power="skip") -> OracleOut:
     """Dense per-tile oracle.  All tensor arguments are CPU torch tensors; the
     differentiable ones may require grad.  ``tiles``: optional iterable of tile
     ids to restrict the blend to (bench cpu_baseline sampling); other pixels
@@ -457,6 +459,8 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
             dx = (gxp[ids] - tx0).to(dtype)[None, :] - (pxs - tx0)[:, None]
             dy = (gyp[ids] - ty0).to(dtype)[None, :] - (pys - ty0)[:, None]
             power = -0.5 * (A[ids][None] * dx * dx + C[ids][None] * dy * dy) - B[ids][None] * dx * dy
+            if positive_power == "clamp":      # what the HIP kernels do; "skip": App. A.8 literally.  The
+                power = torch.clamp(power, max=0.0)   # two differ only where ROUNDING makes the exponent positive (needles, float32)
             G = torch.exp(power)
             araw = opac[ids][None] * G
             if lod_w is not None:
@@ -469,9 +473,19 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
                 stop = live & (T_incl < T_EPS)
                 dead = torch.cumsum(stop.to(torch.int32), dim=1) > 0
                 keep = live & ~dead
-                frag = ((alpha - ALPHA_MIN).abs() < fragile_tol * ALPHA_MIN) & (power <= 0) & ~dead
+                # The band around a threshold inside which a float32 evaluation may decide differently GROWS WITH THE
+                # FOOTPRINT: the exponent is a sum of three products that cancel (|A dx^2|, |C dy^2|, |B dx dy| reach
+                # thousands for a Gaussian hundreds of pixels wide while their sum stays at -5.5), so alpha carries a
+                # relative error of about 2^-24 per unit of M = the sum of their magnitudes, times the handful of
+                # roundings in the chain (FRAGILE_FP32_K); a fixed 1e-5 band missed flips at 1/255 on the trained 1080p
+                # scene of round 5 (3 of 49 128 values, profiles/r05_config2_config3_scripts.log).  The transmittance
+                # inherits the error of every alpha blended before it.
+                M = 0.5 * (A[ids][None].abs() * dx * dx + C[ids][None].abs() * dy * dy) + (B[ids][None] * dx * dy).abs()
+                band = fragile_tol + FRAGILE_FP32_K * M
+                frag = ((alpha - ALPHA_MIN).abs() < band * ALPHA_MIN) & (power <= 0) & ~dead
                 frag |= (power.abs() < 1e-12) & ~dead
-                frag |= ((T_incl - T_EPS).abs() < fragile_tol * T_EPS) & live & \
+                band_T = fragile_tol + torch.cumsum(a_eff / (1.0 - a_eff).clamp_min(1e-2) * band, dim=1)
+                frag |= ((T_incl - T_EPS).abs() < band_T * T_EPS) & live & \
                         (torch.cumsum(stop.to(torch.int32), dim=1) <= 1)
                 fr = frag.any(dim=1)
                 idx = torch.arange(1, e - s + 1)[None, :].expand_as(keep)

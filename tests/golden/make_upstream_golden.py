@@ -16,6 +16,11 @@ from memory here (DESIGN.md sections 3 and 4; their reference call sites in brac
   upstream_lod_cut.npz          expand_to_size + get_interpolation_weights on the synthetic hierarchy at three
                                 thresholds -- pins the cut rule and the weight formula  [train_post.py:91-113,
                                 render_hierarchy.py:55-80]
+  upstream_raster_needles.npz   20 needles (3 000 px x 0.3-0.6 px at every angle, 128x128): a float32 conic of such a needle loses
+                                positive definiteness (a c - b^2 cancels to its last bits; below ~2 500 px it never does), the
+                                exponent A dx^2 + C dy^2 + 2 B dx dy turns POSITIVE on whole stripes -- the reference lineage then
+                                SKIPS the Gaussian there ("power > 0"), this library keeps the conic positive definite in K1 and
+                                clamps the exponent at 0.  Says which of the two upstream is nearer to.
   upstream_hier_file.npz        the bytes of a .hier written by upstream write_hierarchy and what upstream load_hierarchy
                                 returns for it -- pins the file layout  [scene/gaussian_model.py:329,420-427]
 
@@ -111,6 +116,28 @@ def case_config1():
                 bg=bg.numpy(), gc=gc.numpy(), gd=gd.numpy(), do_depth=True, **{"out_" + k: v for k, v in out.items()})
 
 
+def needle_scene(cam, n=20, seed=9):
+    """Needles through the frustum: one axis 3 000 px long on screen, the other two 0.3 .. 0.6 px, random orientation."""
+    scene = synth.make_scene(n, cam, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    fx = cam.image_width / (2.0 * cam.tanfovx)
+    z = scene.means3D[:, 2]
+    thin = (0.3 + 0.3 * torch.rand(n, 2, generator=g)) * (z / fx)[:, None]
+    scene.scales = torch.cat([(3000.0 * z / fx)[:, None], thin], 1).contiguous()
+    scene.opacities = (0.3 + 0.6 * torch.rand(n, 1, generator=g)).contiguous()
+    return scene
+
+
+def case_needles():
+    cam = synth.make_camera(128, 128)
+    scene = needle_scene(cam)
+    gc, gd = synth.upstream_grads(128, 128, seed=9)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    out = run_raster(scene, cam, bg, gc, gd, True)
+    return dict(**{"in_" + k: v for k, v in scene_arrays(scene).items()}, **{"cam_" + k: v for k, v in cam_arrays(cam).items()},
+                bg=bg.numpy(), gc=gc.numpy(), gd=gd.numpy(), do_depth=True, **{"out_" + k: v for k, v in out.items()})
+
+
 def _small_hierarchy():
     cam = synth.make_camera(320, 208)
     h = hierarchy.build_hierarchy(synth.make_scene(3000, cam, seed=5, s_px=(0.7, 3.0)))
@@ -199,7 +226,7 @@ def main():
                          "upstream extension; remove hierarchical-3d-gaussians_amd from PYTHONPATH")
     done = []
     for name, fn in (("raster_config1", case_config1), ("lod_cut", case_lod_cut), ("raster_post", case_raster_post),
-                     ("hier_file", case_hier_file)):
+                     ("raster_needles", case_needles), ("hier_file", case_hier_file)):
         try:
             data = fn()
             np.savez_compressed(os.path.join(HERE, f"upstream_{name}.npz"), **data)

@@ -45,7 +45,7 @@ def settings_kwargs(cam, bg, sh_degree, do_depth=True, debug=False, scale_modifi
 
 def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0,
                interpolation_weights=None, num_node_kids=None, do_depth=True, dtype=torch.float64, mask_fragile=True,
-               lod_mode="opacity"):
+               lod_mode="opacity", positive_power="skip"):
     req = lambda t: None if t is None else t.clone().requires_grad_(True)
     m3, sc, rot, op = req(scene.means3D), req(scene.scales), req(scene.rotations), req(scene.opacities)
     sh = req(scene.shs) if colors_precomp is None else None
@@ -59,7 +59,7 @@ def run_oracle(scene, cam, bg, gc, gd, *, colors_precomp=None, cov3D_precomp=Non
                        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform,
                        projmatrix=cam.full_proj_transform, sh_degree=scene.sh_degree, campos=cam.camera_center,
                        interpolation_weights=interpolation_weights, num_node_kids=num_node_kids, dtype=dtype,
-                       lod_mode=lod_mode)
+                       lod_mode=lod_mode, positive_power=positive_power)
     # see the module docstring: undecidable pixels leave the loss
     ok = torch.from_numpy(~out.fragile) if mask_fragile else torch.ones(out.fragile.shape, dtype=torch.bool)
     out.grad_mask = ok

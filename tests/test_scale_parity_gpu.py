@@ -54,8 +54,9 @@ def _tile_mask(tiles, W, H):
     return m
 
 
-def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, bg=(0.05, 0.1, 0.15), prepared=None):
-    cam = synth.make_camera(W, H)
+def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, bg=(0.05, 0.1, 0.15), prepared=None,
+              cam=None):
+    cam = synth.make_camera(W, H) if cam is None else cam
     gc, gd = synth.upstream_grads(H, W, seed=seed + 1)
     bg = torch.tensor(bg)
     w = kids = None

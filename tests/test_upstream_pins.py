@@ -95,6 +95,40 @@ def check_raster_hip(G, what, gpu):
                     {k: v.numpy() for k, v in hip["grads"].items()}, G, f"HIP, {what}")
 
 
+def check_needles(G, what, hip_color=None):
+    """Which rule for an exponent that ROUNDING made positive does upstream follow -- "power > 0 -> skip" (SURVEY App.
+    A.8, the public lineage) or the clamp at 0 of this library's kernels?  In float64 the exponent
+    of a positive definite conic is never positive and the two coincide; a float32 conic loses positive definiteness only
+    on extreme needles (3 000 px x 0.5 px: a c - b^2 cancels to its last bits; measured: none up to 2 500 px), and then
+    on whole stripes of the image.  The oracle is run ALL in float32 under both rules (its operation order is not
+    upstream's, so single pixels need not coincide -- how many pixels are far off under each rule is what tells) and, when
+    given, the HIP image is held to the golden outside the pixels where the two float32 evaluations disagree."""
+    import parity as pa
+    scene, cam = _scene_cam(G)
+    args = (scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]))
+    img = {}
+    for rule in ("skip", "clamp"):
+        oo, _ = pa.run_oracle(*args, do_depth=True, mask_fragile=False, dtype=torch.float32, positive_power=rule)
+        img[rule] = oo.color.detach().double().numpy()
+    gold = np.asarray(G["out_color"], np.float64)
+    differ = np.abs(img["skip"] - img["clamp"]).max(axis=0) > 1e-6
+    fit = {r: float(np.abs(img[r] - gold).max() / max(np.abs(gold).max(), 1e-12)) for r in img}
+    n_sk = int((np.abs(img["skip"] - gold).max(axis=0) > 1e-2).sum())
+    n_cl = int((np.abs(img["clamp"] - gold).max(axis=0) > 1e-2).sum())
+    print(f"{what}: float32 oracle vs upstream -- max error under 'skip' {fit['skip']:.2e} ({n_sk} pixels off by > 1e-2), under "
+          f"'clamp' {fit['clamp']:.2e} ({n_cl} pixels); the two rules differ on {int(differ.sum())} of {differ.size} pixels")
+    follows = "skip" if n_sk < n_cl else ("clamp" if n_cl < n_sk else "either (the case did not separate them)")
+    print(f"{what}: upstream follows: {follows}")
+    if hip_color is not None:
+        off = np.abs(np.asarray(hip_color, np.float64) - gold).max(axis=0) > 1e-4
+        assert not (off & ~differ).any(), f"{what}: {int((off & ~differ).sum())} HIP pixels differ from upstream where the rules agree"
+        if follows == "skip" and (off & differ).any():
+            pytest.fail(f"{what}: upstream SKIPS a Gaussian whose float32 exponent is positive; the kernels clamp it: "
+                        f"{int((off & differ).sum())} pixels differ -- replace the clamp in render.hip (fwd_pair_live / "
+                        "bwd_pair_live) by the skip")
+    return follows, int(differ.sum())
+
+
 def _lod_compare(i, r, p, n, w, k, G, what):
     assert len(r) == int(G[f"n_{i}"]), f"{what}: cut size {len(r)} != upstream {int(G[f'n_{i}'])} at threshold {i}"
     assert np.array_equal(r, G[f"render_indices_{i}"]), f"{what}: render_indices differ (threshold {i})"
@@ -157,6 +191,10 @@ def test_oracle_matches_upstream_rasterizer_with_lod_tensors():
     check_raster_oracle(_golden("raster_post"), "render_post-shaped call (pins lod_opacity)")
 
 
+def test_oracle_needles_skip_or_clamp():
+    check_needles(_golden("raster_needles"), "needles")
+
+
 def test_lod_oracle_matches_upstream_cut_and_weights():
     check_lod_oracle(_golden("lod_cut"))
 
@@ -174,6 +212,16 @@ def test_hip_matches_upstream_rasterizer_config1(gpu):
 @pytest.mark.gpu
 def test_hip_matches_upstream_rasterizer_with_lod_tensors(gpu):
     check_raster_hip(_golden("raster_post"), "render_post-shaped call (pins lod_opacity)", gpu)
+
+
+@pytest.mark.gpu
+def test_hip_needles_against_upstream(gpu):
+    import parity as pa
+    G = _golden("raster_needles")
+    scene, cam = _scene_cam(G)
+    hip = pa.run_hip(scene, cam, torch.from_numpy(G["bg"]), torch.from_numpy(G["gc"]), torch.from_numpy(G["gd"]), gpu,
+                     do_depth=True, grad_mask=None)
+    check_needles(G, "needles (HIP)", hip["color"].numpy())
 
 
 @pytest.mark.gpu
@@ -199,7 +247,8 @@ def test_pin_kit_plumbing(tmp_path, monkeypatch):
     spec.loader.exec_module(kit)
     monkeypatch.setattr(kit, "DEV", "cpu")
     for name, fn in (("raster_config1", kit.case_config1), ("lod_cut", kit.case_lod_cut),
-                     ("raster_post", kit.case_raster_post), ("hier_file", kit.case_hier_file)):
+                     ("raster_post", kit.case_raster_post), ("raster_needles", kit.case_needles),
+                     ("hier_file", kit.case_hier_file)):
         np.savez_compressed(os.path.join(tmp_path, f"upstream_{name}.npz"), **fn())
     d = str(tmp_path)
     check_raster_oracle(_golden("raster_config1", d), "config 1 (plumbing)")
@@ -210,3 +259,7 @@ def test_pin_kit_plumbing(tmp_path, monkeypatch):
     check_raster_oracle(G, "render_post shape (plumbing)")
     check_lod_oracle(_golden("lod_cut", d))
     check_hier_file(_golden("hier_file", d))
+    # the needle case must SEPARATE the two rules for a positive exponent (here the stand-in's values are the float64
+    # oracle's: both float32 evaluations are compared with those, the verdict itself means nothing)
+    follows, n_differ = check_needles(_golden("raster_needles", d), "needles (plumbing)")
+    assert n_differ > 0, "the needle case does not produce a single float32 exponent above zero: it would pin nothing"
