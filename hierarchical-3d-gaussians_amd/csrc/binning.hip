@@ -605,39 +605,44 @@ __device__ __forceinline__ bool sample_sort_tile(uint64_t* __restrict__ area, ui
   }
   // ---- coarse bucket = number of splitters below the key's depth (all keys of the lane step through the search TOGETHER:
   // one LDS round trip per step); fine bucket by interpolation between the bucket's two ends; place from the counter ----
+  // keys that step together (registers: G members in flight): the largest divisor of KPL up to 8
+  constexpr int G = KPL <= 8 ? KPL : (KPL % 8 == 0 ? 8 : (KPL % 6 == 0 ? 6 : (KPL % 5 == 0 ? 5 : 4)));
+  static_assert(KPL % G == 0, "whole groups");
   uint32_t fb[KPL], rk[KPL];
 #pragma unroll
-  for (int e = 0; e < KPL; ++e) fb[e] = 0u;
+  for (int g0 = 0; g0 < KPL; g0 += G) {
+    uint32_t cb[G];
 #pragma unroll
-  for (int step = 32; step >= 1; step >>= 1) {
-    uint32_t sv[KPL];
+    for (int e = 0; e < G; ++e) cb[e] = 0u;
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) sv[e] = ext[fb[e] + step];
+    for (int step = 32; step >= 1; step >>= 1) {
+      uint32_t sv[G];
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) fb[e] += (sv[e] < kd[e]) ? (uint32_t)step : 0u;
-  }
-  {
-    uint32_t lo[KPL], hi[KPL];
+      for (int e = 0; e < G; ++e) sv[e] = ext[cb[e] + step];
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) {
-      lo[e] = ext[fb[e]];                       // (entries 0 and 64 are never written: the list's ends stand in below)
-      hi[e] = ext[fb[e] + 1];
+      for (int e = 0; e < G; ++e) cb[e] += (sv[e] < kd[g0 + e]) ? (uint32_t)step : 0u;
+    }
+    uint32_t lo[G], hi[G];
+#pragma unroll
+    for (int e = 0; e < G; ++e) {
+      lo[e] = ext[cb[e]];                       // (entries 0 and 64 are never written: the list's ends stand in below)
+      hi[e] = ext[cb[e] + 1];
     }
 #pragma unroll
-    for (int e = 0; e < KPL; ++e) {
-      const uint32_t l = fb[e] == 0u ? dmin : lo[e], h = fb[e] == 63u ? dmax : hi[e];
+    for (int e = 0; e < G; ++e) {
+      const uint32_t l = cb[e] == 0u ? dmin : lo[e], h = cb[e] == 63u ? dmax : hi[e];
       // monotone in the depth bits: conversion, product with a positive factor and truncation all are
-      const float t = (float)(kd[e] - l) * ((float)F * __builtin_amdgcn_rcpf((float)(h - l) + 1.0f));
+      const float t = (float)(kd[g0 + e] - l) * ((float)F * __builtin_amdgcn_rcpf((float)(h - l) + 1.0f));
       const uint32_t sub = min((uint32_t)t, (uint32_t)(F - 1));
-      fb[e] = fb[e] * (uint32_t)F + sub;
+      fb[g0 + e] = cb[e] * (uint32_t)F + sub;
     }
-  }
 #pragma unroll
-  for (int e = 0; e < KPL; ++e) {
-    rk[e] = 0u;
-    if ((uint32_t)(e * NT + tg) < n) {
-      const uint32_t sh = (fb[e] & 1u) << 4;
-      rk[e] = (atomicAdd(&start32[fb[e] >> 1], 1u << sh) >> sh) & 0xffffu;
+    for (int e = 0; e < G; ++e) {
+      rk[g0 + e] = 0u;
+      if ((uint32_t)((g0 + e) * NT + tg) < n) {
+        const uint32_t sh = (fb[g0 + e] & 1u) << 4;
+        rk[g0 + e] = (atomicAdd(&start32[fb[g0 + e] >> 1], 1u << sh) >> sh) & 0xffffu;
+      }
     }
   }
   group_barrier<NW>();
@@ -673,44 +678,38 @@ __device__ __forceinline__ bool sample_sort_tile(uint64_t* __restrict__ area, ui
   group_barrier<NW>();
   if (heavy) return false;
   // ---- park the keys bucket by bucket ------------------------------------------------------------------------------------------
-  uint32_t s0[KPL], s1[KPL];
+  // sl: first place of the key's bucket (13 bits) | keys in the bucket (bits 13 .. 19) | bucket keys below this one (from
+  // bit 20; counted below) -- one register per key instead of three (the 16-keys-per-lane instantiations spilled)
+  static_assert(kSsMaxBucket < 128 && 64 * NW * KPL <= 8192, "the packed fields hold their values");
+  uint32_t sl[KPL];
 #pragma unroll
   for (int e = 0; e < KPL; ++e) {
-    s0[e] = start[fb[e]];
-    s1[e] = start[fb[e] + 1];
+    const uint32_t s0 = start[fb[e]], s1 = start[fb[e] + 1];
+    sl[e] = ((uint32_t)(e * NT + tg) < n) ? (s0 | ((s1 - s0) << 13)) : 0u;
   }
 #pragma unroll
   for (int e = 0; e < KPL; ++e)
-    if ((uint32_t)(e * NT + tg) < n) area[s0[e] + rk[e]] = ((uint64_t)kd[e] << 32) | kg[e];
+    if ((uint32_t)(e * NT + tg) < n) area[(sl[e] & 0x1fffu) + rk[e]] = ((uint64_t)kd[e] << 32) | kg[e];
   group_barrier<NW>();
   // ---- exact rank = first place of the bucket + the bucket's keys below this one (buckets of one to three keys: the
   // lane's keys step through their buckets together) ------------------------------------------------------------------------
-  uint32_t c[KPL];
-#pragma unroll
-  for (int e = 0; e < KPL; ++e) {
-    c[e] = s0[e];
-    if ((uint32_t)(e * NT + tg) >= n) s1[e] = s0[e];
-  }
-  // keys that step together (registers: G 64-bit members in flight): the largest divisor of KPL up to 8
-  constexpr int G = KPL <= 8 ? KPL : (KPL % 8 == 0 ? 8 : (KPL % 6 == 0 ? 6 : (KPL % 5 == 0 ? 5 : 4)));
-  static_assert(KPL % G == 0, "whole groups");
 #pragma unroll
   for (int g0 = 0; g0 < KPL; g0 += G) {
     uint32_t len = 0u;
 #pragma unroll
-    for (int e = g0; e < g0 + G; ++e) len = max(len, s1[e] - s0[e]);
+    for (int e = g0; e < g0 + G; ++e) len = max(len, (sl[e] >> 13) & 0x7fu);
     for (uint32_t k = 0; k < len; ++k) {
       uint64_t m[G];
 #pragma unroll
-      for (int e = 0; e < G; ++e) m[e] = area[min(s0[g0 + e] + k, (uint32_t)(NT * KPL - 1))];
+      for (int e = 0; e < G; ++e) m[e] = area[min((sl[g0 + e] & 0x1fffu) + k, (uint32_t)(NT * KPL - 1))];
 #pragma unroll
       for (int e = 0; e < G; ++e)
-        c[g0 + e] += (s0[g0 + e] + k < s1[g0 + e] && m[e] < (((uint64_t)kd[g0 + e] << 32) | kg[g0 + e])) ? 1u : 0u;
+        sl[g0 + e] += (k < ((sl[g0 + e] >> 13) & 0x7fu) && m[e] < (((uint64_t)kd[g0 + e] << 32) | kg[g0 + e])) ? (1u << 20) : 0u;
     }
   }
 #pragma unroll
   for (int e = 0; e < KPL; ++e)
-    if ((uint32_t)(e * NT + tg) < n) vals[r0 + c[e]] = kg[e];
+    if ((uint32_t)(e * NT + tg) < n) vals[r0 + (sl[e] & 0x1fffu) + (sl[e] >> 20)] = kg[e];
   return true;
 }
 
@@ -905,7 +904,9 @@ __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __rest
   // kQuadCap keys that the four waves sort together (and the cross-wave stages of the network, when a tile falls back);
   // light frames: the radix fallback's arrays lie over it (it runs when the waves are done with their own tiles)
   constexpr uint32_t kOwn = QUAD ? kWaveCap : 512u;
-  constexpr size_t kAreaBytes = 4 * kOwn * sizeof(uint64_t);
+  constexpr uint32_t kOwnMax = QUAD ? kOwn : kWaveCap;          // longest list a wave sorts alone
+  constexpr size_t kAreaBytes = (QUAD ? (size_t)kQuadCap : 4 * (size_t)kOwn) * sizeof(uint64_t);
+  static_assert(!QUAD || 4 * kOwn <= kQuadCap, "the waves' own areas fit the workgroup's");
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[QUAD ? kAreaBytes : (kAreaBytes > sizeof(RadixLds<4>) ? kAreaBytes : sizeof(RadixLds<4>))];
   uint64_t* lk = reinterpret_cast<uint64_t*>(lds_raw);
   constexpr int kFOwn = 8, kFCoop = 32;                   // fine buckets per coarse one: 512 per wave, 2 048 per workgroup
@@ -924,7 +925,7 @@ __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __rest
     for (uint32_t i = (uint32_t)lane; i < n; i += 64u) tile_ids[r0 + i] = (uint32_t)tile;
   if (lane == 0) {
     if (QUAD) {
-      quad_n[wave] = (n > kWaveCap && n <= kQuadCap) ? n : 0u;
+      quad_n[wave] = (n > kOwnMax && n <= kQuadCap) ? n : 0u;
       if (n > kQuadCap) {
         const int cls = n > kLargeCap ? 1 : 0;
         const uint32_t slot = atomicAdd(&big[cls], 1u);
@@ -935,7 +936,7 @@ __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __rest
     }
   }
   // ---- the wave's own tile: the network up to 128 keys, the sample sort above (the network where a bucket overflows) ----
-  if (n > 1 && n <= kWaveCap) {
+  if (n > 1 && n <= kOwnMax) {
     uint64_t* area = lk + wave * kOwn;
     uint32_t* ex = ss_ext + wave * 80;
     uint16_t* st = ss_start + wave * (64 * kFOwn + 2);

@@ -629,7 +629,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       // every ordinary load of the kernel is issued up here: while the LDS DMA below is in flight the compiler waits
       // for ALL outstanding memory operations at the first use of any load's result
       opac = load_opacity<LOD>(a, idx, nullptr);
-      if (a.interpolation_weights && a.num_node_kids)
+      if (a.interpolation_weights && a.num_node_kids && !a.lod_per_pixel)     // (per pixel: the compositing kernels remap alpha)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
     }
     if (a.cov3D_precomp) {
@@ -715,7 +715,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     if (pr.clampy) flags |= 16u;
     if constexpr (!H48) {
       opac = load_opacity<LOD>(a, idx, nullptr);
-      if (a.interpolation_weights && a.num_node_kids)
+      if (a.interpolation_weights && a.num_node_kids && !a.lod_per_pixel)     // (per pixel: the compositing kernels remap alpha)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
     }
     if (!K1X(8)) k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
@@ -1393,7 +1393,7 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
       double dact = 1.0;
       const float o_act = load_opacity<LOD>(a, idx, &dact);
       float o_rec = o_act;      // the opacity K1 put into the record (same functions, same float)
-      if (a.interpolation_weights && a.num_node_kids)
+      if (a.interpolation_weights && a.num_node_kids && !a.lod_per_pixel)
         o_rec = lod_opacity(o_act, a.interpolation_weights[idx], a.num_node_kids[idx], &dod);
       // the instance records carry sum X = sum (o G) dL/dalpha; dL/do = sum G dL/dalpha = (sum X) / o.  o <= 0: never
       // blended, sum X = 0

@@ -111,10 +111,25 @@ __device__ __forceinline__ float exp2_le1(float x) { return __builtin_amdgcn_fme
 
 // the three float4 of staged instance j (a list entry: < 256): the byte offset as ONE 24-bit multiply (across the look-ahead's
 // loop-carried registers the compiler loses the value range and emits the quarter-rate 32-bit multiply)
+template <int KLDS = 3>
 __device__ __forceinline__ const float4* staged(const float4* lrec, uint32_t j) {
   uint32_t off;
-  asm("v_mul_u32_u24 %0, 48, %1" : "=v"(off) : "v"(j));
+  if constexpr (KLDS == 3) asm("v_mul_u32_u24 %0, 48, %1" : "=v"(off) : "v"(j));
+  else off = j << 6;
   return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lrec) + off);
+}
+
+// ---- per-PIXEL LOD remap (hgs_raster_args.lod_per_pixel; oracle: raster_oracle.lod_alpha) -------------------------------
+// alpha' = w a + (1 - w) (1 - (1 - min(a, 0.99))^(1/k)) for k >= 2 sibling nodes, a itself otherwise (ik = 1 / k, 0 for
+// k < 2).  alpha' <= a, so K1's candidate box and skip threshold -- built from the unmapped opacity -- stay conservative.
+// d: also d alpha' / d a (zero through the inner cap, as autograd differentiates the clamp).
+__device__ __forceinline__ float lod_alpha_remap(float a, float w, float ik, float* d) {
+  const float ac = fminf(a, kAlphaMax);
+  const float base = 1.0f - ac;
+  const float pw = __builtin_amdgcn_exp2f(ik * __builtin_amdgcn_logf(base));          // base^(1/k), base in [0.01, 1]
+  const bool on = ik > 0.0f;
+  if (d) *d = on ? w + (1.0f - w) * (a <= kAlphaMax ? ik * pw * __builtin_amdgcn_rcpf(base) : 0.0f) : 1.0f;
+  return on ? w * a + (1.0f - w) * (1.0f - pw) : a;
 }
 
 // number of set bits of `m` below this lane
@@ -196,15 +211,16 @@ struct FwdPair {
   uint32_t last0, last1;
 };
 
-template <bool DEPTH>
+template <bool DEPTH, bool LODA = false>
 __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const float4& q1,
-                                              const float4& q2, uint32_t idx1) {
+                                              const float4& q2, uint32_t idx1, float lw = 0.0f, float lik = 0.0f) {
   // exp2(min(pw, 0)): the conic is positive definite (0.3 px^2 was added to the covariance's diagonal, K1 keeps the
   // rounded conic positive definite), so the exponent is <= 0 up to rounding; clamping replaces the reference lineage's
   // "power > 0 -> skip" test, which in exact arithmetic never fires, by the value the exact exponent would give, and
   // costs nothing (output clamp of the exp instruction)
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
-  const f2 araw = q1.y * G;
+  f2 araw = q1.y * G;
+  if constexpr (LODA) araw = f2{lod_alpha_remap(araw.x, lw, lik, nullptr), lod_alpha_remap(araw.y, lw, lik, nullptr)};
   const f2 alpha = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   // no per-lane candidate flag: alpha >= 1/255 implies the log-domain candidate test (which has a 1e-3 guard band);
   // the dummy instance has opacity 0
@@ -239,14 +255,16 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
 #else
 #define HGS_K6_OCC
 #endif
-template <bool DEPTH>
+template <bool DEPTH, bool LODA>
 __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
-    uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order) {
+    uint32_t* __restrict__ n_contrib, const uint32_t* __restrict__ order, const float* __restrict__ lod_w,
+    const int32_t* __restrict__ lod_kids) {
   constexpr int kB = kFwdBatch;
-  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
+  // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
+  constexpr int kLds = LODA ? 4 : 3;
   __shared__ float4 lrec[(kB + 1) * kLds];
   // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
   __shared__ uint32_t qlist[kB + 3];
@@ -277,6 +295,7 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
     lrec[kB * kLds + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
     lrec[kB * kLds + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+    if constexpr (LODA) lrec[kB * kLds + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
   }
   const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
 
@@ -298,6 +317,10 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
       lrec[lane * kLds + 0] = a0;
       lrec[lane * kLds + 1] = a1;
       lrec[lane * kLds + 2] = a2;
+      if constexpr (LODA) {
+        const int kids = lod_kids[gid];
+        lrec[lane * kLds + 3] = make_float4(lod_w[gid], kids >= 2 ? 1.0f / (float)kids : 0.0f, 0.f, 0.f);
+      }
     }
     // a finished quadrant takes no more instances
     hit.q0 = hit.q0 && (alive & 0xffffull) != 0;
@@ -319,6 +342,12 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
     __syncthreads();
     // one (instance, quadrant) pair per row of the wave
     auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2) {
+      float lw = 0.0f, lik = 0.0f;
+      if constexpr (LODA) {
+        const float4 q3 = staged<kLds>(lrec, j)[3];
+        lw = q3.x;
+        lik = q3.y;
+      }
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
@@ -330,18 +359,18 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
       // (no wave-level "nobody is a candidate" exit: with the exact quadrant test it almost never fires, and the three
       // maxima and the compare it needs cost 4 % of the kernel)
-      fwd_pair_live<DEPTH>(P0, pw0, q1, q2, idx1);
-      fwd_pair_live<DEPTH>(P1, pw1, q1, q2, idx1);
+      fwd_pair_live<DEPTH, LODA>(P0, pw0, q1, q2, idx1, lw, lik);
+      fwd_pair_live<DEPTH, LODA>(P1, pw1, q1, q2, idx1, lw, lik);
     };
 #if HGS_K6_PREFETCH
     uint32_t jA = myq[0], jB = myq[4];
-    float4 A0 = staged(lrec, jA)[0], A1 = staged(lrec, jA)[1], A2 = staged(lrec, jA)[2];
+    float4 A0 = staged<kLds>(lrec, jA)[0], A1 = staged<kLds>(lrec, jA)[1], A2 = staged<kLds>(lrec, jA)[2];
     for (int it = 0; it < nmax; it += 2) {
-      const float4 B0 = staged(lrec, jB)[0], B1 = staged(lrec, jB)[1], B2 = staged(lrec, jB)[2];
+      const float4 B0 = staged<kLds>(lrec, jB)[0], B1 = staged<kLds>(lrec, jB)[1], B2 = staged<kLds>(lrec, jB)[2];
       const uint32_t jA2 = myq[(it + 2) * 4];
       visit(jA, A0, A1, A2);
       if (it + 1 < nmax) {
-        A0 = staged(lrec, jA2)[0]; A1 = staged(lrec, jA2)[1]; A2 = staged(lrec, jA2)[2];
+        A0 = staged<kLds>(lrec, jA2)[0]; A1 = staged<kLds>(lrec, jA2)[1]; A2 = staged<kLds>(lrec, jA2)[2];
         const uint32_t jB2 = myq[(it + 3) * 4];
         visit(jB, B0, B1, B2);
         jB = jB2;
@@ -351,7 +380,7 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
 #else
     for (int it = 0; it < nmax; ++it) {
       const uint32_t j = myq[it * 4];      // this row's next instance (kB: none)
-      visit(j, staged(lrec, j)[0], staged(lrec, j)[1], staged(lrec, j)[2]);
+      visit(j, staged<kLds>(lrec, j)[0], staged<kLds>(lrec, j)[1], staged<kLds>(lrec, j)[2]);
     }
 #endif
     alive = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig);
@@ -399,18 +428,26 @@ struct BwdSums {
 };
 
 // FIRST: the sums are assigned, not accumulated (the first pair of an instance: no zero-filled accumulators)
-template <bool DEPTH, bool FIRST>
+template <bool DEPTH, bool FIRST, bool LODA = false>
 __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 dy, bool c0, bool c1,
-                                              const float4& q1, f2 q2) {   // q2 = (blue, 1/z)
+                                              const float4& q1, f2 q2, float lw = 0.0f, float lik = 0.0f) {   // q2 = (blue, 1/z)
   // exp2(min(pw, 0)) as in the forward (the exponent of a positive definite conic is <= 0 up to rounding); it also
   // keeps G finite on the non-live lanes
   const f2 G = {exp2_le1(pw.x), exp2_le1(pw.y)};
-  const f2 araw0 = q1.y * G;
+  f2 araw0 = q1.y * G;
+  f2 xfac = araw0;                                   // d alpha / d power = alpha (per pixel LOD: x d alpha' / d alpha)
+  if constexpr (LODA) {
+    float d0, d1;
+    const f2 og = araw0;
+    araw0 = f2{lod_alpha_remap(og.x, lw, lik, &d0), lod_alpha_remap(og.y, lw, lik, &d1)};
+    xfac = f2{og.x * d0, og.y * d1};
+  }
   const bool live0 = c0 && (araw0.x >= kAlphaMin);   // = blended by the forward (alpha = min(0.99, araw) >= 1/255)
   const bool live1 = c1 && (araw0.y >= kAlphaMin);
   // non-live lanes take part with o G = 0: alpha = 0 is the identity for T and for the A recurrence, and every sum is
   // a multiple of o G (dL/dopacity = sum G dL/dalpha = (sum X) / o is formed by K8 from sum X: no sum of its own)
   const f2 araw = {live0 ? araw0.x : 0.0f, live1 ? araw0.y : 0.0f};
+  if constexpr (LODA) xfac = f2{live0 ? xfac.x : 0.0f, live1 ? xfac.y : 0.0f};
   const f2 ae = {fminf(kAlphaMax, araw.x), fminf(kAlphaMax, araw.y)};
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
@@ -425,7 +462,7 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   const f2 qA = q - p.A;
   const f2 dLda = fma2(qA, Tcur, -(p.bgd * rinv));              // finite on non-live lanes, multiplied by 0 below
   const f2 w = ae * Tcur;
-  const f2 X = araw * dLda;                                     // dL/dpower (straight-through 0.99 cap)
+  const f2 X = (LODA ? xfac : araw) * dLda;                     // dL/dpower (straight-through 0.99 cap)
   const f2 Xdy = X * dy;
   // dot products over the pair's two pixels with plain instructions (a packed product + a fold of its halves costs more)
   if (FIRST) {
@@ -493,15 +530,17 @@ __device__ __forceinline__ void row_reduce10(float v0, float v1, float v2, float
 #ifndef HGS_K7_WAVES
 #define HGS_K7_WAVES 4
 #endif
-template <bool DEPTH>
+template <bool DEPTH, bool LODA>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES, HGS_K7_WAVES))) void render_bwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
-    const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order) {
+    const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order,
+    const float* __restrict__ lod_w, const int32_t* __restrict__ lod_kids) {
   constexpr int kB = kBwdBatch;
-  constexpr int kLds = 3;   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-)
+  // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
+  constexpr int kLds = LODA ? 4 : 3;
   __shared__ float4 lrec[(kB + 1) * kLds];
   // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
   __shared__ uint32_t qlist[kB + 3];
@@ -576,6 +615,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
     lrec[kB * kLds + 0] = make_float4(0.f, 0.f, 0.f, 0.f);
     lrec[kB * kLds + 1] = make_float4(0.f, 0.f, 0.f, 0.f);
     lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
+    if constexpr (LODA) lrec[kB * kLds + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
   }
   const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
   float* const myacc = acc + (lg.q >> 1) * kAccRows;
@@ -616,6 +656,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       lrec[lane * kLds + 0] = a0;
       lrec[lane * kLds + 1] = a1;
       lrec[lane * kLds + 2] = a2;
+      if constexpr (LODA) {
+        const int kids = lod_kids[gid];
+        lrec[lane * kLds + 3] = make_float4(lod_w[gid], kids >= 2 ? 1.0f / (float)kids : 0.0f, 0.f, 0.f);
+      }
     }
     const uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
     const bool any_hit = hit.q0 || hit.q1 || hit.q2 || hit.q3;
@@ -677,10 +721,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       const bool c2 = !NC || rel < P1.nc0, c3 = !NC || rel < P1.nc1;
 #endif
       const f2 q2 = f2{q2v.x, q2v.y};
+      float lw = 0.0f, lik = 0.0f;
+      if constexpr (LODA) {
+        const float4 q3 = staged<kLds>(lrec, j)[3];
+        lw = q3.x;
+        lik = q3.y;
+      }
       BwdSums S;
       if (!DEPTH) S.s9 = 0.0f;
-      bwd_pair_live<DEPTH, true>(P0, S, pw0, dy0, c0, c1, q1, q2);
-      bwd_pair_live<DEPTH, false>(P1, S, pw1, dy1, c2, c3, q1, q2);
+      bwd_pair_live<DEPTH, true, LODA>(P0, S, pw0, dy0, c0, c1, q1, q2, lw, lik);
+      bwd_pair_live<DEPTH, false, LODA>(P1, S, pw1, dy1, c2, c3, q1, q2, lw, lik);
       const float s0 = dx * S.a0, s3 = dx * S.a1;     // sum X dx, sum X dx dy
       const float s2 = dx * s0;                        // sum X dx^2
       float ta, tb, tc;
@@ -699,13 +749,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       // before the current one is composited: every row's record address depends on a list entry that is itself in
       // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
       uint32_t jA = myq[0], jB = myq[4];
-      float4 A0 = staged(lrec, jA)[0], A1 = staged(lrec, jA)[1], A2 = staged(lrec, jA)[2];
+      float4 A0 = staged<kLds>(lrec, jA)[0], A1 = staged<kLds>(lrec, jA)[1], A2 = staged<kLds>(lrec, jA)[2];
       for (int it = 0; it < nmax; it += 2) {
-        const float4 B0 = staged(lrec, jB)[0], B1 = staged(lrec, jB)[1], B2 = staged(lrec, jB)[2];
+        const float4 B0 = staged<kLds>(lrec, jB)[0], B1 = staged<kLds>(lrec, jB)[1], B2 = staged<kLds>(lrec, jB)[2];
         const uint32_t jA2 = myq[(it + 2) * 4];
         visit(nc_tag, jA, A0, A1, A2);
         if (it + 1 < nmax) {
-          A0 = staged(lrec, jA2)[0]; A1 = staged(lrec, jA2)[1]; A2 = staged(lrec, jA2)[2];
+          A0 = staged<kLds>(lrec, jA2)[0]; A1 = staged<kLds>(lrec, jA2)[1]; A2 = staged<kLds>(lrec, jA2)[2];
           const uint32_t jB2 = myq[(it + 3) * 4];
           visit(nc_tag, jB, B0, B1, B2);
           jB = jB2;
@@ -715,7 +765,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
 #else
       for (int it = 0; it < nmax; ++it) {
         const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
-        visit(nc_tag, j, staged(lrec, j)[0], staged(lrec, j)[1], staged(lrec, j)[2]);
+        visit(nc_tag, j, staged<kLds>(lrec, j)[0], staged<kLds>(lrec, j)[1], staged<kLds>(lrec, j)[2]);
       }
 #endif
     };
@@ -772,10 +822,12 @@ int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth;
-  auto kern = depth ? render_fwd_quad_kernel<true> : render_fwd_quad_kernel<false>;
+  const bool loda = a.lod_per_pixel && a.interpolation_weights && a.num_node_kids;
+  auto kern = loda ? (depth ? render_fwd_quad_kernel<true, true> : render_fwd_quad_kernel<false, true>)
+                   : (depth ? render_fwd_quad_kernel<true, false> : render_fwd_quad_kernel<false, false>);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
-                     out_invdepth, im.final_T, im.n_contrib, b.tile_order);
+                     out_invdepth, im.final_T, im.n_contrib, b.tile_order, a.interpolation_weights, a.num_node_kids);
   HGS_LAUNCH_CHECK("render_fwd_quad", s, a.debug);
   return HGS_OK;
 }
@@ -788,10 +840,13 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
   const int nblk = render_grid_limit(((T + 7) / 8) * 8);
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
-  auto kern = depth ? render_bwd_quad_kernel<true> : render_bwd_quad_kernel<false>;
+  const bool loda = a.lod_per_pixel && a.interpolation_weights && a.num_node_kids;
+  auto kern = loda ? (depth ? render_bwd_quad_kernel<true, true> : render_bwd_quad_kernel<false, true>)
+                   : (depth ? render_bwd_quad_kernel<true, false> : render_bwd_quad_kernel<false, false>);
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
-                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order);
+                     im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order, a.interpolation_weights,
+                     a.num_node_kids);
   HGS_LAUNCH_CHECK("render_bwd_quad", s, a.debug);
   return HGS_OK;
 }

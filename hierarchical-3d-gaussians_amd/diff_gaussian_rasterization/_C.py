@@ -219,6 +219,9 @@ def _build_args(background, means3D, colors, opacity, scales, rotations, scale_m
     a.means3D, a.shs, a.colors_precomp, a.opacities = p(means3D), p(sh), p(colors), p(opacity)
     a.scales, a.rotations, a.cov3D_precomp = p(scales), p(rotations), p(cov3D_precomp)
     a.interpolation_weights, a.num_node_kids = p(w), p(k)
+    if LOD_REMAP not in ("opacity", "alpha"):
+        raise RuntimeError(f"LOD_REMAP must be 'opacity' or 'alpha', not {LOD_REMAP!r}")
+    a.lod_per_pixel = int(LOD_REMAP == "alpha" and w is not None)
     a.shs_rest, a.activations = p(sh_rest), int(activations)
     if lod is not None:
         a.lod_render_indices, a.lod_parent_indices = p(ri), p(pi)
@@ -338,6 +341,14 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     # (geomBuffer, binningBuffer, imgBuffer of the upstream signature: call.geom / call.binb / call.img on demand)
     return L.value, color, radii, None, None, None, invdepth, call
 
+
+# How non-empty interpolation_weights / num_node_kids are used (include/hgs.h: hgs_raster_args.lod_per_pixel): "opacity" --
+# the default, a per-Gaussian remap of the opacity in the per-Gaussian kernel -- or "alpha": the same remap applied per
+# pixel to alpha = o G inside the compositing kernels, under which k coincident children at weight 0 composite exactly like
+# their parent.  Which of the two the reference's CUDA kernel implements cannot be read off its
+# checkout (gaussian_renderer/__init__.py:258-265 passes the tensors on); the pin kit's raster_post golden decides, and
+# following it is this assignment.
+LOD_REMAP = "opacity"
 
 lod_scatter_in_kernel = True     # False: row gradients through memory + lod_gather_backward (kept for 3M % 4 != 0; tests)
 

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libhgs.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 INST_GRAD_STRIDE = 10          # floats per (tile, Gaussian) record of the backward scratch (HGS_INST_GRAD_STRIDE)
 ERR_CAPACITY = 5
 
@@ -27,7 +27,7 @@ class RasterArgs(C.Structure):
         ("means3D", C.c_void_p), ("shs", C.c_void_p), ("colors_precomp", C.c_void_p),
         ("opacities", C.c_void_p), ("scales", C.c_void_p), ("rotations", C.c_void_p),
         ("cov3D_precomp", C.c_void_p), ("interpolation_weights", C.c_void_p), ("num_node_kids", C.c_void_p),
-        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("reserved0", C.c_void_p),
+        ("shs_rest", C.c_void_p), ("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("lod_per_pixel", C.c_int32), ("reserved1", C.c_int32),
         ("prepare_backward", C.c_int32), ("lod_n", C.c_int32),
         ("lod_render_indices", C.c_void_p), ("lod_parent_indices", C.c_void_p),
         ("lod_rows", C.c_int32), ("lod_scatter", C.c_int32),

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define HGS_ABI_VERSION 6
+#define HGS_ABI_VERSION 7
 #define HGS_TILE 16
 #define HGS_INST_GRAD_STRIDE 10 /* floats per (tile, Gaussian) instance in the backward scratch (40 bytes: the ten sums) */
 
@@ -95,10 +95,15 @@ typedef struct hgs_raster_args {
   int32_t activations;      /* OR of HGS_ACT_*; 0 = inputs are already activated (the reference's call) */
   int32_t defer_sh_bwd;     /* backward: skip the SH part (dL_dshs and the view-direction term of dL_dmeans3D); the
                              * caller finishes it for several views at once with hgs_raster_sh_bwd_batched */
-  /* Unused since ABI 5 (was bwd_ws_prezero: the forward zero-filled the backward's instance scratch).  The backward's
-   * compositing kernel now writes EVERY instance record itself -- sums, or zeros for instances no pixel blended -- so
-   * bwd_ws needs no initialisation by anybody.  Kept so that the struct layout does not move. */
-  void* reserved0;
+  /* ABI 7 (the eight bytes that held a pointer until ABI 4 and nothing since): how non-empty interpolation_weights /
+   * num_node_kids are used.  0 (default): a per-GAUSSIAN remap of the opacity in the per-Gaussian kernel,
+   *     o' = w o + (1 - w) (1 - (1 - min(o, 0.99))^(1/k))   for k >= 2;
+   * 1: the same remap applied per PIXEL to alpha = o G inside the compositing kernels -- k coincident children at w = 0 then
+   * composite exactly like their parent at every pixel, not only at the centre (which of the two the
+   * reference's kernel implements is not recoverable from its checkout: gaussian_renderer/__init__.py:258-265 only
+   * passes the tensors on).  Must hold the same value in the forward and the backward call. */
+  int32_t lod_per_pixel;
+  int32_t reserved1;
   /* The caller will run hgs_raster_bwd on the workspaces of this forward (must hold the SAME value in the forward and
    * in the backward call).  The forward's per-Gaussian kernel then also stores, next to the colour, the 3x3 Jacobian
    * d(rgb)/d(view direction) (36 bytes per Gaussian, in geom_ws): it has the SH coefficients in registers anyway, and

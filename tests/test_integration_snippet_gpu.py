@@ -22,7 +22,7 @@ def test_documented_ctypes_binding_renders_the_same_image(gpu):
                    [(n, C.c_void_p) for n in ("bg", "viewmatrix", "projmatrix", "campos", "means3D", "shs",
                     "colors_precomp", "opacities", "scales", "rotations", "cov3D_precomp",
                     "interpolation_weights", "num_node_kids", "shs_rest")] + \
-                   [("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("reserved0", C.c_void_p),
+                   [("activations", C.c_int32), ("defer_sh_bwd", C.c_int32), ("lod_per_pixel", C.c_int32), ("reserved1", C.c_int32),
                     ("prepare_backward", C.c_int32), ("lod_n", C.c_int32), ("lod_render_indices", C.c_void_p),
                     ("lod_parent_indices", C.c_void_p), ("lod_rows", C.c_int32), ("lod_scatter", C.c_int32)]
 

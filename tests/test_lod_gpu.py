@@ -476,3 +476,58 @@ def test_lod_remap_parent_vs_children_on_the_device(gpu, k, o):
                                 "oracle_children_vs_parent": e_or, "predicted": exp}) + "\n")
     except OSError:
         pass
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [2, 4, 8])
+@pytest.mark.parametrize("o", [0.3, 0.9, 1.3])
+def test_per_pixel_lod_remap_children_composite_like_their_parent(gpu, k, o, monkeypatch):
+    """The same KAT with the remap applied per PIXEL to alpha inside K6 (``_C.LOD_REMAP = "alpha"``,
+    hgs_raster_args.lod_per_pixel): k coincident children at w = 0 must give the parent's image at EVERY pixel, up to the
+    share both readings lose to the 1/255 skip rule (each child carries ~alpha / k) -- and the device must reproduce the
+    oracle's ``lod_mode="alpha"`` images."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    import test_oracle_kat as kat
+    monkeypatch.setattr(dgr._C, "LOD_REMAP", "alpha")
+    bg = torch.zeros(3)
+
+    def hip_render(scene, cam, weights, kids):
+        z = torch.zeros(cam.image_height, cam.image_width)
+        return pa.run_hip(scene, cam, bg, z[None].expand(3, -1, -1), z[None], gpu, interpolation_weights=weights,
+                          num_node_kids=kids, grad_mask=None)["color"].double()
+
+    e_hip, parent_hip = kat.lod_parent_vs_children(hip_render, k, o)
+    e_or, parent_or = kat.lod_parent_vs_children(kat._oracle_lod_render("alpha"), k, o)
+    assert (parent_hip - parent_or).abs().max() <= 1e-5
+    assert e_hip <= 1.01 * k / 255.0 and abs(e_hip - e_or) <= 2e-5, (e_hip, e_or)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("do_depth", [True, False])
+def test_per_pixel_lod_remap_matches_the_oracle(gpu, do_depth, monkeypatch):
+    """render_post's call shape (gaussian_renderer/__init__.py:247-277: weights and sibling counts longer than P,
+    abs-activated opacities above 1) with the per-pixel remap: pixels and EVERY gradient against
+    ``rasterize(lod_mode="alpha")``, indices bit-exact -- and the images of the two readings must actually differ."""
+    import diff_gaussian_rasterization as dgr
+    import parity as pa
+    cam, scene, gc, gd = pa.default_case(3000, 208, 144, seed=23)
+    g = torch.Generator().manual_seed(24)
+    scene.opacities = (scene.opacities * 1.35).contiguous()
+    w = torch.rand(scene.P + 50, generator=g)
+    w[torch.rand(scene.P + 50, generator=g) < 0.2] = 1.0            # rows that are not in transition
+    kids = torch.randint(1, 9, (scene.P + 50,), generator=g, dtype=torch.int32)
+    bg = torch.tensor([0.1, 0.2, 0.05])
+    monkeypatch.setattr(dgr._C, "LOD_REMAP", "alpha")
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd, interpolation_weights=w, num_node_kids=kids, do_depth=do_depth,
+                           lod_mode="alpha")
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu, interpolation_weights=w, num_node_kids=kids, do_depth=do_depth)
+    idx = pa.check_indices(hip, oo)
+    assert all(v == 0 for v in idx.values()), idx
+    # (norm-wise 1e-5 as everywhere; element-wise 1.5 x the bound: v_log_f32 / v_exp_f32 / v_rcp_f32 sit in every live
+    # pixel's alpha AND in its derivative here -- measured 1.1 on d_means2D, 0.1 on the pixels)
+    pa.assert_stats("per-pixel LOD remap", pa.compare(hip, oo, og, do_depth=do_depth), mixed_tol=1.5)
+    monkeypatch.setattr(dgr._C, "LOD_REMAP", "opacity")
+    other = pa.run_hip(scene, cam, bg, gc, gd, gpu, interpolation_weights=w, num_node_kids=kids, do_depth=do_depth,
+                       grad_mask=None)
+    assert (other["color"] - hip["color"]).abs().max() > 1e-2        # the two readings are different images
