@@ -588,6 +588,8 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
             color, radii, _ = dgr.GaussianRasterizer(rs)(means3D=bh.means3D, means2D=m2[:bh.B], shs=bh.shs,
                                                          opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
         st["sel"].append((sel.n, sel.tau, sel.misses, sel.attempts))
+        if k + 1 < total:       # the next pose is known here (a viewer extrapolates its camera): its rows cross PCIe under this render
+            bh.prefetch(nodes, boxes, tau, vps[k + 1][0], vps[k + 1][1])
         return color
 
     prev_cache = ghC.set_viewpoint_cache(True)
@@ -689,6 +691,10 @@ def extra_config5_budgeted(dev, steps, warmup, leaves=25_000_000, tau_px=3.0, bu
                        "fetch_kernel": {"launches": len(bh.fetch_events), "rows": fetch_rows, "ms": fetch_ms,
                                         "pcie_GBps": fetch_rows * bh.row_bytes / max(fetch_ms, 1e-9) / 1e6},
                        "evictions": bh.stats["evictions"] - e0,
+                       "prefetch": "the next frame's cut, weights and residency run on a second stream behind this frame's "
+                                   "render; rows_fetched_per_frame counts them, rows_fetched_* min/median/max what select "
+                                   "still had to fetch itself",
+                       "prefetched_rows": bh.stats.get("prefetched_rows", 0),
                        "cold_start": {"seconds": t_cold, "rows": cold["rows_fetched"],
                                       "pcie_GBps": cold["bytes_fetched"] / t_cold / 1e9},
                        "host_copy_s": t_host,

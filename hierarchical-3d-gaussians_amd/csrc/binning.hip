@@ -837,9 +837,16 @@ __device__ __forceinline__ void radix_sort_tile(RadixLds<NW>& l, uint32_t r0, ui
     __syncthreads();
     for (uint32_t i = tid; i < n; i += NT) atomicAdd(&l.hist[(kA[i] >> shift) & 255u], 1u);
     __syncthreads();
-    if (tid == 0) {
-      uint32_t acc = 0;
-      for (int d = 0; d < 256; ++d) { l.base[d] = acc; acc += l.hist[d]; }
+    {   // exclusive scan of the 256 digit counts by the first four waves (one lane walking them was a third of a pass)
+      const uint32_t v = tid < 256 ? l.hist[tid] : 0u;
+      const uint32_t inc = wave_scan_incl(v);
+      if (tid < 256 && lane == 63) l.wave_cnt[0][wave] = inc;          // (wave_cnt is cleared again before its own use)
+      __syncthreads();
+      if (tid < 256) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += l.wave_cnt[0][w];
+        l.base[tid] = before + inc - v;
+      }
     }
     __syncthreads();
     for (uint32_t c0 = 0; c0 < n; c0 += NT) {
@@ -981,6 +988,8 @@ __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __rest
       __syncthreads();
     }
   } else {
+    // a light frame's rare crowded tile: the radix fallback through global scratch, whatever the tile holds (the four-wave
+    // sample sort in here would take the kernel from 71 to 131 registers -- 7 to 3 waves per SIMD for every light frame)
     RadixLds<4>& rl = *reinterpret_cast<RadixLds<4>*>(lds_raw);
     __syncthreads();
 #pragma unroll 1

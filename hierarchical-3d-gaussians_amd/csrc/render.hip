@@ -43,8 +43,6 @@
 //    gradients in registers instead of LDS 0.339).
 #include <stdlib.h>
 
-#include <type_traits>
-
 #include "common.h"
 
 namespace hgs {
@@ -54,31 +52,10 @@ constexpr float kAlphaMin = 1.0f / 255.0f;
 constexpr float kAlphaMax = 0.99f;
 constexpr float kTEps = 0.0001f;
 constexpr float kBig = 1.0e18f;   // y coordinate of a finished / outside pixel: its power is -inf-ish, never a candidate
-#ifndef HGS_K6_BATCH
-#define HGS_K6_BATCH 64
-#endif
-#ifndef HGS_K7_BATCH
-#define HGS_K7_BATCH 64
-#endif
-#ifndef HGS_K6_PREFETCH
-#define HGS_K6_PREFETCH 1
-#endif
-#ifndef HGS_K7_PREFETCH
-#define HGS_K7_PREFETCH 1
-#endif
-#ifndef HGS_K7_NCSPEC
-#define HGS_K7_NCSPEC 0
-#endif
-#ifndef HGS_K7_LPIX_REGS
-#define HGS_K7_LPIX_REGS 1
-#endif
-#ifndef HGS_K7_THR_CMP
-#define HGS_K7_THR_CMP 0
-#endif
 // instances staged per batch (at most one per lane); row kBatch of the LDS arrays is a dummy instance that can never be
 // a candidate (rows whose list is exhausted fetch it)
-constexpr int kFwdBatch = HGS_K6_BATCH;
-constexpr int kBwdBatch = HGS_K7_BATCH;
+constexpr int kFwdBatch = 64;
+constexpr int kBwdBatch = 64;
 
 struct TileGeom {
   int tile, tx, ty;
@@ -153,16 +130,13 @@ __device__ __forceinline__ LaneGeom lane_geom(int lane) {
 
 // What the staging lane decides for its instance: which quadrants can hold a candidate pixel at all.
 //  1. K1's alpha >= 1/255 BOX (ext_x, ext_y around the tile-relative centre) against the quadrants' pixel ranges;
-//  2. (HGS_QUAD_EXACT) the exact test "max of the exponent over the quadrant's rectangle >= skip threshold": the box of a
+//  2. the exact test "max of the exponent over the quadrant's rectangle >= skip threshold": the box of a
 //     slanted ellipse reaches quadrants the ellipse itself misses (7 % of the visits on the benchmark scene, 12 % on the
 //     heavy one, more with needles).  The exponent is a concave quadratic, so its maximum over a rectangle that does not
 //     hold the centre lies on an edge FACING the centre (from any other boundary point the segment towards the centre
 //     runs through the rectangle, along it the exponent grows): one 1-D maximisation per facing edge, at most two per
 //     quadrant.  Continuous rectangle >= its pixel centres, plus a guard of 0.02 in the base-2 exponent: conservative;
 //     the per-pixel candidate and alpha tests still take every decision.  A NaN (degenerate conic) counts as a hit.
-#ifndef HGS_QUAD_EXACT
-#define HGS_QUAD_EXACT 1
-#endif
 struct QuadHit {
   bool q0, q1, q2, q3;
 };
@@ -178,7 +152,6 @@ __device__ __forceinline__ QuadHit quad_hit(float gxt, float gyt, float ex, floa
   const bool yt = (gyt - ey <= 7.0f) && (gyt + ey >= 0.0f);
   const bool yb = (gyt - ey <= 15.0f) && (gyt + ey >= 8.0f);
   QuadHit h{xl && yt, xr && yt, xl && yb, xr && yb};
-#if HGS_QUAD_EXACT
   // pixel - centre ranges of the two column halves and the two row halves
   const float lx[2] = {0.0f - gxt, 8.0f - gxt}, hx[2] = {7.0f - gxt, 15.0f - gxt};
   const float ly[2] = {0.0f - gyt, 8.0f - gyt}, hy[2] = {7.0f - gyt, 15.0f - gyt};
@@ -198,7 +171,6 @@ __device__ __forceinline__ QuadHit quad_hit(float gxt, float gyt, float ex, floa
     e[q] = (in_x && in_y) || !(miss_v && miss_h);
   }
   h.q0 = h.q0 && e[0]; h.q1 = h.q1 && e[1]; h.q2 = h.q2 && e[2]; h.q3 = h.q3 && e[3];
-#endif
   return h;
 }
 
@@ -248,15 +220,10 @@ __device__ __forceinline__ void fwd_pair_live(FwdPair<DEPTH>& p, f2 pw, const fl
   p.fly.y = stop1 ? kBig : p.fly.y;      // is finished is checked once per batch, not per stop event
 }
 
-// Tuning aid: HGS_K6_WPE = waves per SIMD the register allocation is held to (default: what the kernel needs, 6 at 78
-// registers).  8 160 one-wave tiles on 1 024 SIMDs are 1.33 rounds at 6 waves per SIMD, 2 rounds at 4, one round at 8.
-#ifdef HGS_K6_WPE
-#define HGS_K6_OCC __attribute__((amdgpu_waves_per_eu(HGS_K6_WPE, HGS_K6_WPE)))
-#else
-#define HGS_K6_OCC
-#endif
+// (6 waves per SIMD at 78 registers: 8 160 one-wave tiles on 1 024 SIMDs are 1.33 rounds; fewer resident waves cost more
+// than whole rounds win, a 64-register build spills -- profiles/r05_occupancy_vs_rounds.txt)
 template <bool DEPTH, bool LODA>
-__global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
+__global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     float* __restrict__ out_color, float* __restrict__ out_invdepth, float* __restrict__ final_T,
@@ -362,7 +329,6 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
       fwd_pair_live<DEPTH, LODA>(P0, pw0, q1, q2, idx1, lw, lik);
       fwd_pair_live<DEPTH, LODA>(P1, pw1, q1, q2, idx1, lw, lik);
     };
-#if HGS_K6_PREFETCH
     uint32_t jA = myq[0], jB = myq[4];
     float4 A0 = staged<kLds>(lrec, jA)[0], A1 = staged<kLds>(lrec, jA)[1], A2 = staged<kLds>(lrec, jA)[2];
     for (int it = 0; it < nmax; it += 2) {
@@ -377,12 +343,6 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
       }
       jA = jA2;
     }
-#else
-    for (int it = 0; it < nmax; ++it) {
-      const uint32_t j = myq[it * 4];      // this row's next instance (kB: none)
-      visit(j, staged<kLds>(lrec, j)[0], staged<kLds>(lrec, j)[1], staged<kLds>(lrec, j)[2]);
-    }
-#endif
     alive = __ballot(fminf(fminf(P0.fly.x, P0.fly.y), fminf(P1.fly.x, P1.fly.y)) < kBig);
   }
 
@@ -413,11 +373,7 @@ __global__ __launch_bounds__(64) HGS_K6_OCC void render_fwd_quad_kernel(
 // ================================================================================
 struct BwdPair {
   f2 fly, T, A, bgd, gd;   // A: value blended BEHIND the next Gaussian to be visited, per unit T
-#if HGS_K7_LPIX_REGS
   f2 c0, c1, c2;           // dL/dC (r, g, b) of the pair's two pixels
-#else
-  const f2* pix;           // LDS: this lane's dL/dC (r, g, b) of the pair's two pixels at [0], [64], [128] (see the kernel)
-#endif
   uint32_t nc0, nc1;
 };
 // Per-lane partial sums of one (instance, quadrant) over the lane's four pixels, as plain floats.  All four pixels of a
@@ -452,11 +408,7 @@ __device__ __forceinline__ void bwd_pair_live(BwdPair& p, BwdSums& S, f2 pw, f2 
   const f2 oma = 1.0f - ae;
   const f2 rinv = {__builtin_amdgcn_rcpf(oma.x), __builtin_amdgcn_rcpf(oma.y)};
   const f2 Tcur = p.T * rinv;                                   // transmittance in front of this Gaussian
-#if HGS_K7_LPIX_REGS
   const f2 g0 = p.c0, g1 = p.c1, g2 = p.c2;
-#else
-  const f2 g0 = p.pix[0], g1 = p.pix[64], g2 = p.pix[128];
-#endif
   f2 q = fma2(g2, splat(q2.x), fma2(g1, splat(q1.w), g0 * q1.z));
   if (DEPTH) q = fma2(p.gd, splat(q2.y), q);
   const f2 qA = q - p.A;
@@ -527,11 +479,11 @@ __device__ __forceinline__ void row_reduce10(float v0, float v1, float v2, float
       : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "v"(v9));
 }
 
-#ifndef HGS_K7_WAVES
-#define HGS_K7_WAVES 4
-#endif
+// four waves per SIMD (128 registers, no scratch); five need 96 and spill, the colour gradients in LDS reach 113:
+// profiles/r06_k7_occupancy.txt
+constexpr int kK7Waves = 4;
 template <bool DEPTH, bool LODA>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES, HGS_K7_WAVES))) void render_bwd_quad_kernel(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK7Waves))) void render_bwd_quad_kernel(
     const uint32_t* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float4* __restrict__ records, int W, int H, int gx, int T, const float* __restrict__ bg,
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -550,11 +502,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
   // on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute changes no bit)
   constexpr int kAccRows = (kB + 1) * kInstStride;
   __shared__ __attribute__((aligned(8))) float acc[2 * kAccRows];
-#if !HGS_K7_LPIX_REGS
-  // The colour gradients of a lane's four pixels are constants that only the live path reads: they sit in LDS ([pair][r,
-  // g, b][lane] as float2; written and read by the SAME lane, so no barrier), not in 12 registers
-  __shared__ f2 lpix[2 * 3 * 64];
-#endif
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
@@ -599,15 +546,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
   const float flyb = (float)lg.ly0;                              // y of pixel 0; the pairs' fly is set per batch
   P0.T = f2{Tr[0], Tr[1]};     P1.T = f2{Tr[2], Tr[3]};
   P0.bgd = f2{bgd[0], bgd[1]}; P1.bgd = f2{bgd[2], bgd[3]};
-#if HGS_K7_LPIX_REGS
   P0.c0 = f2{g0[0], g0[1]}; P0.c1 = f2{g1[0], g1[1]}; P0.c2 = f2{g2[0], g2[1]};
   P1.c0 = f2{g0[2], g0[3]}; P1.c1 = f2{g1[2], g1[3]}; P1.c2 = f2{g2[2], g2[3]};
-#else
-  P0.pix = lpix + lane; P1.pix = lpix + 3 * 64 + lane;
-  lpix[0 * 64 + lane] = f2{g0[0], g0[1]}; lpix[3 * 64 + lane] = f2{g0[2], g0[3]};
-  lpix[1 * 64 + lane] = f2{g1[0], g1[1]}; lpix[4 * 64 + lane] = f2{g1[2], g1[3]};
-  lpix[2 * 64 + lane] = f2{g2[0], g2[1]}; lpix[5 * 64 + lane] = f2{g2[2], g2[3]};
-#endif
   P0.gd = f2{gd[0], gd[1]};    P1.gd = f2{gd[2], gd[3]};
   P0.A = P1.A = splat(0.0f);
   P0.nc0 = nc[0]; P0.nc1 = nc[1]; P1.nc0 = nc[2]; P1.nc1 = nc[3];
@@ -683,16 +623,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
     // "The forward blended this Gaussian into the pixel" <=> rel < n_contrib.  A pixel whose last contributor lies in a
     // LATER batch passes for every instance of this one; a pixel whose last contributor lies in an EARLIER batch (or
     // outside the image: n_contrib 0) fails for every instance and is parked at y = kBig for the batch; only a batch
-    // that holds some pixel's last contributor needs the per-instance compare (one batch in five on the benchmark).
+    // that holds some pixel's last contributor needs the per-instance compare at all (one batch in five on the benchmark;
+    // a second instantiation of the loop without it measured slower: profiles/r03_optimisation_ladders.md).
     const uint32_t bs = (uint32_t)bstart;
     P0.fly = f2{P0.nc0 > bs ? flyb : kBig, P0.nc1 > bs ? flyb + 2.0f : kBig};
     P1.fly = f2{P1.nc0 > bs ? flyb + 4.0f : kBig, P1.nc1 > bs ? flyb + 6.0f : kBig};
-    const bool mixed = __ballot((P0.nc0 > bs && P0.nc0 < bs + kB) || (P0.nc1 > bs && P0.nc1 < bs + kB) ||
-                                (P1.nc0 > bs && P1.nc0 < bs + kB) || (P1.nc1 > bs && P1.nc1 < bs + kB)) != 0;
 
     // one (instance, quadrant) pair per row of the wave
-    auto visit = [&](auto nc_tag, uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
-      constexpr bool NC = decltype(nc_tag)::value;
+    auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
       const uint32_t rel = (uint32_t)bstart + j;
       const float gyt = q0.y;
       const float dx = q0.x - flx;
@@ -704,22 +642,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
       // per-pixel predicate "the forward blended this Gaussian into the pixel": rel < n_contrib here, alpha >= 1/255 in
       // bwd_pair_live (exactly the forward's test; a parked pixel and the dummy instance have alpha 0).
-#if HGS_K7_THR_CMP
-      // (+ the log-domain candidate test power2 >= thr before the exp: implied by alpha >= 1/255 -- it has a guard band
-      // -- so it decides nothing; four compares per visit, K7 0.314 -> see DESIGN.md)
-      const float thr = q2v.z;
-      uint64_t k0 = __ballot(pw0.x >= thr), k1 = __ballot(pw0.y >= thr);
-      uint64_t k2 = __ballot(pw1.x >= thr), k3 = __ballot(pw1.y >= thr);
-      if (NC) {
-        k0 &= __ballot(rel < P0.nc0); k1 &= __ballot(rel < P0.nc1);
-        k2 &= __ballot(rel < P1.nc0); k3 &= __ballot(rel < P1.nc1);
-      }
-      const bool c0 = __builtin_amdgcn_inverse_ballot_w64(k0), c1 = __builtin_amdgcn_inverse_ballot_w64(k1);
-      const bool c2 = __builtin_amdgcn_inverse_ballot_w64(k2), c3 = __builtin_amdgcn_inverse_ballot_w64(k3);
-#else
-      const bool c0 = !NC || rel < P0.nc0, c1 = !NC || rel < P0.nc1;
-      const bool c2 = !NC || rel < P1.nc0, c3 = !NC || rel < P1.nc1;
-#endif
+      const bool c0 = rel < P0.nc0, c1 = rel < P0.nc1;
+      const bool c2 = rel < P1.nc0, c3 = rel < P1.nc1;
       const f2 q2 = f2{q2v.x, q2v.y};
       float lw = 0.0f, lik = 0.0f;
       if constexpr (LODA) {
@@ -743,8 +667,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
         if (adder_c) atomicAdd(row + kc, tc);
       }
     };
-    auto run = [&](auto nc_tag) {
-#if HGS_K7_PREFETCH
+    {
       // Two iterations per trip, the record of the NEXT iteration and the list entry of the one after it requested
       // before the current one is composited: every row's record address depends on a list entry that is itself in
       // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
@@ -753,28 +676,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
       for (int it = 0; it < nmax; it += 2) {
         const float4 B0 = staged<kLds>(lrec, jB)[0], B1 = staged<kLds>(lrec, jB)[1], B2 = staged<kLds>(lrec, jB)[2];
         const uint32_t jA2 = myq[(it + 2) * 4];
-        visit(nc_tag, jA, A0, A1, A2);
+        visit(jA, A0, A1, A2);
         if (it + 1 < nmax) {
           A0 = staged<kLds>(lrec, jA2)[0]; A1 = staged<kLds>(lrec, jA2)[1]; A2 = staged<kLds>(lrec, jA2)[2];
           const uint32_t jB2 = myq[(it + 3) * 4];
-          visit(nc_tag, jB, B0, B1, B2);
+          visit(jB, B0, B1, B2);
           jB = jB2;
         }
         jA = jA2;
       }
-#else
-      for (int it = 0; it < nmax; ++it) {
-        const uint32_t j = myq[it * 4];              // this row's next instance (kB: none)
-        visit(nc_tag, j, staged<kLds>(lrec, j)[0], staged<kLds>(lrec, j)[1], staged<kLds>(lrec, j)[2]);
-      }
-#endif
-    };
-#if HGS_K7_NCSPEC
-    if (mixed) run(std::true_type{}); else run(std::false_type{});
-#else
-    (void)mixed;
-    run(std::true_type{});
-#endif
+    }
     __syncthreads();
     // lane i stores instance i's record to its emission slot: every staged instance is written, reached or not
     if (lane < n) {
@@ -800,32 +711,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(HGS_K7_WAVES
 
 }  // namespace
 
-// Diagnostic (timing only, results incomplete): HGS_RENDER_GRID_LIMIT=n launches only the first n workgroups of K6 / K7 --
-// how the kernels' time scales with the number of tiles (launch tail, occupancy: profiles/r05_k6_k7_page.md).
-static int render_grid_limit(int nblk) {
-  static const char* e = getenv("HGS_RENDER_GRID_LIMIT");
-  if (!e) return nblk;
-  const int n = atoi(e);
-  return n > 0 && n < nblk ? n : nblk;
-}
-
-// Tuning aid: HGS_K6_DYN_LDS / HGS_K7_DYN_LDS = bytes of (unused) dynamic LDS per workgroup -- caps the workgroups a
-// compute unit holds (160 KB / (static + dynamic)) without touching the code: occupancy against the number of rounds.
-static size_t env_bytes(const char* name) {
-  const char* e = getenv(name);
-  return e ? (size_t)atoi(e) : 0;
-}
-
 int launch_render_fwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b, const ImgWs& im,
                       float* out_color, float* out_invdepth, hipStream_t s) {
-  static const size_t dyn = env_bytes("HGS_K6_DYN_LDS");
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
-  const int nblk = render_grid_limit(((T + 7) / 8) * 8);
+  const int nblk = ((T + 7) / 8) * 8;
   const bool depth = a.do_depth && out_invdepth;
   const bool loda = a.lod_per_pixel && a.interpolation_weights && a.num_node_kids;
   auto kern = loda ? (depth ? render_fwd_quad_kernel<true, true> : render_fwd_quad_kernel<false, true>)
                    : (depth ? render_fwd_quad_kernel<true, false> : render_fwd_quad_kernel<false, false>);
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, out_color,
                      out_invdepth, im.final_T, im.n_contrib, b.tile_order, a.interpolation_weights, a.num_node_kids);
   HGS_LAUNCH_CHECK("render_fwd_quad", s, a.debug);
@@ -836,14 +730,13 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
                       const float* out_color, const float* out_invdepth, const float* dL_dcolor,
                       const float* dL_dinvdepth, float* inst_grads, hipStream_t s) {
   (void)out_color;
-  static const size_t dyn = env_bytes("HGS_K7_DYN_LDS");
   const int gxx = grid_x(a.width), T = gxx * grid_y(a.height);
-  const int nblk = render_grid_limit(((T + 7) / 8) * 8);
+  const int nblk = ((T + 7) / 8) * 8;
   const bool depth = a.do_depth && out_invdepth && dL_dinvdepth;
   const bool loda = a.lod_per_pixel && a.interpolation_weights && a.num_node_kids;
   auto kern = loda ? (depth ? render_bwd_quad_kernel<true, true> : render_bwd_quad_kernel<false, true>)
                    : (depth ? render_bwd_quad_kernel<true, false> : render_bwd_quad_kernel<false, false>);
-  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), dyn, s, b.ranges, b.vals_out,
+  hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
                      im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order, a.interpolation_weights,
                      a.num_node_kids);

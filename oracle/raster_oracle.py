@@ -484,7 +484,10 @@ def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotation
                 band = fragile_tol + FRAGILE_FP32_K * M
                 frag = ((alpha - ALPHA_MIN).abs() < band * ALPHA_MIN) & (power <= 0) & ~dead
                 frag |= (power.abs() < 1e-12) & ~dead
-                band_T = fragile_tol + torch.cumsum(a_eff / (1.0 - a_eff).clamp_min(1e-2) * band, dim=1)
+                # (an alpha AT the 0.99 cap is a constant: it carries no rounding error into 1 - alpha)
+                noise = torch.where(araw < ALPHA_MAX, a_eff / (1.0 - a_eff).clamp_min(1e-2) * (FRAGILE_FP32_K * M),
+                                    torch.zeros_like(M))
+                band_T = fragile_tol + torch.cumsum(noise, dim=1)
                 frag |= ((T_incl - T_EPS).abs() < band_T * T_EPS) & live & \
                         (torch.cumsum(stop.to(torch.int32), dim=1) <= 1)
                 fr = frag.any(dim=1)

@@ -181,3 +181,44 @@ def test_fly_through_of_a_million_node_hierarchy_streams_bit_identically(gpu):
     assert sum(fetched) > 1.2 * bh.B and bh.stats["evictions"] > 0.4 * bh.B    # slots are recycled continuously
     assert bh.stats["retries"] == 0
     assert int((bh.slot_of == -2).sum()) == 0
+
+
+def test_fly_through_with_prefetch_of_the_next_view(gpu):
+    """The same kind of fly-through with ``prefetch`` of the NEXT view on a second stream after every render was enqueued
+    (hgs/residency.py, round 6): every frame -- the one after the jump included -- still equals the fully resident render
+    bit for bit, the rows now cross PCIe under the previous frame (``select`` finds the prefetched cut resident: it fetches
+    nothing), rows of the frame being rendered are never evicted by the prefetch, and a view that was NOT the prefetched
+    one (the pose prediction missed) is rendered correctly all the same."""
+    from hgs.residency import BudgetedHierarchy
+    cam0 = synth.make_camera(W, H)
+    h = hierarchy.build_hierarchy_on_device(300_000, cam0, gpu, seed=13)
+    G = h.xyz.shape[0]
+    full = dict(means3D=h.xyz, shs=h.shs, opacities=h.alpha.abs().reshape(-1, 1).contiguous(),
+                scales=torch.exp(h.log_scales), rotations=torch.nn.functional.normalize(h.rots))
+    nodes, boxes = h.nodes, h.boxes
+    tau = (2 * 8.0 + 1) * cam0.tanfovx / (0.5 * W)
+    cams = [synth.make_camera(W, H, T=np.array([0.0 if k < 10 else -3.0, 0.0, -0.25 * (k % 10)])) for k in range(18)]
+    refs = [_reference(gpu, c, full, nodes, boxes, tau) for c in cams]
+    need = max(r[3] for r in refs)
+    bh = BudgetedHierarchy(full["means3D"].cpu(), full["shs"].cpu(), full["opacities"].cpu(), full["scales"].cpu(),
+                           full["rotations"].cpu(), gpu, budget_rows=int(1.1 * need))
+    vps = [(c.camera_center.to(gpu), c.camera_center.cpu()) for c in cams]
+    fetched_in_select, mispredicted = [], 13
+    for k, (c, (color_ref, radii_ref, n_ref, rows_ref)) in enumerate(zip(cams, refs)):
+        sel = bh.select(nodes, boxes, tau, *vps[k])
+        assert sel.attempts == 1 and sel.n == n_ref
+        arrays = dict(means3D=bh.means3D, shs=bh.shs, opacities=bh.opacities, scales=bh.scales, rotations=bh.rotations)
+        color, radii = _render(gpu, c, arrays, sel.render_indices, sel.parent_indices, sel.weights, sel.kids)
+        if k + 1 < len(cams):          # (frame `mispredicted` is prefetched for the wrong pose)
+            nxt = vps[k + 1] if k + 1 != mispredicted else vps[0]
+            bh.prefetch(nodes, boxes, tau, *nxt)
+        assert torch.equal(color, color_ref) and torch.equal(radii, radii_ref), k
+        fetched_in_select.append(sel.misses)
+    torch.cuda.synchronize()
+    print("rows fetched inside select per frame:", fetched_in_select, "prefetched", bh.stats.get("prefetched_rows"))
+    # the budget is 1.1 x the largest view: the prefetch may only take free slots and slots of OLDER frames, so select
+    # still fetches what did not fit -- but most rows cross the bus behind a render
+    later = sum(m for i, m in enumerate(fetched_in_select[1:], 1) if i != mispredicted)
+    assert fetched_in_select[0] > 0 and fetched_in_select[mispredicted] > 0
+    assert bh.stats["prefetched_rows"] > 2 * later, (bh.stats["prefetched_rows"], later)
+    assert bh.stats["evictions"] > 0 and bh.stats["retries"] == 0 and int((bh.slot_of == -2).sum()) == 0
