@@ -67,10 +67,8 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_f
     rec, inst = 64, 40
     ch = 4 if depth else 3
     b = {}
-    # K1 as two kernels (round 5): geometry (inputs, record, per-Gaussian arrays) and colour (SH block in, the record's
-    # three colour floats and the Jacobian row out); `fold_k1` adds them up again when the fused kernel ran
-    b["preprocess_fwd"] = P * 44 + 4 * P + V * rec + 20 * P
-    b["preprocess_fwd_color"] = V * 12 * M + 16 * P + V * (12 + 48)
+    # K1: inputs, record, per-Gaussian arrays + SH block in, the record's three colour floats and the Jacobian row out
+    b["preprocess_fwd"] = P * 44 + 4 * P + V * rec + 20 * P + V * 12 * M + 16 * P + V * (12 + 48)
     b["scan"] = 8 * (P // 256 + 1)
     b["duplicate_keys"] = 12 * P + 8 * L
     b["tile_sort"] = 8 * L + 4 * L + 8 * T        # (tile id, Gaussian id) pairs in, ids grouped by tile out, ranges
@@ -87,7 +85,6 @@ def algorithmic_bytes(P, V, L, N, T, M, depth=True, k=1, deferred_sh=False, sh_f
     if sh_forward:
         # the colours come from one batched pass per step; K1 reads 12 B of colour instead of 12 M B of coefficients
         b["preprocess_fwd"] = P * 44 + V * 12 + 4 * P + V * (rec + 12) + 8 * P
-        b.pop("preprocess_fwd_color", None)
         b["sh_colors_batched"] = P * 12 * M + 12 * P + k * (13 * P)
     return b
 
@@ -99,8 +96,7 @@ def survey_bytes(P, V, L, N, T, M):
     ``algorithmic_bytes`` above additionally charges this implementation's 64-byte record and its 48-byte
     per-instance scratch and is reported under ``roofline.impl_*``."""
     b = {}
-    b["preprocess_fwd"] = 44 * P + 4 * P + 28 * V             # (of the 40-byte 2D record: everything but the colour)
-    b["preprocess_fwd_color"] = 12 * M * V + 12 * V            # SH block in, colour out
+    b["preprocess_fwd"] = 44 * P + 4 * P + 28 * V + 12 * M * V + 12 * V     # inputs, radii, the 40-byte 2D record; SH block in
     b["duplicate_keys"] = 12 * L
     b["tile_sort"] = 12 * L + 4 * L                      # sort read + sorted ids written
     b["render_fwd"] = 4 * L + 40 * L + 16 * N + 8 * N + 8 * T
@@ -346,11 +342,11 @@ def extra_dropin(name, scene_cpu, W, H, dev, measure, steps, warmup, what):
     P, M = scene.P, scene.shs.shape[1]
     L, V = int(round(d.mean_L())), int(round(d.mean_V()))
     N, T = W * H, ((W + 15) // 16) * ((H + 15) // 16)
-    sb = fold_k1(survey_bytes(P, V, L, N, T, M), stages)
+    sb = survey_bytes(P, V, L, N, T, M)
     out = {"what": what, "metric": "fwd+bwd frames/s", "value": steps / elapsed, "unit": "frames/s", "steps": steps,
            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
            "host_ms_per_step": getattr(measure, "last_host_ms", None),
-           "stage_sum_ms": sum(v for k_, v in stages.items() if k_ not in OVERLAPPED_STAGES) if stages else None,
+           "stage_sum_ms": sum(stages.values()) if stages else None,
            "config": {"gaussians": P, "visible": V, "tile_instances": L, "width": W, "height": H, "schedule": "dropin",
                       "capacity_misses": dgrC.stats["capacity_misses"] - miss0},
            "algorithmic_bytes_per_frame": sum(sb.values()), "stages_ms": stages}
@@ -744,22 +740,7 @@ def run_extras(args, dev, measure):
     return out
 
 
-def fold_k1(sb, stages):
-    """The byte models carry K1 as its two kernels; where the fused kernel ran (no `preprocess_fwd_color` stage was
-    timed) the colour part's bytes go back to `preprocess_fwd`."""
-    sb = dict(sb)
-    if "preprocess_fwd_color" in sb and "preprocess_fwd_color" not in (stages or {}):
-        sb["preprocess_fwd"] = sb.get("preprocess_fwd", 0) + sb.pop("preprocess_fwd_color")
-    return sb
-
-
-# stages that run on the library's second stream NEXT TO other stages of the same frame: their time is not part of the
-# frame's critical path (their bytes are part of its traffic)
-OVERLAPPED_STAGES = ("preprocess_fwd_color",)
-
-
 def roofline_object(sb, stages, dom, model_text, extra=None):
-    sb = fold_k1(sb, stages)
     sec = stages[dom] * 1e-3
     achieved = sb[dom] / sec / 1e9
     r = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -770,12 +751,10 @@ def roofline_object(sb, stages, dom, model_text, extra=None):
     known = [s_ for s_ in stages if s_ in sb]
     if known:
         tot_b = sum(sb[s_] for s_ in known)
-        tot_s = sum(stages[s_] for s_ in known if s_ not in OVERLAPPED_STAGES) * 1e-3
+        tot_s = sum(stages[s_] for s_ in known) * 1e-3
         r["frame"] = {"achieved": tot_b / tot_s / 1e9, "frac": tot_b / tot_s / 1e9 / HBM_PEAK_GBS, "bytes": tot_b,
-                      "ms": tot_s * 1e3, "what": "all stages of the frame: sum of their §8(d) bytes / sum of the times of "
-                                                 "the stages on the caller's stream (preprocess_fwd_color runs next to the "
-                                                 "binning stages on a second stream: its bytes count, its time does not; "
-                                                 "frame_hbm_frac uses the wall clock)"}
+                      "ms": tot_s * 1e3, "what": "all stages of the frame: sum of their §8(d) bytes / sum of their times "
+                                                 "(frame_hbm_frac uses the wall clock)"}
     if extra:
         r.update(extra)
     return r
@@ -1142,8 +1121,7 @@ def main():
         batched_primary = primary == "batched"
         ab = algorithmic_bytes(P, V, L, N, T, M, k=kk_, deferred_sh=batched_primary and (defer_sh or sh_fwd),
                                sh_forward=batched_primary and sh_fwd)
-        sb = fold_k1(survey_bytes(P, V, L, N, T, M), r.get("stages"))
-        ab = fold_k1(ab, r.get("stages"))
+        sb = survey_bytes(P, V, L, N, T, M)
         per_step = ("sh_bwd_batched", "sh_colors_batched")
         impl_frame = sum(v for n_, v in ab.items() if n_ not in per_step) + sum(ab.get(n_, 0) for n_ in per_step) / kk_
         survey_frame = sum(sb.values())

@@ -16,10 +16,10 @@ namespace hgs {
 
 // ---- optional per-stage timing (hipEvents on the caller's stream) ---------------
 enum Stage { ST_PREPROCESS_FWD = 0, ST_SCAN, ST_DUPLICATE, ST_SORT, ST_RANGES, ST_SORT_DEPTH, ST_RENDER_FWD,
-             ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_BATCHED, ST_PREPROCESS_COLOR, ST_COUNT };
+             ST_MEMSET_BWD, ST_RENDER_BWD, ST_PREPROCESS_BWD, ST_SH_BATCHED, ST_COUNT };
 static const char* kStageNames[ST_COUNT] = {"preprocess_fwd", "scan", "duplicate_keys", "tile_sort", "tile_ranges",
                                             "tile_depth_sort", "render_fwd", "memset_bwd", "render_bwd",
-                                            "preprocess_bwd", "sh_bwd_batched", "preprocess_fwd_color"};
+                                            "preprocess_bwd", "sh_bwd_batched"};
 struct Pending { int stage; hipEvent_t a, b; };
 static uint32_t g_timing = 0;      // bit 0: every stage; bit (1 + stage): that stage only
 static std::mutex g_tmu;
@@ -59,17 +59,14 @@ constexpr int kMaxDevices = 16;
 struct ThreadHost {
   uint32_t* pinned_L = nullptr;
   hipEvent_t ev[kMaxDevices] = {};     // one per device: an event is recorded on streams of the device it was created on
-  hipEvent_t fork[kMaxDevices] = {};   // K1's geometry kernel done -> the colour kernel may start (second stream)
-  hipEvent_t join[kMaxDevices] = {};   // the colour kernel done -> K6 may start
 };
 static pthread_key_t g_host_key;
 static pthread_once_t g_host_once = PTHREAD_ONCE_INIT;
 static void thread_host_free(void* p) {
   ThreadHost* h = static_cast<ThreadHost*>(p);
   if (!h) return;
-  for (hipEvent_t* set : {h->ev, h->fork, h->join})
-    for (int i = 0; i < kMaxDevices; ++i)
-      if (set[i]) (void)hipEventDestroy(set[i]);
+  for (int i = 0; i < kMaxDevices; ++i)
+    if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->pinned_L) (void)hipHostFree(h->pinned_L);
   delete h;
 }
@@ -92,32 +89,6 @@ static ThreadHost* thread_host(int device) {
     return nullptr;
   }
   return h;
-}
-
-// The library's second stream per device (the colour half of K1 runs on it next to the binning kernels, preprocess.hip)
-// and the calling thread's fork / join events.  false: no split (the fused K1 is launched instead).
-static bool aux_resources(int device, ThreadHost* th, hipStream_t* aux) {
-  static std::mutex mu;
-  static hipStream_t streams[kMaxDevices] = {};
-  static bool failed[kMaxDevices] = {};
-  {
-    std::lock_guard<std::mutex> lk(mu);
-    if (failed[device]) return false;
-    if (!streams[device] && hipStreamCreateWithFlags(&streams[device], hipStreamNonBlocking) != hipSuccess) {
-      (void)hipGetLastError();
-      streams[device] = nullptr;
-      failed[device] = true;
-      return false;
-    }
-    *aux = streams[device];
-  }
-  for (hipEvent_t* e : {&th->fork[device], &th->join[device]})
-    if (!*e && hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) {
-      (void)hipGetLastError();
-      *e = nullptr;
-      return false;
-    }
-  return true;
 }
 
 static bool blocking_waits() {
@@ -323,14 +294,13 @@ int hgs_raster_fwd_stage1(const hgs_raster_args* a, void* geom_ws, int32_t* radi
 
 // Stage-2 launches.  L is exact when L_dev == nullptr; otherwise it is a capacity and the kernels read the
 // actual instance count from device memory.
-// colours_done: an event of another stream that K6 must wait for (the colour half of a split K1).
 // super != nullptr (single-call forward only): K1 left raw workgroup sums + superblock totals, K3 finishes the scans and
 // is the kernel that produces the instance count -- into *mirror (mapped host word) or, without a mapping, by a copy
 // into `stage` -- and `ev` is recorded right behind it.
 static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs& b, const ImgWs& im, uint32_t L,
                           const uint32_t* L_dev, int T, float* out_color, float* out_invdepth, hipStream_t s,
                           uint32_t* super = nullptr, uint32_t* mirror = nullptr, uint32_t* stage = nullptr,
-                          hipEvent_t ev = nullptr, hipEvent_t colours_done = nullptr) {
+                          hipEvent_t ev = nullptr) {
   int rc;
   const bool bin = L > 0 && tile_bin_supported(T);
   if ((rc = HGS_TIMED(ST_DUPLICATE, s, launch_duplicate_tiles(*a, g, b, L, bin, s, super, mirror)))) return rc;   // also zeroes b.ranges
@@ -349,7 +319,6 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
   }
   if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
   if (!bin && (rc = launch_tile_order(b, T, s, a->debug))) return rc;   // (the binning path orders inside its scatter launch)
-  if (colours_done) HGS_HIP(hipStreamWaitEvent(s, colours_done, 0));    // K1's colour kernel (second stream) completes the records
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
 }
 
@@ -399,31 +368,9 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   const int nblk = (a->P + kPreBlock - 1) / kPreBlock;
   uint32_t* super = nullptr;
   if (L_cap > 0 && tile_bin_supported(T) && nblk <= kSuper * kMaxSuper) super = super_block_acquire(s);
-  // K1 in two kernels where the layout allows: geometry here, colour on the library's second stream next to the binning
-  hipStream_t aux = nullptr;
-  const bool split = preprocess_fwd_splits(*a) && aux_resources(device, th, &aux);
-  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s, super, split, super ? k3_heavy_threshold(L_cap, a->P) : 0u)))) {
+  if ((rc = HGS_TIMED(ST_PREPROCESS_FWD, s, launch_preprocess_fwd(*a, g, radii, s, super, super ? k3_heavy_threshold(L_cap, a->P) : 0u)))) {
     if (super) super_block_mark_dirty(super);
     return rc;
-  }
-  hipEvent_t colours_done = nullptr;
-  if (split) {
-    // (K1 has added its sums to `super` by now: every error exit from here on marks the block dirty)
-    hipError_t fe = hipEventRecord(th->fork[device], s);
-    if (fe == hipSuccess) fe = hipStreamWaitEvent(aux, th->fork[device], 0);
-    if (fe != hipSuccess) {
-      set_error("hgs_raster_fwd: fork of the colour kernel failed: %s", hipGetErrorString(fe));
-      if (super) super_block_mark_dirty(super);
-      return HGS_ERR_HIP;
-    }
-    rc = HGS_TIMED(ST_PREPROCESS_COLOR, aux, launch_preprocess_color(*a, g, aux));
-    if (rc == HGS_OK && hipEventRecord(th->join[device], aux) != hipSuccess) { set_error("hgs_raster_fwd: event record failed"); rc = HGS_ERR_HIP; }
-    if (rc) {                 // whatever did get enqueued on the second stream finishes before the caller's stream goes on
-      (void)hipStreamSynchronize(aux);
-      if (super) super_block_mark_dirty(super);
-      return rc;
-    }
-    colours_done = th->join[device];
   }
   const uint32_t* L_dev = g.block_sums + nblk;
   hipError_t e = hipSuccess;
@@ -434,11 +381,9 @@ int hgs_raster_fwd(const hgs_raster_args* a, void* geom_ws, void* bin_ws, void* 
   }
   // everything else is enqueued before the host looks at L: the GPU never waits for the host
   if (e == hipSuccess) rc = enqueue_stage2(a, g, b, im, L_cap, L_dev, T, out_color, out_invdepth, s, super,
-                                           static_cast<uint32_t*>(mirror), stage, ev, colours_done);
+                                           static_cast<uint32_t*>(mirror), stage, ev);
   if (rc || e != hipSuccess) {
-    // the colour kernel must not outlive the call on a stream the caller does not know about; the superblock totals may
-    // not have been consumed and cleared: zero them before the next use
-    if (colours_done) (void)hipStreamWaitEvent(s, colours_done, 0);
+    // the superblock totals may not have been consumed and cleared: zero them before the next use
     if (super) super_block_mark_dirty(super);
     if (rc) return rc;
   }

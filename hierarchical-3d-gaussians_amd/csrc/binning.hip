@@ -894,11 +894,6 @@ __device__ __forceinline__ void radix_sort_tile(RadixLds<NW>& l, uint32_t r0, ui
 // radix fallback once its waves are done with their own tiles -- the lists stay empty and NO further launch follows
 // (rounds 1-4 launched the 1024-lane kernel with 146 KB of LDS per workgroup behind every frame to find its lists empty:
 // 5 us and a kernel boundary).
-#ifdef HGS_SORT_WPE          // tuning aid, as HGS_K6_WPE in render.hip
-#define HGS_SORT_OCC __attribute__((amdgpu_waves_per_eu(HGS_SORT_WPE, HGS_SORT_WPE)))
-#else
-#define HGS_SORT_OCC
-#endif
 template <bool QUAD>
 __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __restrict__ ranges,
                                                           const float* __restrict__ depths,
@@ -1002,11 +997,9 @@ __device__ __forceinline__ void tile_depth_sort_wave_body(const uint32_t* __rest
 
 // (two kernels for the two bodies: the register budgets differ -- 32 KB of LDS per workgroup hold the QUAD kernel at
 // four waves per SIMD anyway, so it is told to fit them)
-#ifndef HGS_SORT_QUAD_WPE
-#define HGS_SORT_QUAD_WPE 4
-#endif
+constexpr int kSortQuadWaves = 4;
 template <bool QUAD>
-__global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
+__global__ __launch_bounds__(256) void tile_depth_sort_wave_kernel(const uint32_t* __restrict__ ranges,
                                                                    const float* __restrict__ depths,
                                                                    uint32_t* __restrict__ vals, uint32_t* big, int T,
                                                                    uint32_t* __restrict__ tile_ids,
@@ -1015,7 +1008,7 @@ __global__ __launch_bounds__(256) HGS_SORT_OCC void tile_depth_sort_wave_kernel(
                                                                    uint32_t* __restrict__ scratch_k2) {
   tile_depth_sort_wave_body<false>(ranges, depths, vals, big, T, tile_ids, scratch_k, scratch_v, scratch_k2);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HGS_SORT_QUAD_WPE, HGS_SORT_QUAD_WPE))) void
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kSortQuadWaves, kSortQuadWaves))) void
 tile_depth_sort_quad_kernel(const uint32_t* __restrict__ ranges, const float* __restrict__ depths,
                             uint32_t* __restrict__ vals, uint32_t* big, int T, uint32_t* __restrict__ tile_ids,
                             uint32_t* __restrict__ scratch_k, uint32_t* __restrict__ scratch_v,
@@ -1166,9 +1159,7 @@ int launch_tile_depth_sort(const hgs_raster_args& a, const GeomWs& g, const BinW
   // scratch: keys_in / vals_in and the radix sort's alternate key buffer are free once the tile sort is done
   const bool quad = (uint64_t)L > (uint64_t)T * 512u;
   auto kern = quad ? tile_depth_sort_quad_kernel : tile_depth_sort_wave_kernel<false>;
-  static const char* dyn_env = getenv("HGS_SORT_DYN_LDS");      // tuning aid, as HGS_K6_DYN_LDS (render.hip)
-  static const size_t dyn = dyn_env ? (size_t)atoi(dyn_env) : 0;
-  hipLaunchKernelGGL(kern, dim3((T + 3) / 4), dim3(256), dyn, s, b.ranges, g.depths, b.vals_out, b.big_tiles, T,
+  hipLaunchKernelGGL(kern, dim3((T + 3) / 4), dim3(256), 0, s, b.ranges, g.depths, b.vals_out, b.big_tiles, T,
                      fill_tile_ids ? b.keys_out : nullptr, b.keys_in, b.vals_in, reinterpret_cast<uint32_t*>(b.sort_tmp));
   HGS_LAUNCH_CHECK("tile_depth_sort_wave", s, a.debug);
   static const bool dbg = getenv("HGS_SORT_DEBUG") != nullptr;       // diagnostic: tiles the sample sort handed to the network

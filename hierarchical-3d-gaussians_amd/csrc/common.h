@@ -193,13 +193,9 @@ bool scan_split_forced();
 // ---- stage launchers (each returns an HGS_* code) ----------------------------
 // super (optional): zeroed superblock totals (super_block_acquire): K1 adds its workgroup sums to them, g.block_sums /
 // g.block_band keep the RAW sums, no scan launch follows and K3 builds its prefixes itself (preprocess.hip, binning.hip)
-// geometry_only (preprocess_fwd_splits(a) only): everything but the colour; launch_preprocess_color completes the records
-// (colour, clamp bits of g.flags, Jacobian rows) -- on another stream, next to the binning, any time before K6
 // heavy_thr (with super): workgroups whose instance sum exceeds it are filed into the heavy list (0: none)
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s,
-                          uint32_t* super = nullptr, bool geometry_only = false, uint32_t heavy_thr = 0);
-bool preprocess_fwd_splits(const hgs_raster_args& a);
-int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream_t s);
+                          uint32_t* super = nullptr, uint32_t heavy_thr = 0);
 // Superblocks of K1's workgroup sums: kSuper consecutive workgroups; the library-owned block holds (1 + kBands) rows of
 // kMaxSuper totals per (device, stream) and one row of the superblocks' largest workgroup sums.  acquire: nullptr = take the scan launch (more than kMaxSuper superblocks is
 // the caller's check).  mark_dirty: an error return left totals behind, zero them before the next use.

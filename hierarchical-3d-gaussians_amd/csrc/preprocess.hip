@@ -269,52 +269,17 @@ __device__ __forceinline__ void load_sh_lod(const hgs_raster_args& a, int idx, f
 }
 
 
-// ---- M = 16, plain [P, 16, 3] layout: the coefficient block in two HALVES, straight into LDS ------------------------
+// ---- M = 16, plain [P, 16, 3] layout: the coefficient block straight into LDS ----------------------------------------------
 // K1 at M = 16 used to stage the workgroup's whole block (256 rows x 52 floats = 53 KB) through LDS and to hold its
 // twelve 16-byte loads per lane in registers across the double-precision chain: 53 KB and 144 registers both capped the
-// kernel at 3 waves per SIMD, and it is bound by latency, not by its arithmetic or by HBM.  Here a row travels as two
-// halves of 8 coefficients (96 bytes): `global_load_lds_dwordx4` writes them into LDS without passing through registers
-// (nothing to hold across the chain), the image of a half is 24 KB per workgroup (five workgroups per compute unit),
-// half 1 is fetched while half 0 is being evaluated (its cache lines are the ones half 0 just brought in), and with an
-// active degree below 2 it is not fetched at all.
-//   LDS image of one half: row r = 6 chunks of 16 bytes at r * 96, UNPADDED (the DMA's destination is the wave's base +
-//   16 * lane: no room for pad).  A ds_read_b128 of the same chunk by 16 consecutive-ish rows would hit every bank group
-//   twice (96 r mod 256 takes 8 values); row r therefore keeps chunk c in slot (c + f(r)) mod 6, f(r) = bit 3 of r --
-//   the rows of one lane group then cover all 16 bank groups.  The swizzle is applied on the SOURCE address of the DMA
-//   and on the read, never on the destination (cdna_hip_programming.md rule 21).
-constexpr int kHalfChunks = 6;                       // 16-byte chunks per half row (8 coefficients x 3 channels)
-constexpr int kHalfBytes = kPreBlock * kHalfChunks * 16;
+// kernel at 3 waves per SIMD.  `global_load_lds_dwordx4` writes the rows into LDS without passing through registers
+// (nothing to hold across the chain); the image is UNPADDED (the DMA's destination is the wave's base + 16 * lane: no
+// room for pad), so the bank swizzle is applied on the SOURCE address of the DMA and on the read, never on the
+// destination (cdna_hip_programming.md rule 21).  (Round 5 also built the block as two half rows -- every line requested
+// twice -- and as two row groups, and K1 as a geometry kernel + a colour kernel on a second stream: all measured slower,
+// profiles/r05_k1_layouts.txt, r05_k1_split_ab.txt; removed in round 6.)
 typedef const void __attribute__((address_space(1))) * gptr_t;
 typedef void __attribute__((address_space(3))) * lptr_t;
-
-template <int HALF>
-__device__ __forceinline__ void sh48_issue_half(const float* __restrict__ shs, int block_first, int P, float* lds) {
-  const int count = min(kPreBlock, P - block_first);
-  const char* src = reinterpret_cast<const char*>(shs + (size_t)block_first * 48) + HALF * 96;
-  const int wave_base = (int)(threadIdx.x & ~63u);
-#pragma unroll
-  for (int k = 0; k < kHalfChunks; ++k) {
-    const int slot = k * kPreBlock + (int)threadIdx.x;          // linear 16-byte slot of the LDS image
-    const int row = slot / kHalfChunks, cs = slot - row * kHalfChunks;
-    int c = cs - ((row >> 3) & 1);                               // the logical chunk this slot keeps
-    c = c < 0 ? c + kHalfChunks : c;
-    char* dst = reinterpret_cast<char*>(lds) + (size_t)(k * kPreBlock + wave_base) * 16;   // wave-uniform
-    if (row < count)
-      __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * 192 + c * 16), (lptr_t)dst, 16, 0, 0);
-  }
-}
-// this lane's half row, logical chunks [C0, C0 + 3): 12 floats = 4 coefficients
-template <int C0>
-__device__ __forceinline__ void sh48_read_quarter(const float* lds, float v[12]) {
-  const int row = threadIdx.x, f = (row >> 3) & 1;
-  const float* base = lds + row * 24 + f * 4;
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const float4 t = (C0 + c < 5) ? *reinterpret_cast<const float4*>(base + (C0 + c) * 4)
-                                  : *reinterpret_cast<const float4*>(lds + row * 24 + (f ? 0 : 20));
-    v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
-  }
-}
 
 // rgb and (JAC) d(rgb)/d(direction) sums over the four coefficients [K0, K0 + 4); same order of additions as the
 // one-block loop (k ascending), so the two routes give the same bits
@@ -348,16 +313,6 @@ __device__ __forceinline__ void sh48_accumulate4(int deg, float dx, float dy, fl
     }
   }
 }
-// one half (coefficients [8 HALF, 8 HALF + 8)) of this lane's row out of the LDS image, in two pieces of four
-template <bool JAC, int HALF>
-__device__ __forceinline__ void sh48_half_from_lds(const float* lds, bool vis, int deg, float dx, float dy, float dz,
-                                                   float rgb[3], float J[9]) {
-  float sh[12];
-  sh48_read_quarter<0>(lds, sh);
-  if (vis) sh48_accumulate4<JAC, HALF * 8>(deg, dx, dy, dz, sh, rgb, J);
-  sh48_read_quarter<3>(lds, sh);
-  if (vis) sh48_accumulate4<JAC, HALF * 8 + 4>(deg, dx, dy, dz, sh, rgb, J);
-}
 // the same from global memory (mostly-culled workgroups: visible lanes only), 48 bytes at a time
 template <bool JAC>
 __device__ __forceinline__ void sh48_row_from_global(const float* __restrict__ shs, int idx, int deg, float dx, float dy,
@@ -377,40 +332,25 @@ __device__ __forceinline__ void sh48_row_from_global(const float* __restrict__ s
 #undef HGS_SH48_Q
 }
 
-// ---- the same block as whole ROWS, in row groups (HGS_K1_LAYOUT) ----------------------------------------------------------
-// The half-row image above fetches a Gaussian's 192 bytes as two 96-byte pieces, a double-precision chain apart: every
-// 128-byte line of the block is requested twice, and the counters say the second request is not served on chip (K1's
-// FETCH_SIZE 174 MB against 115 MB of the round-4 kernel that loaded the block with consecutive 16-byte loads,
-// profiles/r05_final_pmc.json).  Layout 1 keeps the 24 KB image but fills it with the WHOLE rows of half the
-// workgroup's Gaussians at a time -- rows 0 .. 127 while all four waves run the chain, evaluated by waves 0 and 1; then
-// rows 128 .. 255 for waves 2 and 3 -- so that every line is requested once, by one DMA burst.  Layout 2: all 256 rows at
-// once (48 KB: three workgroups per compute unit).  A row = 12 chunks of 16 bytes at row * 192, unpadded; row r keeps chunk
-// c in slot (c + f(r)) mod 12, f(r) = bits 2..3 of r: the 16 rows of a ds_read_b128 lane group then cover all 16 bank
-// groups (192 r mod 256 takes four values).  Only the chunks the active degree needs are fetched.
-// Measured on one box (profiles/r05_k1_layouts.txt, metric configuration, K1 in the frame): half rows 96.4 us, two row
-// groups 92.4 us (FETCH_SIZE back at 115 MB), all rows at once 88.9 us -- one DMA burst, one barrier, every wave busy in
-// the one evaluation phase; three workgroups per compute unit are enough because the DMA keeps 48 KB per workgroup in
-// flight without a register.  Default: 2.
-#ifndef HGS_K1_LAYOUT
-#define HGS_K1_LAYOUT 2
-#endif
-constexpr int kK1Groups = HGS_K1_LAYOUT == 1 ? 2 : 1;
-constexpr int kK1GroupRows = kPreBlock / kK1Groups;
-constexpr int kK1ImageBytes = HGS_K1_LAYOUT == 0 ? kHalfBytes : kK1GroupRows * 192;
+// All 256 rows at once (48 KB: three workgroups per compute unit -- enough, because the DMA keeps 48 KB per workgroup in
+// flight without a register).  A row = 12 chunks of 16 bytes at row * 192; row r keeps chunk c in slot (c + f(r)) mod 12,
+// f(r) = bits 2..3 of r: the 16 rows of a ds_read_b128 lane group then cover all 16 bank groups (192 r mod 256 takes four
+// values).  Only the chunks the active degree needs are fetched.
+constexpr int kK1ImageBytes = kPreBlock * 192;
 
-__device__ __forceinline__ void sh48_issue_rows(const float* __restrict__ shs, int block_first, int P, int group,
-                                                int nchunks, float* lds) {
+__device__ __forceinline__ void sh48_issue_rows(const float* __restrict__ shs, int block_first, int P, int nchunks,
+                                                float* lds) {
   const int count = min(kPreBlock, P - block_first);
   const char* src = reinterpret_cast<const char*>(shs + (size_t)block_first * 48);
   const int wave_base = (int)(threadIdx.x & ~63u);
-  constexpr int kPer = kK1GroupRows * 12 / kPreBlock;          // DMA instructions per lane and group: 6 or 12
+  constexpr int kPer = 12;                                      // DMA instructions per lane
 #pragma unroll
   for (int k = 0; k < kPer; ++k) {
     const int slot = k * kPreBlock + (int)threadIdx.x;          // linear 16-byte slot of the LDS image
     const int row_l = slot / 12, cs = slot - row_l * 12;
     int c = cs - ((row_l >> 2) & 3);                             // the logical chunk this slot keeps
     c = c < 0 ? c + 12 : c;
-    const int row = group * kK1GroupRows + row_l;
+    const int row = row_l;
     char* dst = reinterpret_cast<char*>(lds) + (size_t)(k * kPreBlock + wave_base) * 16;   // wave-uniform
     if (row < count && c < nchunks)
       __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)row * 192 + c * 16), (lptr_t)dst, 16, 0, 0);
@@ -544,22 +484,11 @@ __device__ __forceinline__ void k1_continuous(const hgs_raster_args& a, const Ca
   o.invz = (float)pd.itz;
 }
 
-// Tuning aid (scripts/diag_k1_anatomy.py; never defined in the product build): HGS_K1X = bit mask of parts of the
-// half-row K1 to leave out -- 1 record store, 2 Jacobian store, 4 SH block (no DMA, no LDS reads), 8 double-precision
-// chain, 16 the 4- and 8-byte arrays -- to see what each costs.
-#ifdef HGS_K1X
-#define K1X(bit) (((HGS_K1X) & (bit)) != 0)
-#else
-#define K1X(bit) false
-#endif
-// How the half-row K1 stores its 64-byte records and 48-byte Jacobian rows: 1 = through the wave's own part of the LDS
-// image (free once the wave has read its last half row; a lane's row of NV 16-byte pieces goes to LDS as it will lie in
-// memory, then every store instruction of the wave writes 1 KB of consecutive bytes), 0 = straight from the lane (NV
-// instructions that each touch 64 different cache lines: a row-per-lane store pattern is bound by the rate at which
-// the memory pipeline takes partial lines, not by bandwidth).
-#ifndef HGS_K1_COALESCED_STORES
-#define HGS_K1_COALESCED_STORES 1
-#endif
+// How the M = 16 K1 stores its 64-byte records and 48-byte Jacobian rows: through the wave's own part of the LDS image
+// (free once the wave has read its rows; a lane's row of NV 16-byte pieces goes to LDS as it will lie in memory, then
+// every store instruction of the wave writes 1 KB of consecutive bytes).  Straight from the lane -- NV instructions
+// that each touch 64 different cache lines -- a row-per-lane store pattern is bound by the rate at which the memory
+// pipeline takes partial lines, not by bandwidth (8 us more; what each part of K1 costs: profiles/r05_k1_anatomy.txt).
 // v[NV] of lane l = the NV consecutive float4 of row (row0 + l) of a [rows, NV] float4 array at dst; rows whose bit in
 // `mask` is clear are not written.  wave_lds: >= 64 * NV * 16 bytes private to the calling wave.
 template <int NV>
@@ -582,18 +511,15 @@ __device__ __forceinline__ void wave_store_rows(float4* __restrict__ dst, size_t
   __builtin_amdgcn_wave_barrier();               // (the next use of wave_lds overwrites it)
 }
 
-template <bool JAC, bool LOD, bool DEFER, bool H48, bool GEOM_ONLY = false>
+template <bool JAC, bool LOD, bool DEFER, bool H48>
                                 // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
                                 // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
                                 // ahead of the double-precision chain (their own instantiations: the extra state
-                                // would cost every other caller of K1 its occupancy); H48: plain [P, 16, 3] block in
-                                // two halves straight into LDS (above; DEFER and LOD do not apply); GEOM_ONLY (with
-                                // H48): everything but the colour -- the record's colour slots are left zero and
-                                // preprocess_color_h48_kernel (below) fills them in, concurrently with the binning
+                                // would cost every other caller of K1 its occupancy); H48: plain [P, 16, 3] block
+                                // straight into LDS by DMA (above; DEFER and LOD do not apply)
 __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, const GeomWs& g,
                                                     int32_t* __restrict__ radii, uint32_t* __restrict__ super, uint32_t heavy_thr) {
-  static_assert(!(H48 && (LOD || DEFER)), "the half-row route is the plain layout's");
-  static_assert(!GEOM_ONLY || (H48 && !JAC), "the geometry-only kernel is the half-row route's first part");
+  static_assert(!(H48 && (LOD || DEFER)), "the DMA route is the plain layout's");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* lds_sh = reinterpret_cast<float*>(smem_raw);
   __shared__ uint32_t wave_tot[kPreBlock / 64];
@@ -654,7 +580,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   // SH coefficients: stream the workgroup's block through LDS when most of it is visible (coalesced),
   // fall back to per-lane loads (visible lanes only) when most of the block is culled.
   bool coop = false, deferred = false;
-  const bool sh_lds = !GEOM_ONLY && a.shs && (shn & 3) == 0;
+  const bool sh_lds = a.shs && (shn & 3) == 0;
   const int nvis = __syncthreads_count(pr.visible);        // (also orders wave_tot / band_cnt)
   if (threadIdx.x < 64) {                                  // (wave 0) raw sums; with `super` also into the superblock totals
     uint32_t mine = 0;
@@ -685,11 +611,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
     coop = nvis * 2 >= kPreBlock;
     if (coop) {
       if constexpr (H48) {
-#if HGS_K1_LAYOUT == 0
-        if (!K1X(4)) sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
-#else
-        if (!K1X(4)) sh48_issue_rows(a.shs, blockIdx.x * kPreBlock, a.P, 0, ((a.sh_degree + 1) * (a.sh_degree + 1) * 3 + 3) / 4, lds_sh);
-#endif
+        sh48_issue_rows(a.shs, blockIdx.x * kPreBlock, a.P, ((a.sh_degree + 1) * (a.sh_degree + 1) * 3 + 3) / 4, lds_sh);
       } else if (lod) {
         coop_gather_sh(a.shs, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
       } else if (a.shs_rest) {
@@ -718,13 +640,12 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       if (a.interpolation_weights && a.num_node_kids && !a.lod_per_pixel)     // (per pixel: the compositing kernels remap alpha)
         opac = lod_opacity(opac, a.interpolation_weights[idx], a.num_node_kids[idx], nullptr);
     }
-    if (!K1X(8)) k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
-    else { rec.opac = opac; rec.gx_hi = pr.px; rec.gy_hi = pr.py; rec.A2 = pr.conA; rec.B2 = pr.conB; rec.C2 = pr.conC; rec.invz = pr.tz; }
+    k1_continuous(a, cam, pr, p, sc_act, q_act, opac, rec);
   }
   if constexpr (DEFER) {
     if (deferred) coop_commit_sh(shreg, blockIdx.x * kPreBlock, a.P, shn, lds_sh);
   }
-  if constexpr (H48) {      // the DMA of half 0 has landed before any wave passes the barrier
+  if constexpr (H48) {      // the DMA has landed before any wave passes the barrier
     if (coop) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   if (coop) __syncthreads();
@@ -732,38 +653,13 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   float rgb[3] = {0.f, 0.f, 0.f};
   const bool vis = idx < a.P && pr.visible;
   float J[JAC ? 9 : 1];
-  if constexpr (GEOM_ONLY) {
-    // (colour, clamp flags and Jacobian: preprocess_color_h48_kernel)
-  } else if constexpr (H48) {     // (launched with a.shs only)
+  if constexpr (H48) {     // (launched with a.shs only)
     float dx, dy, dz;
     unit_dir(p, cam.cam, dx, dy, dz);
     float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (coop && !K1X(4)) {
-#if HGS_K1_LAYOUT == 0
-      // (the barrier above waited for the DMA of half 0)
-      const bool second = a.sh_degree > 1;               // coefficients 8 .. 15 belong to degrees 2 and 3
-      sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-      if (second) {
-        __syncthreads();                                 // every lane has read its half 0: the image may be replaced
-        sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-      }
-#else
-      // (the barrier above waited for the DMA of row group 0)
-      const int my_group = (int)threadIdx.x / kK1GroupRows, row_l = (int)threadIdx.x - my_group * kK1GroupRows;
-      if (my_group == 0) sh48_row_from_lds<JAC>(lds_sh, row_l, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-      if (kK1Groups > 1) {
-        __syncthreads();                                 // group 0's rows are in registers: the image may be replaced
-        sh48_issue_rows(a.shs, blockIdx.x * kPreBlock, a.P, 1, ((a.sh_degree + 1) * (a.sh_degree + 1) * 3 + 3) / 4, lds_sh);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (my_group == 1) sh48_row_from_lds<JAC>(lds_sh, row_l, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-        __syncthreads();                                 // (the store staging below takes the image over)
-      }
-#endif
-    } else if (vis && !K1X(4)) {
+    if (coop) {                                          // (the barrier above waited for the DMA)
+      sh48_row_from_lds<JAC>(lds_sh, (int)threadIdx.x, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
+    } else if (vis) {
       sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, Jt);
     }
     if constexpr (JAC) {
@@ -815,57 +711,46 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
   // ---- the record and the per-Gaussian arrays ----------------------------------------------------------------------------
   const uint32_t rectbits = (uint32_t)pr.minx | ((uint32_t)pr.miny << 10) | ((uint32_t)(pr.maxx - pr.minx) << 20);
   bool rows_stored = false;
-  if constexpr (H48 && HGS_K1_COALESCED_STORES) {
-    if ((GEOM_ONLY || coop) && !K1X(4)) {  // (uniform; the wave's own part of the image -- or, after the last barrier of
-                                           // the row groups, anybody's -- is free by now)
+  if constexpr (H48) {
+    if (coop) {                            // (uniform; the wave's own part of the image is free by now)
       rows_stored = true;
       float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) +
-                                             (threadIdx.x >> 6) * ((GEOM_ONLY ? kHalfBytes : kK1ImageBytes) / (kPreBlock / 64)));
+                                             (threadIdx.x >> 6) * (kK1ImageBytes / (kPreBlock / 64)));
       const unsigned long long vmask = __ballot(vis);
       const size_t row0 = (size_t)blockIdx.x * kPreBlock + (threadIdx.x & ~63u);
-      if (!K1X(1)) {
-        const float4 r4[4] = {make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2), make_float4(rec.C2, rec.opac, rgb[0], rgb[1]),
-                              make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits)),
-                              make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y)};
-        wave_store_rows<4>(reinterpret_cast<float4*>(g.records), row0, r4, vmask, wl);
-      }
+      const float4 r4[4] = {make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2), make_float4(rec.C2, rec.opac, rgb[0], rgb[1]),
+                            make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits)),
+                            make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y)};
+      wave_store_rows<4>(reinterpret_cast<float4*>(g.records), row0, r4, vmask, wl);
       if constexpr (JAC) {
-        if (!K1X(2)) {
-          const float4 j4[3] = {make_float4(J[0], J[1], J[2], J[3]), make_float4(J[4], J[5], J[6], J[7]),
-                                make_float4(J[8], 0.f, 0.f, 0.f)};
-          wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), row0, j4, vmask, wl);
-        }
+        const float4 j4[3] = {make_float4(J[0], J[1], J[2], J[3]), make_float4(J[4], J[5], J[6], J[7]),
+                              make_float4(J[8], 0.f, 0.f, 0.f)};
+        wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), row0, j4, vmask, wl);
       }
     }
   }
   if (idx < a.P) {
     if (pr.visible && !rows_stored) {
-      if (!K1X(1)) {
-        float4* recp = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
-        recp[0] = make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2);
-        recp[1] = make_float4(rec.C2, rec.opac, rgb[0], rgb[1]);
-        recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
-        recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
-      }
+      float4* recp = reinterpret_cast<float4*>(g.records) + (size_t)idx * kRecVec;
+      recp[0] = make_float4(rec.gx_hi, rec.gy_hi, rec.A2, rec.B2);
+      recp[1] = make_float4(rec.C2, rec.opac, rgb[0], rgb[1]);
+      recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
+      recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
       if constexpr (H48 && JAC) {
-        if (!K1X(2)) {
-          float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-          jd[0] = make_float4(J[0], J[1], J[2], J[3]);
-          jd[1] = make_float4(J[4], J[5], J[6], J[7]);
-          jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
-        }
+        float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
+        jd[0] = make_float4(J[0], J[1], J[2], J[3]);
+        jd[1] = make_float4(J[4], J[5], J[6], J[7]);
+        jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
       }
     }
-    if (!K1X(16)) {
-      // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
-      reinterpret_cast<uint2*>(g.rects)[idx] =
-          pr.visible ? make_uint2((uint32_t)pr.minx | ((uint32_t)pr.miny << 16), (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16))
-                     : make_uint2(0u, 0u);
-      radii[idx] = rad;
-      g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
-      g.tiles_touched[idx] = touched;
-      g.flags[idx] = flags;
-    }
+    // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
+    reinterpret_cast<uint2*>(g.rects)[idx] =
+        pr.visible ? make_uint2((uint32_t)pr.minx | ((uint32_t)pr.miny << 16), (uint32_t)pr.maxx | ((uint32_t)pr.maxy << 16))
+                   : make_uint2(0u, 0u);
+    radii[idx] = rad;
+    g.depths[idx] = pr.tz;            // every Gaussian: the depth sort runs over all P keys
+    g.tiles_touched[idx] = touched;
+    g.flags[idx] = flags;
   }
 }
 
@@ -874,91 +759,13 @@ __global__ __launch_bounds__(kPreBlock) void preprocess_fwd_kernel(hgs_raster_ar
                                                                    int32_t* __restrict__ radii, uint32_t* __restrict__ super, uint32_t heavy_thr) {
   preprocess_fwd_body<JAC, LOD, DEFER, false>(a, g, radii, super, heavy_thr);
 }
-// The half-row route: 24 KB of LDS per workgroup allow five workgroups per compute unit; the registers are held to what
-// HGS_K1_H48_WAVES waves per SIMD leave (128 at 4).
-#ifndef HGS_K1_H48_WAVES
-#define HGS_K1_H48_WAVES 4
-#endif
+// The M = 16 DMA route: 48 KB of LDS per workgroup (three workgroups per compute unit), the registers held to what four
+// waves per SIMD leave (128).
 template <bool JAC>
-__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_fwd_h48_kernel(hgs_raster_args a, GeomWs g,
-                                                                                         int32_t* __restrict__ radii,
-                                                                                         uint32_t* __restrict__ super, uint32_t heavy_thr) {
+__global__ __launch_bounds__(kPreBlock, 4) void preprocess_fwd_h48_kernel(hgs_raster_args a, GeomWs g,
+                                                                          int32_t* __restrict__ radii,
+                                                                          uint32_t* __restrict__ super, uint32_t heavy_thr) {
   preprocess_fwd_body<JAC, false, false, true>(a, g, radii, super, heavy_thr);
-}
-
-// ---- K1 in two kernels (M = 16, plain layout, single-call forward) -------------------------------------------------------
-// The binning that follows K1 (K3, the counting partition, the per-tile depth sort: ~110 us of small, latency-bound
-// kernels at the metric configuration) needs K1's RECTANGLES AND DEPTHS, not its colours; the colours are first read by
-// K6.  And the colour part of K1 is its bandwidth: 192 of the 236 bytes it reads per Gaussian and the 48-byte Jacobian row
-// (profiles/r05_k1_anatomy.txt: 30 + 13 of its 80 us).  So the half-row route is split:
-//   preprocess_geom_h48_kernel   on the caller's stream: everything but the colour (44 bytes in per Gaussian); the
-//                                record's three colour floats are left zero;
-//   preprocess_color_h48_kernel  on a second stream of the library, started when the first has finished, running NEXT TO
-//                                the binning kernels: SH block (two halves by LDS DMA), colour into bytes 24..35 of the
-//                                record, the clamp bits into the flags word, the Jacobian row;
-// and K6 waits for the second (abi.cpp).  The frame's critical path loses what the colour kernel takes (~50 us).
-template <bool JAC>
-__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_color_h48_kernel(hgs_raster_args a, GeomWs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* lds_sh = reinterpret_cast<float*>(smem_raw);
-  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
-  // every ordinary load up here (see the fused kernel): visibility, the mean, the flags word the clamp bits go into
-  const bool vis = idx < a.P && g.tiles_touched[idx] != 0u;
-  float p[3] = {0.f, 0.f, 1.f};
-  uint32_t flags = 0;
-  if (idx < a.P) {
-    p[0] = a.means3D[(size_t)idx * 3 + 0]; p[1] = a.means3D[(size_t)idx * 3 + 1]; p[2] = a.means3D[(size_t)idx * 3 + 2];
-    flags = g.flags[idx];
-  }
-  const float cam[3] = {a.campos[0], a.campos[1], a.campos[2]};
-  const bool coop = __syncthreads_count(vis) * 2 >= kPreBlock;
-  if (coop) sh48_issue_half<0>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
-  float dx, dy, dz;
-  unit_dir(p, cam, dx, dy, dz);
-  float rgb[3] = {0.f, 0.f, 0.f};
-  float Jt[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (coop) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the DMA of half 0 has landed before any wave passes the barrier
-    __syncthreads();
-    const bool second = a.sh_degree > 1;                 // coefficients 8 .. 15 belong to degrees 2 and 3
-    sh48_half_from_lds<JAC, 0>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-    if (second) {
-      __syncthreads();                                   // every lane has read its half 0: the image may be replaced
-      sh48_issue_half<1>(a.shs, blockIdx.x * kPreBlock, a.P, lds_sh);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      sh48_half_from_lds<JAC, 1>(lds_sh, vis, a.sh_degree, dx, dy, dz, rgb, Jt);
-    }
-  } else if (vis) {
-    sh48_row_from_global<JAC>(a.shs, idx, a.sh_degree, dx, dy, dz, rgb, Jt);
-  }
-  if (vis) {
-    uint32_t cbits = 0;
-    rgb[0] += 0.5f; rgb[1] += 0.5f; rgb[2] += 0.5f;
-    if (rgb[0] < 0.f) { rgb[0] = 0.f; cbits |= 1u; }
-    if (rgb[1] < 0.f) { rgb[1] = 0.f; cbits |= 2u; }
-    if (rgb[2] < 0.f) { rgb[2] = 0.f; cbits |= 4u; }
-    if (cbits) g.flags[idx] = flags | cbits;
-    float* rp = g.records + (size_t)idx * kRecFloats + 6;        // q1.z, q1.w, q2.x
-    rp[0] = rgb[0]; rp[1] = rgb[1]; rp[2] = rgb[2];
-  }
-  if constexpr (JAC) {
-    const float4 j4[3] = {make_float4(Jt[0], Jt[1], Jt[2], Jt[3]), make_float4(Jt[4], Jt[5], Jt[6], Jt[7]),
-                          make_float4(Jt[8], 0.f, 0.f, 0.f)};
-    if (coop && HGS_K1_COALESCED_STORES) {               // (uniform; the wave's own 6 KB of the image, see the fused kernel)
-      float4* wl = reinterpret_cast<float4*>(reinterpret_cast<char*>(lds_sh) + (threadIdx.x >> 6) * (kHalfBytes / (kPreBlock / 64)));
-      wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), (size_t)blockIdx.x * kPreBlock + (threadIdx.x & ~63u), j4,
-                         __ballot(vis), wl);
-    } else if (vis) {
-      float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-      jd[0] = j4[0]; jd[1] = j4[1]; jd[2] = j4[2];
-    }
-  }
-}
-__global__ __launch_bounds__(kPreBlock, HGS_K1_H48_WAVES) void preprocess_geom_h48_kernel(hgs_raster_args a, GeomWs g,
-                                                                                          int32_t* __restrict__ radii,
-                                                                                          uint32_t* __restrict__ super, uint32_t heavy_thr) {
-  preprocess_fwd_body<false, false, false, true, true>(a, g, radii, super, heavy_thr);
 }
 
 // Exclusive scan of the per-workgroup sums (nblk = P/256): grid row 0 scans block_sums, rows 1..kBands the columns of
@@ -1120,16 +927,8 @@ __global__ __launch_bounds__(kPreBlock) void k8_presum_work_kernel(const uint2* 
   }
 }
 
-#ifndef HGS_K8_STAGE
-#define HGS_K8_STAGE 1     // 0: every lane walks its run of instance records in global memory (round 3; kept for A/B runs)
-#endif
-#ifdef HGS_K8_WPE            // tuning aid: cap the registers so that HGS_K8_WPE waves fit a SIMD (160 registers = 3 today)
-#define HGS_K8_OCC __attribute__((amdgpu_waves_per_eu(HGS_K8_WPE, HGS_K8_WPE)))
-#else
-#define HGS_K8_OCC
-#endif
 template <bool ACC, bool LOD>   // ACC: add into the gradient buffers (accumulation over the views of one optimizer step)
-__global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
+__global__ __launch_bounds__(kPreBlock) void preprocess_bwd_kernel(hgs_raster_args a, GeomWs g,
                                                                    const float* __restrict__ inst,
                                                                    float* __restrict__ drgb,
                                                                    float* __restrict__ dmean_rows,
@@ -1161,7 +960,6 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long long_mask = presummed ? __ballot(n > kK8LongRun) : 0ull;
     if (long_mask == 0ull) {
-#if HGS_K8_STAGE
       uint32_t incl = n;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -1207,17 +1005,6 @@ __global__ __launch_bounds__(kPreBlock) HGS_K8_OCC void preprocess_bwd_kernel(hg
           __builtin_amdgcn_wave_barrier();                               // (the next pass overwrites the stage)
         }
       }
-#else
-      if (n) {
-        const float2* ip = reinterpret_cast<const float2*>(inst) + (size_t)g.offsets[idx] * 5;
-        for (uint32_t k = 0; k < n; ++k) {
-          const float2 v0 = ip[k * 5 + 0], v1 = ip[k * 5 + 1], v2 = ip[k * 5 + 2], v3 = ip[k * 5 + 3], v4 = ip[k * 5 + 4];
-          s[0] += v0.x; s[1] += v0.y; s[2] += v1.x; s[3] += v1.y;
-          s[4] += v2.x; s[5] += v2.y; s[6] += v3.x; s[7] += v3.y;
-          s[8] += v4.x; s[9] += v4.y;
-        }
-      }
-#endif
     } else if (n != 0u) {
       const size_t off = (size_t)g.offsets[idx];
       if (n > kK8LongRun) {
@@ -1977,47 +1764,21 @@ void super_block_mark_dirty(const uint32_t* words) {
     if (g_sync[i].words == words) g_sync[i].dirty = true;
 }
 
-// Measured (profiles/r05_k1_split_ab.txt, metric configuration): geometry kernel 52 us, but next to the colour kernel the
-// binning kernels -- bound by memory LATENCY -- take twice their time (K3 28 -> 49 us, counting + scatter 42 -> 75 us) and
-// the colour kernel itself 90 us: 1 250 frames/s against 1 316 with the fused kernel.  A streaming kernel does not hide
-// under latency-bound ones, it loads the memory system they wait for.  The split therefore stays OFF unless HGS_K1_SPLIT
-// is set (kept for configurations whose binning is short against K1: very large P at small resolutions).
-bool preprocess_fwd_splits(const hgs_raster_args& a) {
-  static const bool split = getenv("HGS_K1_SPLIT") != nullptr;
-  return split && a.P > 0 && a.shs && !a.shs_rest && !a.lod_render_indices && a.M == 16;
-}
-
 int launch_preprocess_fwd(const hgs_raster_args& a, const GeomWs& g, int32_t* radii, hipStream_t s, uint32_t* super,
-                          bool geometry_only, uint32_t heavy_thr) {
+                          uint32_t heavy_thr) {
   const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
   if (nblk > 0) {
     const bool jac = a.prepare_backward && a.shs;
     const bool plain = a.shs && !a.shs_rest && !a.lod_render_indices && ((a.M * 3) & 3) == 0;
     const bool h48 = plain && a.M == 16;
     const bool defer = plain && !h48;
-    if (geometry_only && !h48) { set_error("launch_preprocess_fwd: the geometry-only kernel needs the plain M = 16 layout"); return HGS_ERR_INVALID; }
-    const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)(geometry_only ? kHalfBytes : kK1ImageBytes)
-                                              : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
-    if (geometry_only) {
-      hipLaunchKernelGGL(preprocess_geom_h48_kernel, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super, heavy_thr);
-    } else {
-      auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
-                : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
-                : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
-                        : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
-      hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super, heavy_thr);
-    }
+    const size_t lds_bytes = !a.shs ? 0 : h48 ? (size_t)kK1ImageBytes : (size_t)kPreBlock * (a.M * 3 + 4) * sizeof(float);
+    auto k1 = a.lod_render_indices ? (jac ? preprocess_fwd_kernel<true, true, false> : preprocess_fwd_kernel<false, true, false>)
+              : h48   ? (jac ? preprocess_fwd_h48_kernel<true> : preprocess_fwd_h48_kernel<false>)
+              : defer ? (jac ? preprocess_fwd_kernel<true, false, true> : preprocess_fwd_kernel<false, false, true>)
+                      : (jac ? preprocess_fwd_kernel<true, false, false> : preprocess_fwd_kernel<false, false, false>);
+    hipLaunchKernelGGL(k1, dim3(nblk), dim3(kPreBlock), lds_bytes, s, a, g, radii, super, heavy_thr);
     HGS_LAUNCH_CHECK("preprocess_fwd", s, a.debug);
-  }
-  return HGS_OK;
-}
-
-int launch_preprocess_color(const hgs_raster_args& a, const GeomWs& g, hipStream_t s) {
-  const int nblk = (a.P + kPreBlock - 1) / kPreBlock;
-  if (nblk > 0) {
-    auto k = (a.prepare_backward && a.shs) ? preprocess_color_h48_kernel<true> : preprocess_color_h48_kernel<false>;
-    hipLaunchKernelGGL(k, dim3(nblk), dim3(kPreBlock), (size_t)kHalfBytes, s, a, g);
-    HGS_LAUNCH_CHECK("preprocess_color", s, a.debug);
   }
   return HGS_OK;
 }

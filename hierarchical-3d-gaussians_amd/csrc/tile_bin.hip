@@ -29,17 +29,7 @@ namespace {
 
 constexpr int kTbThreads = 256;
 constexpr int kGroups = 8;
-#ifndef HGS_TB_BATCH
-#define HGS_TB_BATCH 16
-#endif
-#ifndef HGS_TB_STRICT
-#define HGS_TB_STRICT 0
-#endif
-#ifndef HGS_TB_STAGED
-#define HGS_TB_STAGED 1
-#endif
-constexpr bool kTbStaged = HGS_TB_STAGED != 0;   // 0: the scatter stores instance by instance (A/B runs)
-constexpr int kTbBatch = HGS_TB_BATCH;     // instances per lane whose loads are issued together (count and scatter)
+constexpr int kTbBatch = 16;               // instances per lane whose loads are issued together (count and scatter)
 constexpr int kMaxTiles = 32768;
 
 struct BandStream {
@@ -125,10 +115,10 @@ __global__ __launch_bounds__(kTbThreads) void tb_count_kernel(const uint32_t* __
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave: its row stores have left
   __syncthreads();
   if (threadIdx.x == 0) {
-    // (HGS_TB_STRICT: the arrival as a RELEASE in the language's memory model -- on gfx950 an L2 write-back in front of
-    // the atomic; the rows were stored write-through and drained above, which is what the hardware needs)
-    const uint32_t before = __hip_atomic_fetch_add(&arrive[band * kGroups + g], 1u,
-                                                   HGS_TB_STRICT ? __ATOMIC_ACQ_REL : __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed: the rows were stored write-through and drained above, which is what the hardware needs.  The arrival as
+    // an ACQ_REL in the language's memory model is an L2 write-back in front of the atomic on gfx950: +7 us on this
+    // 14 us kernel, measured in round 6 -- profiles/r06_notes.md)
+    const uint32_t before = __hip_atomic_fetch_add(&arrive[band * kGroups + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     completes_group = before == (uint32_t)(c1 - c0 - 1);
   }
   __syncthreads();
@@ -400,10 +390,7 @@ __global__ __launch_bounds__(kTbThreads) void tb_scatter_kernel(const uint32_t* 
   }
 }
 
-#ifndef HGS_TB_CHUNK
-#define HGS_TB_CHUNK 4096
-#endif
-inline uint32_t tb_chunk(int T) { return T <= 12288 ? (uint32_t)HGS_TB_CHUNK : 16384u; }
+inline uint32_t tb_chunk(int T) { return T <= 12288 ? 4096u : 16384u; }
 
 }  // namespace
 
@@ -440,7 +427,7 @@ int launch_tile_bin(const uint32_t* keys, const uint32_t* vals, uint32_t* vals_o
                      super ? (int)(super_block_bytes() / sizeof(uint32_t)) : 0);
   HGS_LAUNCH_CHECK("tile_bin_count", s, debug);
   // one batch per workgroup: the scatter groups its chunk by tile in LDS first (cursors + counts + 8 bytes per instance)
-  const bool staged = kTbStaged && chunk == (uint32_t)(kTbThreads * kTbBatch);
+  const bool staged = chunk == (uint32_t)(kTbThreads * kTbBatch);
   if (staged)
     hipLaunchKernelGGL(tb_scatter_kernel<true>, dim3(kBands * max_chunks + kBands), dim3(kTbThreads),
                        lds * 2 + (size_t)chunk * 8, s, keys, vals, L_cap, band_totals, col, per, chunk, max_chunks, T, Tp,

@@ -148,7 +148,7 @@ _last_L = {}
 SPECULATIVE = True
 SPEC_GROWTH = 1.25       # speculative instance capacity = SPEC_GROWTH * (previous L of this shape) + SPEC_SLACK
 SPEC_SLACK = 65536
-SPEC_DECAY = 0.97        # what the remembered count (per shape) / instances per row (per resolution) keeps of its maximum per call
+SPEC_DECAY = 0.99        # what the remembered count (per shape) / instances per row (per resolution) keeps of its maximum per call
 stats = {"speculative_calls": 0, "capacity_misses": 0, "last_L": 0}     # counters (bench.py reports them)
 
 

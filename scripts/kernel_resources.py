@@ -129,7 +129,6 @@ def occupancy(vgprs, agprs, lds_static, wg_threads, lds_dynamic=0):
 
 # dynamic LDS of the kernels that take it at launch (bytes per workgroup at the metric configuration: M = 16, 256 lanes)
 DYNAMIC_LDS = {"preprocess_fwd_kernel": 256 * (16 * 3 + 4) * 4, "preprocess_fwd_h48_kernel": 256 * 192,
-               "preprocess_geom_h48_kernel": 256 * 6 * 16, "preprocess_color_h48_kernel": 256 * 6 * 16,
                "sh_bwd_kernel": 256 * (16 * 3 + 4) * 4,
                # 1080p: two arrays over a band's 1 020 tiles + 8 bytes per instance of a 4 096-instance chunk (staged scatter)
                "tb_scatter_kernel": 2 * 1020 * 4 + 4096 * 8, "tb_scatter_kernel<false>": 1020 * 4, "tb_count_kernel": 1020 * 4}

@@ -21,7 +21,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STAGES = {           # bench.py stage -> substrings of the kernels it launches
     "render_bwd": ["render_bwd_quad"], "render_fwd": ["render_fwd_quad"],
-    "preprocess_fwd": ["preprocess_fwd", "preprocess_geom"], "preprocess_fwd_color": ["preprocess_color"],
+    "preprocess_fwd": ["preprocess_fwd"],
     "preprocess_bwd": ["preprocess_bwd", "sh_bwd"], "duplicate_keys": ["duplicate_tiles"],
     "tile_ranges": ["tile_ranges"],
     "tile_depth_sort": ["tile_depth_sort_wave", "tile_depth_sort_medium", "tile_depth_sort_big"],

@@ -185,12 +185,9 @@ def test_bench_byte_model_is_consistent():
     deferred = bench.algorithmic_bytes(P, P, L, N, T, M, k=k, deferred_sh=True)
     both = bench.algorithmic_bytes(P, P, L, N, T, M, k=k, deferred_sh=True, sh_forward=True)
     assert frame(both) < frame(deferred) < frame(base)
-    # (K1 is carried as its two kernels, geometry + colour; fold_k1 adds them up where the fused kernel ran)
-    k1 = lambda ab: bench.fold_k1(ab, {})["preprocess_fwd"]
-    assert k1(both) < k1(base) and "sh_colors_batched" in both and "preprocess_fwd_color" not in both
+    assert both["preprocess_fwd"] < base["preprocess_fwd"] and "sh_colors_batched" in both
     sb = bench.survey_bytes(P, P, L, N, T, M)
-    assert bench.fold_k1(sb, {})["preprocess_fwd"] == 44 * P + 12 * M * P + 4 * P + 40 * P
-    assert bench.fold_k1(sb, {"preprocess_fwd_color": 0.05}) == sb
+    assert sb["preprocess_fwd"] == 44 * P + 12 * M * P + 4 * P + 40 * P
 
 
 def test_source_stamp_ignores_comments_but_not_code():

@@ -249,16 +249,15 @@ def test_diagnostic_wait_and_count_routes_give_the_same_frame(gpu):
     """HGS_BLOCKING_WAIT (sleeping host waits instead of polling), HGS_COUNT_BY_COPY (the instance count by a copy
     command instead of a kernel's store into mapped host memory), HGS_SCAN_LAUNCH (the workgroup sums scanned by a launch
     between K1 and K3 -- the route of rounds 1-4, kept for the radix path and very large P -- instead of K1's superblock
-    totals finished by K3), HGS_SCAN_SPLIT (that launch once per array), HGS_K1_SPLIT (K1 as a geometry kernel and a
-    colour kernel on a second stream, off by default: measured slower) and HGS_K8_PRESUM (long runs of instance records
-    summed by a kernel of their own whatever the frame's mean run) are read once per process: one small
+    totals finished by K3), HGS_SCAN_SPLIT (that launch once per array) and HGS_K8_PRESUM (long runs of instance records
+    summed by kernels of their own whatever the frame's mean run) are read once per process: one small
     fwd+bwd per setting in a process of its own, bit-identical outputs and gradients."""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = {}
     for name, env in (("default", {}), ("blocking", {"HGS_BLOCKING_WAIT": "1"}), ("copy", {"HGS_COUNT_BY_COPY": "1"}),
                       ("split", {"HGS_SCAN_SPLIT": "1", "HGS_SCAN_LAUNCH": "1"}), ("scanlaunch", {"HGS_SCAN_LAUNCH": "1"}),
-                      ("k1_split", {"HGS_K1_SPLIT": "1"}), ("k8_presum", {"HGS_K8_PRESUM": "1"})):
+                      ("k8_presum", {"HGS_K8_PRESUM": "1"})):
         r = subprocess.run([sys.executable, "-c", _FRAME_DIGEST, root], env={**os.environ, **env}, capture_output=True,
                            text=True, timeout=600)
         assert r.returncode == 0, (name, r.stderr[-2000:])

@@ -87,17 +87,6 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
     mask = _tile_mask(tiles, W, H)
     gc_m, gd_m = gc * mask, gd * mask
 
-    # ---- HIP: whole frame, forward + backward ---------------------------------------------------------------------
-    hip = pa.run_hip(scene, cam, bg, gc_m, gd_m, gpu, interpolation_weights=w, num_node_kids=kids,
-                     do_depth=do_depth, debug=False)
-
-    class _O:      # what check_indices expects of an oracle output
-        pass
-    oo_int = _O()
-    oo_int.geom, oo_int.binning = geom, binning
-    idx = pa.check_indices(hip, oo_int)
-    assert all(v == 0 for v in idx.values()), f"{name}: integer mismatch over the whole frame {idx}"
-
     # ---- oracle on the sub-scene that reaches the sampled tiles ---------------------------------------------------
     sub = np.unique(np.concatenate([binning.point_list[binning.ranges[t, 0]:binning.ranges[t, 1]] for t in tiles]))
     sub_t = torch.from_numpy(sub.astype(np.int64))
@@ -117,12 +106,28 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
         a = binning.point_list[binning.ranges[t, 0]:binning.ranges[t, 1]]
         b = sub[oo.binning.point_list[oo.binning.ranges[t, 0]:oo.binning.ranges[t, 1]]]
         assert np.array_equal(a, b), f"{name}: tile {t}: sub-scene list differs from the frame's"
+    # pixels with a blend decision on a knife edge leave BOTH losses (tests/parity.py does the same for the small scenes;
+    # until round 6 this harness only left them out of the PIXEL comparison: on rows the reference's scripts trained, one
+    # such pixel -- 2e-4 off, flagged -- put 2e-5 on the gradients of the four Gaussians around it)
+    ok_loss = mask & torch.from_numpy(~oo.fragile)
+    gc_m, gd_m = gc * ok_loss, gd * ok_loss
     loss = (oo.color * gc_m.double()).sum()
     if do_depth:
         loss = loss + (oo.invdepth * gd_m.double()).sum()
     loss.backward(retain_graph=F32_ORACLE)
     og = {k: (None if v is None else v.clone()) for k, v in
           dict(means3D=m3.grad, means2D=m2.grad, opacities=op.grad, shs=sh.grad, scales=sc.grad, rotations=rot.grad).items()}
+
+    # ---- HIP: whole frame, forward + backward ---------------------------------------------------------------------
+    hip = pa.run_hip(scene, cam, bg, gc_m, gd_m, gpu, interpolation_weights=w, num_node_kids=kids,
+                     do_depth=do_depth, debug=False, grad_mask=None)
+
+    class _O:      # what check_indices expects of an oracle output
+        pass
+    oo_int = _O()
+    oo_int.geom, oo_int.binning = geom, binning
+    idx = pa.check_indices(hip, oo_int)
+    assert all(v == 0 for v in idx.values()), f"{name}: integer mismatch over the whole frame {idx}"
 
     # ---- whose error is it?  The SAME oracle with the kernels' precision split (per-Gaussian stage in float64, blend and
     # its backward in float32) against the float64 oracle: what float32 arithmetic costs on this scene whatever the
@@ -140,6 +145,9 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
                           num_node_kids=None if kids is None else kids[sub_t], tiles=tiles, dtype=torch.float32,
                           geom_dtype=torch.float64)
         okf = okd & torch.from_numpy(~of.fragile)
+        for nm, a_, b_ in (("color", of.color, oo.color), ("invdepth", of.invdepth, oo.invdepth)):
+            st = pa.err_stats(a_.detach()[:, okf & mask], b_.detach()[:, okf & mask])
+            f32[nm] = dict(mixed=st["mixed"], p999_rel=st["p999_rel"], maxrel=st["maxrel"], l2=st["l2"])
         lf = (of.color * (gc_m * okf).to(of.color.dtype)).sum()
         if do_depth:
             lf = lf + (of.invdepth * (gd_m * okf).to(of.invdepth.dtype)).sum()
@@ -156,7 +164,7 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
                      rotations=rotf.grad)
         for k in ref64:
             st = pa.err_stats(got32[k], ref64[k])
-            f32["d_" + k] = dict(mixed=st["mixed"], p999_rel=st["p999_rel"], maxrel=st["maxrel"])
+            f32["d_" + k] = dict(mixed=st["mixed"], p999_rel=st["p999_rel"], maxrel=st["maxrel"], l2=st["l2"])
 
     # ---- compare ---------------------------------------------------------------------------------------------------
     ok = mask & torch.from_numpy(~oo.fragile)
@@ -179,20 +187,37 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
                    float32_oracle_vs_float64=f32)
     _log(payload)
     print(json.dumps(payload, default=float))
+    dump = os.environ.get("HGS_PARITY_DUMP")
+    if dump:        # everything needed to look at a case offline: the sub-scene, the sample, both sides' results
+        os.makedirs(dump, exist_ok=True)
+        np.savez_compressed(
+            os.path.join(dump, "".join(c if c.isalnum() else "_" for c in name)[:80] + ".npz"),
+            sub=sub, tiles=np.asarray(tiles), W=W, H=H, viewmatrix=cam.world_view_transform.numpy(),
+            projmatrix=cam.full_proj_transform.numpy(), campos=cam.camera_center.numpy(), tanfovx=cam.tanfovx,
+            tanfovy=cam.tanfovy, bg=bg.numpy(), seed=seed, do_depth=do_depth,
+            **{"in_" + k: getattr(sub_scene, k).numpy() for k in ("means3D", "scales", "rotations", "opacities", "shs")},
+            **({} if w is None else {"w": w[sub_t].numpy(), "kids": kids[sub_t].numpy()}),
+            **{"hip_d_" + k: hip["grads"][k][sub_t].numpy() for k in og}, **{"ora_d_" + k: v.numpy() for k, v in og.items()},
+            hip_color=hip["color"][:, mask].numpy(), ora_color=oo.color.detach()[:, mask].numpy(),
+            fragile=oo.fragile[mask.numpy()], mask_idx=np.flatnonzero(mask.numpy().reshape(-1)))
     # every candidate of a pixel has its own small chance of sitting inside its band (which grows with the footprint,
-    # oracle FRAGILE_FP32_K): 1e-3 of the pixels for the short lists of the benchmark scenes, 2e-6 per list entry beyond
-    # (measured 1.8e-3 on the 64 sampled tiles of the trained-scale frame: 1 200 entries on average, footprints of
-    # hundreds of pixels)
-    assert stats["fragile_frac"] <= max(pa.FRAGILE_FRAC, 2e-6 * payload["tile_instances_sampled"] / len(tiles))
+    # oracle FRAGILE_FP32_K): 1e-3 of the pixels for the short lists of the benchmark scenes, 4e-6 per list entry beyond
+    # (measured 1.8e-3 on the 64 sampled tiles of the synthetic trained-scale frame, 2.6e-3 .. 4.8e-3 on rows the
+    # reference's scripts trained: 1 200 .. 1 700 entries on average, footprints of hundreds of pixels)
+    assert stats["fragile_frac"] <= max(pa.FRAGILE_FRAC, 4e-6 * payload["tile_instances_sampled"] / len(tiles))
     assert stats["n_contrib_mismatch"] == 0
     assert all(v == 0 for v in nonzero_outside.values()), nonzero_outside
-    # norm-wise 1e-5 on everything; element-wise: within the mixed bound, or within 1.5 x what the float32 ORACLE loses
-    # against float64 on the same tiles (a float32 sum over a tile's pixels has that error whoever evaluates it)
+    # norm-wise 1e-5 and the element-wise bound on everything -- or, per tensor and figure, within 1.5 x what the float32
+    # ORACLE loses against float64 on the same tiles (a float32 sum over a tile's pixels and a list's thousands of entries
+    # has that error whoever evaluates it: on rows the reference's scripts TRAINED the float32 oracle itself is at 2e-5
+    # norm-wise on d_scales / d_rotations, profiles/r06_trained_rows_parity.md)
     for k, v in stats.items():
         if not isinstance(v, dict):
             continue
-        allow = max(1.0, 1.5 * f32.get(k, {}).get("mixed", 0.0))
-        pa.assert_stats(name, {k: v}, mixed_tol=allow)
+        f = f32.get(k, {})
+        allow = max(1.0, 1.5 * f.get("mixed", 0.0))
+        rel = max(pa.REL_TOL, 1.5 * f.get("maxrel", 0.0), 1.5 * f.get("l2", 0.0))
+        pa.assert_stats(name, {k: v}, rel_tol=rel, mixed_tol=allow)
 
 
 def test_config2_300k_1080p(gpu):
