@@ -317,7 +317,8 @@ static int enqueue_stage2(const hgs_raster_args* a, const GeomWs& g, const BinWs
     }
     if ((rc = HGS_TIMED(ST_RANGES, s, launch_tile_ranges(b, L, L_dev, T, s, a->debug)))) return rc;
   }
-  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin, s)))) return rc;
+  // (the sorted tile-id column is introspection: the binning path only writes it for a debug forward)
+  if ((rc = HGS_TIMED(ST_SORT_DEPTH, s, launch_tile_depth_sort(*a, g, b, L, T, bin && a->debug, s)))) return rc;
   if (!bin && (rc = launch_tile_order(b, T, s, a->debug))) return rc;   // (the binning path orders inside its scatter launch)
   return HGS_TIMED(ST_RENDER_FWD, s, launch_render_fwd(*a, g, b, im, out_color, out_invdepth, s));
 }

@@ -528,8 +528,15 @@ def raster_views(call):
 
     P, L, W, H = call.P, call.L, call.W, call.H
     T = ((W + 15) // 16) * ((H + 15) // 16)
+    ranges = view(binb, v.ranges, torch.int32, T * 2).view(T, 2)
+    # the sorted tile-id column from the ranges (the kernels write it only for a debug forward: include/hgs.h)
+    counts = (ranges[:, 1] - ranges[:, 0]).long().clamp_(min=0)
+    if int(counts.sum()) == L:
+        tile_ids = torch.repeat_interleave(torch.arange(T, dtype=torch.int32, device=ranges.device), counts)
+    else:                   # (ranges that do not add up: a workspace no forward has filled -- hand back the raw column)
+        tile_ids = view(binb, v.tile_ids_sorted, torch.int32, L)
     return {
-        "tile_ids_sorted": view(binb, v.tile_ids_sorted, torch.int32, L),
+        "tile_ids_sorted": tile_ids,
         "point_list": view(binb, v.point_list, torch.int32, L),
         "ranges": view(binb, v.ranges, torch.int32, T * 2).view(T, 2),
         "tiles_touched": view(geom, v.tiles_touched, torch.int32, P),

@@ -243,7 +243,10 @@ int hgs_sh_colors_batched_bwd(const hgs_sh_color_view* views, int32_t n_views, i
  * device pointers into the workspaces after stage 2. */
 typedef struct hgs_raster_views {
   const uint32_t* tile_ids_sorted; /* [L] tile id per sorted instance; with depths[point_list[i]] this is the
-                                     (tile<<32 | depth bits) key sequence of the reference's sort */
+                                     (tile<<32 | depth bits) key sequence of the reference's sort.  Written by a forward
+                                     with args.debug != 0 (and on the radix path of tile grids above 32 768 tiles); the
+                                     binning path does not need the column -- entry i lies in [ranges[t][0], ranges[t][1])
+                                     of its tile t, which is how the Python host rebuilds it */
   const uint32_t* point_list;    /* [L] Gaussian id per sorted instance */
   const uint32_t* ranges;        /* [T,2] start,end per tile */
   const uint32_t* tiles_touched; /* [P] */

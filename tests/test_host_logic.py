@@ -302,6 +302,20 @@ def test_forward_arena_layout_against_the_real_size_functions(monkeypatch):
     assert [c[0] for c in fake.calls] == ["fwd", "stage2"] and call.L_ws == 10 ** 6 and call.p_bwd == 0
     bwd(call)                                                # a backward nobody announced allocates its scratch itself
     assert call.p_bwd != 0 and fake.calls[-1] == ("bwd", 10 ** 6)
+    # the remembered count of a shape is a DECAYING MAXIMUM (train_post.py: a cut that shrank must not make the next, larger
+    # one overflow): after the 10^6 frame, a small one, then a large one again -- no capacity miss
+    fake.calls.clear()
+    fake.L_next = 4000
+    fwd(P, False)
+    fake.L_next = int(0.9e6)
+    call = fwd(P, False)
+    assert [c[0] for c in fake.calls] == ["fwd", "fwd"] and call.L_ws >= int(0.9e6)
+    # workspace arenas come in size classes: 2^(k/4) above 1 MB, never smaller than asked, at most 19 % larger
+    for n in (1, 4097, 1 << 20, (1 << 20) + 1, 123_456_789, 700_000_001, 1 << 30, (1 << 30) + 1):
+        c = Cm.size_class(n)
+        assert c >= n and (c == n if n <= 1 << 20 else c <= 1.19 * n + 512) and Cm.size_class(c) == c, (n, c)
+    assert len({Cm.size_class(int(7e8 * 1.01 ** i)) for i in range(30)}) <= 3     # a drifting request asks for few sizes
+    assert all(t.numel() >= 1 for t in call.bufs) and call.bufs[0].numel() == Cm.size_class(call.bufs[0].numel())
     fake.calls.clear()
     fake.L_next = 0
     monkeypatch.setattr(Cm, "_last_L", {})
@@ -389,3 +403,20 @@ def test_k3_share_partition_covers_every_excess_slot_exactly_once():
                 emitted[b][s0:s1] += 1
         assert all((e == 1).all() for e in emitted), (nblk, share_max)
 
+
+
+def test_bench_gpus_flag_means_ranks():
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment launches itself under torch.distributed.run --
+    and refuses, with a non-zero exit and no JSON line, a node that shows fewer GPUs than ranks (here: none)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HGS_DP_BACKEND")}
+    if __import__("torch").cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU node: the refusal cannot be provoked")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, env=dict(env, WORLD_SIZE="4", RANK="0"), timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
