@@ -845,34 +845,60 @@ __device__ __forceinline__ uint32_t k8_nseg(uint32_t n) {        // n > kK8LongR
   if (c > 1u && n - (c - 1u) * kK8Seg < 2u) --c;
   return c;
 }
+// (at most kWorklistGrid workgroups, each over a contiguous share of the 256-Gaussian blocks: one workgroup per block had
+// 1 465 workgroups queue up on the one counter -- 20 us of a 2 us job on the trained-scale frame)
+constexpr int kWorklistGrid = 256;
 __global__ __launch_bounds__(kPreBlock) void k8_worklist_kernel(int P, const uint32_t* __restrict__ tiles_touched,
                                                                 uint2* __restrict__ work, uint32_t* __restrict__ counter) {
   __shared__ uint32_t wave_tot[kPreBlock / 64];
   __shared__ uint32_t base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int idx = blockIdx.x * kPreBlock + threadIdx.x;
-  const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
-  const uint32_t c = n > kK8LongRun ? k8_nseg(n) : 0u;
-  uint32_t inc = c;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += t;
+  const int nblk = (P + kPreBlock - 1) / kPreBlock;
+  const int per = (nblk + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int b0 = (int)blockIdx.x * per, b1 = min(b0 + per, nblk);
+  // pass 1: this workgroup's pairs, one reservation
+  uint32_t mine = 0;
+  for (int b = b0; b < b1; ++b) {
+    const int idx = b * kPreBlock + (int)threadIdx.x;
+    const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
+    mine += n > kK8LongRun ? k8_nseg(n) : 0u;
   }
-  if (lane == 63) wave_tot[wave] = inc;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mine += __shfl_xor(mine, off, 64);
+  if (lane == 0) wave_tot[wave] = mine;
   __syncthreads();
-  uint32_t before = 0, total = 0;
+  uint32_t total = 0;
 #pragma unroll
-  for (int w = 0; w < kPreBlock / 64; ++w) {
-    const uint32_t t = wave_tot[w];
-    before += w < wave ? t : 0u;
-    total += t;
-  }
+  for (int w = 0; w < kPreBlock / 64; ++w) total += wave_tot[w];
   if (total == 0u) return;                                               // (workgroup-uniform)
   if (threadIdx.x == 0) base_s = atomicAdd(counter, total);
   __syncthreads();
-  uint2* dst = work + base_s + before + inc - c;
-  for (uint32_t j = 0; j < c; ++j) dst[j] = make_uint2((uint32_t)idx, j);
+  uint32_t run = base_s;
+  // pass 2: block by block, the pairs in Gaussian order
+  for (int b = b0; b < b1; ++b) {
+    const int idx = b * kPreBlock + (int)threadIdx.x;
+    const uint32_t n = idx < P ? tiles_touched[idx] : 0u;
+    const uint32_t c = n > kK8LongRun ? k8_nseg(n) : 0u;
+    uint32_t inc = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += t;
+    }
+    __syncthreads();                                                     // (the previous block's totals have been read)
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < kPreBlock / 64; ++w) {
+      const uint32_t t = wave_tot[w];
+      before += w < wave ? t : 0u;
+      tot += t;
+    }
+    uint2* dst = work + run + before + inc - c;
+    for (uint32_t j = 0; j < c; ++j) dst[j] = make_uint2((uint32_t)idx, j);
+    run += tot;
+  }
 }
 
 constexpr int kPresumGrid = 2048;        // workgroups of four waves: every wave takes pairs w, w + 8192, ...
@@ -1816,7 +1842,8 @@ int launch_preprocess_bwd(const hgs_raster_args& a, const GeomWs& g, const float
     const bool presum = force ? force[0] == '1' : (uint64_t)L > 6ull * (uint64_t)a.P;
     if (presum) {
       HGS_HIP(hipMemsetAsync(work_counter, 0, sizeof(uint32_t), s));
-      hipLaunchKernelGGL(k8_worklist_kernel, dim3(nblk), dim3(kPreBlock), 0, s, a.P, g.tiles_touched, work, work_counter);
+      hipLaunchKernelGGL(k8_worklist_kernel, dim3(nblk < kWorklistGrid ? nblk : kWorklistGrid), dim3(kPreBlock), 0, s, a.P,
+                         g.tiles_touched, work, work_counter);
       HGS_LAUNCH_CHECK("preprocess_bwd_worklist", s, a.debug);
       const int want = (int)(((size_t)L / 64 + 3) / 4);                   // no more workgroups than a pair each could use
       hipLaunchKernelGGL(k8_presum_work_kernel, dim3(want < 1 ? 1 : (want < kPresumGrid ? want : kPresumGrid)), dim3(kPreBlock), 0,
