@@ -32,11 +32,14 @@
 //    less accurate on pixels with capped alphas and was dropped).
 //  * the ten per-(instance, quadrant) sums are reduced INSIDE THE ROW -- the natural domain of DPP: 21 bank-masked DPP adds
 //    reduce all ten values of all four rows (four different instances) at once (rounds 1-2: ~30 instructions of
-//    permlane swaps + DPP per instance) -- and added to the instance's accumulator row in LDS (ds_add_f32, ten lanes
-//    per row: an instance seen by several quadrants is combined there, in an order-independent way).  At the end of a
-//    batch lane i stores the accumulator of instance i to its EMISSION slot (40 bytes); instances the tile never
-//    reaches store zeros, so the scratch needs no zero fill by anybody.  K8 sums each Gaussian's contiguous run.  No
-//    global atomics; bit-reproducible.
+//    permlane swaps + DPP per instance) -- and STORED to the pair's own slot in LDS (round 6; rounds 3-5 added them to
+//    the instance's row with ds_add_f32, and the LDS float adds turned out to be the single most expensive thing of a
+//    visit: ~12 cycles per adding lane, profiles/r06_notes.md).  The staging lanes hand out the slots: a lane's pairs take
+//    consecutive slots behind those of the lanes below it (the four ballots' ranks are a prefix sum for free); a batch
+//    whose pairs outnumber the slots keeps its back-most instances and leaves the rest to the next one.  At the end of a
+//    batch lane i adds up instance i's slots in quadrant order and stores the record to its EMISSION slot (40 bytes);
+//    instances the tile never reaches store zeros, so the scratch needs no zero fill by anybody.  K8 sums each Gaussian's
+//    contiguous run.  No atomics anywhere; bit-reproducible.
 //  * the record of the NEXT iteration is requested before the current one is composited (two iterations per trip of the
 //    loop): a row's record address depends on a list entry that is itself in LDS, and at 4 waves per SIMD two dependent
 //    LDS round trips per iteration are not hidden by the other waves (K7 0.426 -> 0.385 ms; with the pixels' colour
@@ -107,6 +110,23 @@ __device__ __forceinline__ float lod_alpha_remap(float a, float w, float ik, flo
   const bool on = ik > 0.0f;
   if (d) *d = on ? w + (1.0f - w) * (a <= kAlphaMax ? ik * pw * __builtin_amdgcn_rcpf(base) : 0.0f) : 1.0f;
   return on ? w * a + (1.0f - w) * (1.0f - pw) : a;
+}
+
+// ---- wave priority by remaining work (K7) -------------------------------------------------------------------------------
+// The SIMD's arbiter serves the OLDEST of its waves first: of the four tiles a SIMD holds, the one dispatched first runs
+// at nearly the speed of a wave alone and the youngest gets what is left, so the waves of a launch's last round end one
+// after the other and the last of them runs alone (timeline of every wave: profiles/r06_notes.md: per SIMD 228 us with
+// four waves resident, 77 us with three, two, one).  s_setprio ranks above age: a wave drops from the top priority over
+// its last three batches (2, 1, 0), so a wave about to finish yields to the ones that still have work and the waves of
+// a SIMD end together (275 us with four resident, 24 us with fewer).  Of the rules tried -- the quarter of its batches
+// or of its list a wave has left, the last round only, by dispatch order -- this one measured best with the slot stores
+// below (K7 0.284 -> 0.270 ms on the metric frame, 0.487 -> 0.470 on heavy_1m; 0.600 -> 0.609 on trained_like_10m).  K6
+// gains nothing from any such rule (measured) and keeps the hardware's order.
+__device__ __forceinline__ void set_priority(int q) {      // q wave-uniform (the instruction takes an immediate)
+  if (q >= 3) __builtin_amdgcn_s_setprio(3);
+  else if (q == 2) __builtin_amdgcn_s_setprio(2);
+  else if (q == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
 }
 
 // number of set bits of `m` below this lane
@@ -494,14 +514,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
   constexpr int kLds = LODA ? 4 : 3;
   __shared__ float4 lrec[(kB + 1) * kLds];
-  // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
-  __shared__ uint32_t qlist[kB + 3];
-  // The batch's instance sums, one array for the upper and one for the lower quadrants: a box reaches 1, 2 or all 4
-  // quadrants, so each array receives at most TWO additions per value -- commutative, whatever order the rows' lists
-  // reach the instance in -- and the two are added in a fixed order at the end of the batch: the result does not depend
-  // on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute changes no bit)
-  constexpr int kAccRows = (kB + 1) * kInstStride;
-  __shared__ __attribute__((aligned(8))) float acc[2 * kAccRows];
+  // entry `it`: 16 bits per quadrant q = the it-th (instance, quadrant) pair of q's list: staged instance (low byte; kB:
+  // none) and the pair's slot in `acc` (high byte; kSlots: the sink of the rows that have run out of pairs); three spare
+  // entries for the look-ahead
+  __shared__ uint2 qlist[kB + 3];
+  // One slot of ten sums per (instance, quadrant) pair of the batch, each written by exactly one visit: the pairs of an
+  // instance are consecutive (quadrant order) and are added up in that order at the end of the batch, so the result does
+  // not depend on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute
+  // changes no bit).  64 instances have up to 256 pairs (a hierarchy cut's big nodes reach all four quadrants); 128 slots
+  // hold a whole batch of the benchmark scenes (88 pairs on average) and at least 32 instances of any.
+  constexpr int kSlots = 128;
+  __shared__ __attribute__((aligned(8))) float acc[(kSlots + 1) * kInstStride];
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
@@ -557,26 +580,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
     if constexpr (LODA) lrec[kB * kLds + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
   }
-  const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
-  float* const myacc = acc + (lg.q >> 1) * kAccRows;
-  // which float of the instance record this lane adds after the row reduction (see row_reduce10): only the first lane
-  // of every quad takes part
+  const uint16_t* myq = reinterpret_cast<const uint16_t*>(qlist) + lg.q;
+  // which float of the pair's slot this lane stores after the row reduction (see row_reduce10): only the first lane of
+  // every quad takes part
   const int quad = (lane >> 2) & 3;
-  const bool adder = (lane & 3) == 0;
+  const bool writer = (lane & 3) == 0;
   const int ka = ((quad & 1) << 1) | (quad >> 1);          // {0,2,1,3}[quad]
-  const int kc = 8 + (quad >> 1);                          // quads 0 / 2 add v8 / v9
-  const bool adder_c = adder && (quad & 1) == 0;
+  const int kc = 8 + (quad >> 1);                          // quads 0 / 2 store v8 / v9
+  const bool writer_c = writer && (quad & 1) == 0;
 
-  // Batches back to front.  The first batch is the one holding the last contributor; instances behind it (and every
+  // Batches back to front, from the last contributor of the tile: lane i stages instance bstart + i of the list (bstart
+  // may be negative in the front-most batch: those lanes stage nothing).  Instances behind the last contributor (and every
   // instance of a tile whose pixels blended nothing) only get their zero record written (tail loop below).
-  const int top = maxnc ? (int)((maxnc - 1) / kB) * kB : -kB;
-  for (int bstart = top; bstart >= 0; bstart -= kB) {
-    const int n = min(kB, (int)total - bstart);
+  for (int hi = (int)maxnc; hi > 0;) {
+    const int bstart = hi - kB;
+    set_priority((hi + kB - 1) / kB - 1);                   // top priority down to the last three batches: 2, 1, 0
     __syncthreads();
     QuadHit hit{false, false, false, false};
     uint32_t my_off = 0, my_rect = 0;
-    if (lane < n) {
-      const uint32_t gid = point_list[r0 + bstart + lane];
+    const bool staged_lane = bstart + lane >= 0;
+    if (staged_lane) {
+      const uint32_t gid = point_list[r0 + (uint32_t)(bstart + lane)];
       const float4* r = records + (size_t)gid * kRecVec;
       float4 a0 = r[0], a2 = r[2];
       const float4 a3 = r[3];
@@ -585,11 +609,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       const float4 a1 = r[1];
       // (behind the last contributor of every pixel of a quadrant: nothing to do there)
       const uint32_t rel = (uint32_t)(bstart + lane);
-      if (rel < maxnc) {
-        hit = quad_hit(a0.x, a0.y, a2.z, a3.w, a0.z, a0.w, a1.x, a3.z);
-        hit.q0 = hit.q0 && rel < qnc0; hit.q1 = hit.q1 && rel < qnc1;
-        hit.q2 = hit.q2 && rel < qnc2; hit.q3 = hit.q3 && rel < qnc3;
-      }
+      hit = quad_hit(a0.x, a0.y, a2.z, a3.w, a0.z, a0.w, a1.x, a3.z);
+      hit.q0 = hit.q0 && rel < qnc0; hit.q1 = hit.q1 && rel < qnc1;
+      hit.q2 = hit.q2 && rel < qnc2; hit.q3 = hit.q3 && rel < qnc3;
       my_off = offsets[gid];
       my_rect = __float_as_uint(a2.w);
       a2.z = a3.z;                               // skip threshold
@@ -601,22 +623,42 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
         lrec[lane * kLds + 3] = make_float4(lod_w[gid], kids >= 2 ? 1.0f / (float)kids : 0.0f, 0.f, 0.f);
       }
     }
-    const uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
-    const bool any_hit = hit.q0 || hit.q1 || hit.q2 || hit.q3;
+    uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
+    int c0n = __builtin_popcountll(m0), c1n = __builtin_popcountll(m1);
+    int c2n = __builtin_popcountll(m2), c3n = __builtin_popcountll(m3);
+    uint32_t k0 = rank_below(m0), k1 = rank_below(m1), k2 = rank_below(m2), k3 = rank_below(m3);
+    // The pairs of the lanes below this one = this lane's first slot.  More pairs than slots (wave-uniform, rare outside
+    // scenes of very large Gaussians): the batch keeps the longest run of its BACK-most lanes whose pairs fit (at most
+    // four per lane: never fewer than 32 lanes) and the next batch starts at the first lane left out.
+    int first = 0;                                           // first lane of the batch that is processed
+    if (c0n + c1n + c2n + c3n > kSlots) {
+      const uint32_t from_here = (uint32_t)(c0n + c1n + c2n + c3n) - (k0 + k1 + k2 + k3);      // pairs of lanes >= this one
+      const uint64_t keep = __ballot(from_here <= (uint32_t)kSlots);                           // lanes first .. 63
+      first = __builtin_ctzll(keep);
+      const uint64_t low = ~keep;
+      const int d0 = __builtin_popcountll(m0 & low), d1 = __builtin_popcountll(m1 & low);
+      const int d2 = __builtin_popcountll(m2 & low), d3 = __builtin_popcountll(m3 & low);
+      m0 &= keep; m1 &= keep; m2 &= keep; m3 &= keep;
+      c0n -= d0; c1n -= d1; c2n -= d2; c3n -= d3;
+      k0 -= (uint32_t)d0; k1 -= (uint32_t)d1; k2 -= (uint32_t)d2; k3 -= (uint32_t)d3;      // (lanes below `first`: unused)
+      const bool kept = lane >= first;
+      hit.q0 = hit.q0 && kept; hit.q1 = hit.q1 && kept; hit.q2 = hit.q2 && kept; hit.q3 = hit.q3 && kept;
+    }
+    const uint32_t slot0 = k0 + k1 + k2 + k3;
+    const uint32_t npairs = (uint32_t)hit.q0 + (uint32_t)hit.q1 + (uint32_t)hit.q2 + (uint32_t)hit.q3;
     // the quadrants' lists, BACK to front: entry = number of the mask's set bits ABOVE the instance.  (DS operations of
-    // one wave execute in order: the fill is complete before the byte stores.)
-    for (int i = lane; i < kB + 3; i += 64) qlist[i] = 0x01010101u * (uint32_t)kB;
-    uint8_t* ql8 = reinterpret_cast<uint8_t*>(qlist);
-    const int c0n = __builtin_popcountll(m0), c1n = __builtin_popcountll(m1);
-    const int c2n = __builtin_popcountll(m2), c3n = __builtin_popcountll(m3);
-    if (hit.q0) ql8[(c0n - 1 - (int)rank_below(m0)) * 4 + 0] = (uint8_t)lane;
-    if (hit.q1) ql8[(c1n - 1 - (int)rank_below(m1)) * 4 + 1] = (uint8_t)lane;
-    if (hit.q2) ql8[(c2n - 1 - (int)rank_below(m2)) * 4 + 2] = (uint8_t)lane;
-    if (hit.q3) ql8[(c3n - 1 - (int)rank_below(m3)) * 4 + 3] = (uint8_t)lane;
-    if (any_hit) {      // this instance's accumulator rows
-      f2* row = reinterpret_cast<f2*>(acc + lane * kInstStride);
-#pragma unroll
-      for (int k = 0; k < kInstStride / 2; ++k) row[k] = row[kAccRows / 2 + k] = splat(0.0f);
+    // one wave execute in order: the fill is complete before the entries' stores.)
+    {
+      const uint32_t none = (uint32_t)kB | ((uint32_t)kSlots << 8);
+      for (int i = lane; i < kB + 3; i += 64) qlist[i] = make_uint2(none * 0x00010001u, none * 0x00010001u);
+    }
+    uint16_t* ql16 = reinterpret_cast<uint16_t*>(qlist);
+    {
+      uint32_t sl = slot0;
+      if (hit.q0) { ql16[(c0n - 1 - (int)k0) * 4 + 0] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
+      if (hit.q1) { ql16[(c1n - 1 - (int)k1) * 4 + 1] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
+      if (hit.q2) { ql16[(c2n - 1 - (int)k2) * 4 + 2] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
+      if (hit.q3) { ql16[(c3n - 1 - (int)k3) * 4 + 3] = (uint16_t)((uint32_t)lane | (sl << 8)); }
     }
     const int nmax = max(max(c0n, c1n), max(c2n, c3n));
     __syncthreads();
@@ -625,13 +667,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     // outside the image: n_contrib 0) fails for every instance and is parked at y = kBig for the batch; only a batch
     // that holds some pixel's last contributor needs the per-instance compare at all (one batch in five on the benchmark;
     // a second instantiation of the loop without it measured slower: profiles/r03_optimisation_ladders.md).
-    const uint32_t bs = (uint32_t)bstart;
+    const uint32_t bs = (uint32_t)max(bstart + first, 0);    // the front-most instance this batch processes
     P0.fly = f2{P0.nc0 > bs ? flyb : kBig, P0.nc1 > bs ? flyb + 2.0f : kBig};
     P1.fly = f2{P1.nc0 > bs ? flyb + 4.0f : kBig, P1.nc1 > bs ? flyb + 6.0f : kBig};
 
     // one (instance, quadrant) pair per row of the wave
-    auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2v) {
-      const uint32_t rel = (uint32_t)bstart + j;
+    auto visit = [&](uint32_t e, const float4& q0, const float4& q1, const float4& q2v, auto&& pin_lookahead) {
+      const uint32_t j = e & 0xffu;                   // staged instance; e >> 8: the pair's slot
+      const uint32_t rel = (uint32_t)(bstart + (int)j);
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
@@ -659,12 +702,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       const float s2 = dx * s0;                        // sum X dx^2
       float ta, tb, tc;
       row_reduce10(s0, S.a1, s2, s3, S.a4, S.a0, S.s6, S.s7, S.s8, S.s9, ta, tb, tc);
-      // combine with what other quadrants found for the same instance (dummy: row kB, never read)
-      if (adder) {
-        float* row = myacc + j * kInstStride;
-        atomicAdd(row + ka, ta);
-        atomicAdd(row + 4 + ka, tb);
-        if (adder_c) atomicAdd(row + kc, tc);
+      // The look-ahead's LDS reads are made to land HERE, in front of the branch around the stores: behind a branch the
+      // compiler no longer knows how many LDS operations are in flight and waits for all of them at the next use of a
+      // look-ahead register -- the first instruction of the next visit.
+      pin_lookahead();
+      // the pair's own slot (rows that have run out of pairs: the sink)
+      if (writer) {
+        float* row = acc + (e >> 8) * kInstStride;
+        row[ka] = ta;
+        row[4 + ka] = tb;
+        if (writer_c) row[kc] = tc;
       }
     };
     {
@@ -672,33 +719,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       // before the current one is composited: every row's record address depends on a list entry that is itself in
       // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
       uint32_t jA = myq[0], jB = myq[4];
-      float4 A0 = staged<kLds>(lrec, jA)[0], A1 = staged<kLds>(lrec, jA)[1], A2 = staged<kLds>(lrec, jA)[2];
+      float4 A0 = staged<kLds>(lrec, jA & 0xffu)[0], A1 = staged<kLds>(lrec, jA & 0xffu)[1], A2 = staged<kLds>(lrec, jA & 0xffu)[2];
+      // (nothing of the loop's first trip is left pending at its head either)
+      asm volatile("" : : "v"(jB), "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), "v"(A2.x),
+                   "v"(A2.y));
       for (int it = 0; it < nmax; it += 2) {
-        const float4 B0 = staged<kLds>(lrec, jB)[0], B1 = staged<kLds>(lrec, jB)[1], B2 = staged<kLds>(lrec, jB)[2];
+        const float4 B0 = staged<kLds>(lrec, jB & 0xffu)[0], B1 = staged<kLds>(lrec, jB & 0xffu)[1], B2 = staged<kLds>(lrec, jB & 0xffu)[2];
         const uint32_t jA2 = myq[(it + 2) * 4];
-        visit(jA, A0, A1, A2);
+        visit(jA, A0, A1, A2, [&] {
+          asm volatile("" : : "v"(B0.x), "v"(B0.y), "v"(B0.z), "v"(B0.w), "v"(B1.x), "v"(B1.y), "v"(B1.z), "v"(B1.w), "v"(B2.x),
+                       "v"(B2.y), "v"(jA2));
+        });
         if (it + 1 < nmax) {
-          A0 = staged<kLds>(lrec, jA2)[0]; A1 = staged<kLds>(lrec, jA2)[1]; A2 = staged<kLds>(lrec, jA2)[2];
+          A0 = staged<kLds>(lrec, jA2 & 0xffu)[0]; A1 = staged<kLds>(lrec, jA2 & 0xffu)[1]; A2 = staged<kLds>(lrec, jA2 & 0xffu)[2];
           const uint32_t jB2 = myq[(it + 3) * 4];
-          visit(jB, B0, B1, B2);
+          visit(jB, B0, B1, B2, [&] {
+            asm volatile("" : : "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), "v"(A2.x),
+                         "v"(A2.y), "v"(jB2));
+          });
           jB = jB2;
         }
         jA = jA2;
       }
     }
     __syncthreads();
-    // lane i stores instance i's record to its emission slot: every staged instance is written, reached or not
-    if (lane < n) {
+    // lane i adds up instance i's pairs (quadrant order) and stores the record to its emission slot: every processed
+    // instance is written, reached or not
+    if (staged_lane && lane >= first) {
       const uint32_t minx = my_rect & 1023u, miny = (my_rect >> 10) & 1023u, rw = my_rect >> 20;
       const uint32_t e = my_off + ((uint32_t)tg.ty - miny) * rw + ((uint32_t)tg.tx - minx);
       f2* dst = reinterpret_cast<f2*>(inst + (size_t)e * kInstStride);
-      const f2* row = reinterpret_cast<const f2*>(acc + lane * kInstStride);
+      const f2* row = reinterpret_cast<const f2*>(acc + slot0 * kInstStride);
+      f2 sum[kInstStride / 2];
 #pragma unroll
-      for (int k = 0; k < kInstStride / 2; ++k) dst[k] = any_hit ? row[k] + row[kAccRows / 2 + k] : splat(0.0f);
+      for (int k = 0; k < kInstStride / 2; ++k) sum[k] = npairs > 0 ? row[k] : splat(0.0f);
+#pragma unroll
+      for (int t = 1; t < 4; ++t) {
+        if ((uint32_t)t < npairs) {
+#pragma unroll
+          for (int k = 0; k < kInstStride / 2; ++k) sum[k] += row[t * (kInstStride / 2) + k];
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kInstStride / 2; ++k) dst[k] = sum[k];
     }
+    hi = bstart + first;
   }
   // instances behind the last contributor of every pixel: zero records
-  for (int i = top + kB + lane; i < (int)total; i += 64) {
+  for (int i = (int)maxnc + lane; i < (int)total; i += 64) {
     const uint32_t gid = point_list[r0 + i];
     const uint32_t rb = __float_as_uint(reinterpret_cast<const float*>(records + (size_t)gid * kRecVec + 2)[3]);
     const uint32_t minx = rb & 1023u, miny = (rb >> 10) & 1023u, rw = rb >> 20;
