@@ -909,6 +909,38 @@ def test_large_footprints_take_the_long_run_route(gpu):
     pa.assert_stats("large footprints", pa.compare(hip, oo, og))
 
 
+def test_batches_with_more_pairs_than_accumulator_slots(gpu):
+    """K7 keeps the ten sums of every (instance, quadrant) pair of a 64-instance batch in a slot of its own (128 slots,
+    render.hip): Gaussians that reach all four quadrants of a tile make up to 256 pairs per batch, the batch then keeps
+    its back-most instances and the next one starts at the first instance left out.  Tiles whose lists are several
+    hundred wide Gaussians (every batch cut), mixed with small ones (cuts at varying lanes, batches that just fit), low
+    opacities so that pixels blend hundreds of entries -- pixels, indices and every gradient against the oracle."""
+    W, H = 160, 96
+    cam = synth.make_camera(W, H)
+    big = synth.make_scene(500, cam, seed=41, s_px=(30.0, 90.0))
+    small = synth.make_scene(2500, cam, seed=42, s_px=(0.5, 5.0))
+    scene = synth.Scene(torch.cat([big.means3D, small.means3D]), torch.cat([big.scales, small.scales]),
+                        torch.cat([big.rotations, small.rotations]), torch.cat([big.opacities * 0.05, small.opacities * 0.3]),
+                        torch.cat([big.shs, small.shs]), 3)
+    perm = torch.randperm(scene.P, generator=torch.Generator().manual_seed(3))
+    scene = synth.Scene(scene.means3D[perm], scene.scales[perm], scene.rotations[perm], scene.opacities[perm], scene.shs[perm], 3)
+    gc, gd = synth.upstream_grads(H, W, seed=9)
+    bg = torch.tensor([0.2, 0.1, 0.0])
+    oo, og = pa.run_oracle(scene, cam, bg, gc, gd)
+    hip = pa.run_hip(scene, cam, bg, gc, gd, gpu)
+    per_tile = (oo.binning.ranges[:, 1].astype(np.int64) - oo.binning.ranges[:, 0].astype(np.int64))
+    assert int(per_tile.min()) > 300 and int(oo.n_contrib.max()) > 256, (int(per_tile.min()), int(oo.n_contrib.max()))
+    idx = pa.check_indices(hip, oo)
+    assert all(v == 0 for v in idx.values()), idx
+    st = pa.compare(hip, oo, og)
+    _log("more pairs than slots", {"indices": idx, "stats": st})
+    # (every entry of a list has its own small chance of a knife-edge decision, and the band grows with the footprint:
+    # 4e-6 per entry in the at-scale suite, 6e-6 here where every fifth entry is 30 - 90 px wide; measured 2.5e-3)
+    assert st["fragile_frac"] <= max(pa.FRAGILE_FRAC, 6e-6 * float(per_tile.mean())), st["fragile_frac"]
+    # element-wise bound x 2, as for the other case of screen-filling Gaussians (float32 sums over thousands of pixels)
+    pa.assert_stats("more pairs than slots", st, mixed_tol=2.0)
+
+
 def test_forwards_on_two_streams_keep_their_own_superblock_totals(gpu):
     """K1 adds its workgroup sums to zeroed superblock totals the library keeps PER (device, stream) (preprocess.hip): two
     streams rendering different scenes in turns -- the speculative single-call path on both -- must each see only their own
