@@ -187,8 +187,8 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
                    float32_oracle_vs_float64=f32)
     _log(payload)
     print(json.dumps(payload, default=float))
-    dump = os.environ.get("HGS_PARITY_DUMP")
-    if dump:        # everything needed to look at a case offline: the sub-scene, the sample, both sides' results
+
+    def dump_case(dump):        # everything needed to look at a case offline: the sub-scene, the sample, both sides' results
         os.makedirs(dump, exist_ok=True)
         np.savez_compressed(
             os.path.join(dump, "".join(c if c.isalnum() else "_" for c in name)[:80] + ".npz"),
@@ -200,24 +200,38 @@ def _run_case(name, gpu, P, W, H, n_tiles, *, lod=False, do_depth=True, seed=0, 
             **{"hip_d_" + k: hip["grads"][k][sub_t].numpy() for k in og}, **{"ora_d_" + k: v.numpy() for k, v in og.items()},
             hip_color=hip["color"][:, mask].numpy(), ora_color=oo.color.detach()[:, mask].numpy(),
             fragile=oo.fragile[mask.numpy()], mask_idx=np.flatnonzero(mask.numpy().reshape(-1)))
-    # every candidate of a pixel has its own small chance of sitting inside its band (which grows with the footprint,
-    # oracle FRAGILE_FP32_K): 1e-3 of the pixels for the short lists of the benchmark scenes, 4e-6 per list entry beyond
-    # (measured 1.8e-3 on the 64 sampled tiles of the synthetic trained-scale frame, 2.6e-3 .. 4.8e-3 on rows the
-    # reference's scripts trained: 1 200 .. 1 700 entries on average, footprints of hundreds of pixels)
-    assert stats["fragile_frac"] <= max(pa.FRAGILE_FRAC, 4e-6 * payload["tile_instances_sampled"] / len(tiles))
-    assert stats["n_contrib_mismatch"] == 0
-    assert all(v == 0 for v in nonzero_outside.values()), nonzero_outside
-    # norm-wise 1e-5 and the element-wise bound on everything -- or, per tensor and figure, within 1.5 x what the float32
-    # ORACLE loses against float64 on the same tiles (a float32 sum over a tile's pixels and a list's thousands of entries
-    # has that error whoever evaluates it: on rows the reference's scripts TRAINED the float32 oracle itself is at 2e-5
-    # norm-wise on d_scales / d_rotations, profiles/r06_trained_rows_parity.md)
-    for k, v in stats.items():
-        if not isinstance(v, dict):
-            continue
-        f = f32.get(k, {})
-        allow = max(1.0, 1.5 * f.get("mixed", 0.0))
-        rel = max(pa.REL_TOL, 1.5 * f.get("maxrel", 0.0), 1.5 * f.get("l2", 0.0))
-        pa.assert_stats(name, {k: v}, rel_tol=rel, mixed_tol=allow)
+    dump = os.environ.get("HGS_PARITY_DUMP")
+    if dump and os.environ.get("HGS_PARITY_DUMP_ON_FAIL", "0") != "1":
+        dump_case(dump)
+    try:
+        # every candidate of a pixel has its own small chance of sitting inside its band (which grows with the footprint,
+        # oracle FRAGILE_FP32_K): 1e-3 of the pixels for the short lists of the benchmark scenes, 4e-6 per list entry beyond
+        # (measured 1.8e-3 on the 64 sampled tiles of the synthetic trained-scale frame, 2.6e-3 .. 4.8e-3 on rows the
+        # reference's scripts trained: 1 200 .. 1 700 entries on average, footprints of hundreds of pixels)
+        assert stats["fragile_frac"] <= max(pa.FRAGILE_FRAC, 4e-6 * payload["tile_instances_sampled"] / len(tiles))
+        assert stats["n_contrib_mismatch"] == 0
+        assert all(v == 0 for v in nonzero_outside.values()), nonzero_outside
+        # Norm-wise 1e-5 and the element-wise bound on everything -- or, per tensor, as good as the float32 ORACLE is against
+        # float64 on the same tiles (a float32 sum over a tile's pixels and a list's thousands of entries has that error
+        # whoever evaluates it: on rows the reference's scripts TRAINED the float32 oracle itself is at 2e-5 norm-wise on
+        # d_scales / d_rotations, profiles/r06_trained_rows_parity.md).  "As good as": the relative L2 error -- a mean over
+        # 1e5 .. 1e6 entries -- within 1.5 x the float32 oracle's; the two MAXIMA over those entries (max-rel, the
+        # element-wise figure) within 3 x: the largest of a million rounding errors differs by that much between two
+        # float32 evaluation orders (28 tensors of four trained-row cases, profiles/r06_trained_rows_parity.md: HIP's
+        # rel-L2 is the smaller one in 26, ratio 0.35 .. 1.05; the ratios of the maxima spread over 0.19 .. 1.65).
+        for k, v in stats.items():
+            if not isinstance(v, dict):
+                continue
+            f = f32.get(k, {})
+            assert v["l2"] <= max(pa.REL_TOL, 1.5 * f.get("l2", 0.0)), f"{name}: {k} rel-L2 error {v['l2']:.3e} (float32 oracle {f.get('l2', 0.0):.3e})"
+            assert v["maxrel"] <= max(pa.REL_TOL, 3.0 * f.get("maxrel", 0.0), 1.5 * f.get("l2", 0.0)), \
+                f"{name}: {k} max error {v['maxrel']:.3e} rel. to max (float32 oracle {f.get('maxrel', 0.0):.3e})"
+            assert v["mixed"] <= max(1.0, 3.0 * f.get("mixed", 0.0)), \
+                f"{name}: {k} element-wise error {v['mixed']:.3f} x the bound (float32 oracle {f.get('mixed', 0.0):.3f})"
+    except AssertionError:
+        if dump and os.environ.get("HGS_PARITY_DUMP_ON_FAIL", "0") == "1":
+            dump_case(dump)
+        raise
 
 
 def test_config2_300k_1080p(gpu):
