@@ -47,7 +47,7 @@ constexpr int kTile = HGS_TILE;
 constexpr int kRecFloats = 16;              // per-Gaussian 2D record, 4 x float4 (one 64-byte line)
 constexpr int kRecVec = kRecFloats / 4;
 constexpr int kInstStride = HGS_INST_GRAD_STRIDE;
-constexpr int kJacStride = 12;              // floats per row of GeomWs::shjac (9 used: three aligned float4)
+constexpr int kJacStride = 9;               // floats per row of GeomWs::shjac (36 bytes: rows are packed; 48-byte rows until round 6)
 constexpr int kPreBlock = 256;              // Gaussians per preprocess / binning workgroup
 // Tile BANDS: band x = tiles [x * per, (x + 1) * per), per = ceil(T / 8) -- the eighth of the frame that XCD x composites
 // (render.hip: block_to_tile).  The binning keeps one instance stream per band and runs the kernels that touch band x's
@@ -66,7 +66,7 @@ struct GeomWs {
   uint32_t* block_sums;    // [nblk+1] exclusive scan of per-workgroup instance counts (index order); [nblk] = L
   uint32_t* block_band;    // [kBands][nblk+1] the same per tile band: column b = exclusive scan of the workgroups' counts of
                            // instances whose tile lies in band b; [b][nblk] = the band's total
-  float* shjac;            // [P,kJacStride] d(rgb)/d(view direction): 9 values, rows = direction component, padded to 12 floats (hgs_raster_args.prepare_backward)
+  float* shjac;            // [P,kJacStride] d(rgb)/d(view direction): 9 values, rows = direction component (hgs_raster_args.prepare_backward)
   unsigned long long* scan_chain;  // [(1 + kBands) * scan_chunks(nblk)] published chunk totals of the K2 scans (K1 clears it)
   static size_t bytes(int32_t P);
   static GeomWs carve_from(void* base, int32_t P);

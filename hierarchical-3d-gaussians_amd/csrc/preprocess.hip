@@ -511,6 +511,30 @@ __device__ __forceinline__ void wave_store_rows(float4* __restrict__ dst, size_t
   __builtin_amdgcn_wave_barrier();               // (the next use of wave_lds overwrites it)
 }
 
+// The 36-byte Jacobian rows of the wave's 64 Gaussians the same way: nine words per lane at a stride of nine (odd: no
+// bank conflict), read back as the 144 consecutive 16-byte pieces they are in memory.  A wave with no visible row
+// stores nothing; otherwise all 64 rows are written (the rows of culled Gaussians are never read).
+__device__ __forceinline__ void wave_store_jac(float* __restrict__ dst, size_t row0, const float (&J)[9],
+                                               unsigned long long mask, float4* wave_lds) {
+  const int lane = threadIdx.x & 63;
+  float* wl = reinterpret_cast<float*>(wave_lds);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) wl[lane * 9 + k] = J[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float4* d4 = reinterpret_cast<float4*>(dst + row0 * kJacStride);      // row0 is a multiple of 64: 16-byte aligned
+  if (mask) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int i = j * 64 + lane;
+      if (i < 64 * 9 / 4) d4[i] = wave_lds[i];
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();               // (the next use of wave_lds overwrites it)
+}
+
 template <bool JAC, bool LOD, bool DEFER, bool H48>
                                 // JAC: also store d(rgb)/d(direction) for the backward; LOD: in-kernel LOD
                                 // interpolation; DEFER: the plain [P, M, 3] coefficient block is loaded into registers
@@ -693,12 +717,10 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       sh48_accumulate4<JAC, 8>(a.sh_degree, dx, dy, dz, sh + 24, rgb, Jt);
       sh48_accumulate4<JAC, 12>(a.sh_degree, dx, dy, dz, sh + 36, rgb, Jt);
       if constexpr (JAC) {
-        // rows of kJacStride = 12 floats: three 16-byte stores per lane, a wave writes 3 KB of whole cache lines (nine
-        // dword stores at a 36-byte stride touched every line of the block nine times)
-        float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-        jd[0] = make_float4(Jt[0], Jt[1], Jt[2], Jt[3]);
-        jd[1] = make_float4(Jt[4], Jt[5], Jt[6], Jt[7]);
-        jd[2] = make_float4(Jt[8], 0.f, 0.f, 0.f);
+        // (row-per-lane stores: the routes off the M = 16 plain layout; that one stores whole lines, below)
+        float* jd = g.shjac + (size_t)idx * kJacStride;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) jd[k] = Jt[k];
       }
       float r0 = rgb[0], r1 = rgb[1], r2 = rgb[2];
       r0 += 0.5f; r1 += 0.5f; r2 += 0.5f;
@@ -723,9 +745,7 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
                             make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y)};
       wave_store_rows<4>(reinterpret_cast<float4*>(g.records), row0, r4, vmask, wl);
       if constexpr (JAC) {
-        const float4 j4[3] = {make_float4(J[0], J[1], J[2], J[3]), make_float4(J[4], J[5], J[6], J[7]),
-                              make_float4(J[8], 0.f, 0.f, 0.f)};
-        wave_store_rows<3>(reinterpret_cast<float4*>(g.shjac), row0, j4, vmask, wl);
+        wave_store_jac(g.shjac, row0, J, vmask, wl);
       }
     }
   }
@@ -737,10 +757,9 @@ __device__ __forceinline__ void preprocess_fwd_body(const hgs_raster_args& a, co
       recp[2] = make_float4(rgb[2], rec.invz, rec.ext_x, __uint_as_float(rectbits));
       recp[3] = make_float4(rec.gx_lo, rec.gy_lo, rec.thr, rec.ext_y);
       if constexpr (H48 && JAC) {
-        float4* jd = reinterpret_cast<float4*>(g.shjac + (size_t)idx * kJacStride);
-        jd[0] = make_float4(J[0], J[1], J[2], J[3]);
-        jd[1] = make_float4(J[4], J[5], J[6], J[7]);
-        jd[2] = make_float4(J[8], 0.f, 0.f, 0.f);
+        float* jd = g.shjac + (size_t)idx * kJacStride;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) jd[k] = J[k];
       }
     }
     // zero rectangle (= zero instances) for culled Gaussians: the binning kernels derive counts from it
@@ -1379,9 +1398,10 @@ __global__ __launch_bounds__(kPreBlock) void sh_bwd_kernel(hgs_raster_args a, Ge
     const int nb = (a.sh_degree + 1) * (a.sh_degree + 1);
     float gdx = 0.f, gdy = 0.f, gdz = 0.f;
     if constexpr (JAC) {
-      const float4* j4 = reinterpret_cast<const float4*>(g.shjac + (size_t)idx * kJacStride);
-      const float4 ja = j4[0], jb = j4[1], jc = j4[2];
-      const float J[9] = {ja.x, ja.y, ja.z, ja.w, jb.x, jb.y, jb.z, jb.w, jc.x};
+      const float* jp = g.shjac + (size_t)idx * kJacStride;
+      float J[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) J[k] = jp[k];
       gdx = gr[0] * J[0] + gr[1] * J[1] + gr[2] * J[2];
       gdy = gr[0] * J[3] + gr[1] * J[4] + gr[2] * J[5];
       gdz = gr[0] * J[6] + gr[1] * J[7] + gr[2] * J[8];
