@@ -49,7 +49,7 @@ echo "== the trained-scale frame alone: kernel trace + SQ counters"
 bash scripts/r06_pmc.sh index > gpurun_out/final_trained_pmc.txt 2>&1; head -14 gpurun_out/final_trained_pmc.txt | cut -c1-150
 cp gpurun_out/r06_pmc_kernel_stats.txt gpurun_out/final_trained_kernel_stats.txt 2>/dev/null; cp gpurun_out/r06_pmc.json gpurun_out/final_trained_pmc.json 2>/dev/null
 echo "== configs[1] / [2] through the unmodified scripts at scale"
-timeout 1500 python scripts/run_config2_config3.py > gpurun_out/final_config2_config3_scripts.log 2>&1; echo "exit $?"
+HGS_PARITY_DUMP=$R/gpurun_out/parity_dump_final HGS_PARITY_DUMP_ON_FAIL=1 timeout 1500 python scripts/run_config2_config3.py > gpurun_out/final_config2_config3_scripts.log 2>&1; echo "exit $?"
 grep -E "iterations/s|wall per iteration|op stages|op counters|parity|delta|gradients|GRADIENT|allocator at" gpurun_out/final_config2_config3_scripts.log | cut -c1-330
 echo "== fuzz soak"
 timeout 200 python tests/tools/fuzz_parity.py 40 > gpurun_out/final_fuzz_parity.json 2> /dev/null; echo "fuzz exit $?"
