@@ -35,16 +35,16 @@ print(" budgeted frame_ms", c5.get("frame_ms"), "occupancy", c5.get("config", {}
 PY
 B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --schedule dropin"
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/fprof -o r -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --schedule dropin > $R/gpurun_out/final_rocprof_dropin.log 2>&1; echo "rocprof exit $?"
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/fprof -o r -- python $R/bench.py --steps 60 --warmup 30 --no-cpu-baseline --no-extras --no-stage-timing --no-secondary --no-live-pmc --schedule dropin > $R/gpurun_out/final_rocprof_dropin.log 2>&1; echo "rocprof exit $?"
 timeout 100 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d /tmp/fpmc_SQ -o pmc -- $B > /dev/null 2>&1; echo "pmc SQ exit $?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 100 rocprofv3 --pmc $c --kernel-trace -d /tmp/fpmc_$c -o pmc -- $B > /dev/null 2>&1; echo "pmc $c exit $?"
 done
 cd $R
-python scripts/rocprof_summary.py $(ls /tmp/fprof/*.db | head -1) > gpurun_out/final_kernel_stats_dropin.txt 2>/dev/null
+HGS_SKIP_CALLS=30 python scripts/rocprof_summary.py $(ls /tmp/fprof/*.db | head -1) > gpurun_out/final_kernel_stats_dropin.txt 2>/dev/null
 python scripts/pmc_summary.py SQ=$(ls /tmp/fpmc_SQ/*.db | head -1) F=$(ls /tmp/fpmc_FETCH_SIZE/*.db | head -1) W=$(ls /tmp/fpmc_WRITE_SIZE/*.db | head -1) > gpurun_out/final_pmc_summary.json 2>/dev/null; echo "pmc summary exit $?"
 rm -rf /tmp/fprof /tmp/fpmc_*
-head -16 gpurun_out/final_kernel_stats_dropin.txt | cut -c1-150
+head -17 gpurun_out/final_kernel_stats_dropin.txt | cut -c1-150
 echo "== the trained-scale frame alone: kernel trace + SQ counters"
 bash scripts/r06_pmc.sh index > gpurun_out/final_trained_pmc.txt 2>&1; head -14 gpurun_out/final_trained_pmc.txt | cut -c1-150
 cp gpurun_out/r06_pmc_kernel_stats.txt gpurun_out/final_trained_kernel_stats.txt 2>/dev/null; cp gpurun_out/r06_pmc.json gpurun_out/final_trained_pmc.json 2>/dev/null
