@@ -89,15 +89,12 @@ __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 // median into the instruction's clamp bit).  Also turns +inf / NaN inputs into 1 / 0.
 __device__ __forceinline__ float exp2_le1(float x) { return __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(x), 0.0f, 1.0f); }
 
-// the three float4 of staged instance j (a list entry: < 256): the byte offset as ONE 24-bit multiply (across the look-ahead's
-// loop-carried registers the compiler loses the value range and emits the quarter-rate 32-bit multiply)
-template <int KLDS = 3>
-__device__ __forceinline__ const float4* staged(const float4* lrec, uint32_t j) {
-  uint32_t off;
-  if constexpr (KLDS == 3) asm("v_mul_u32_u24 %0, 48, %1" : "=v"(off) : "v"(j));
-  else off = j << 6;
+// The lists' entries name a staged instance by the BYTE OFFSET of its three (four) float4 in `lrec` (no multiply per
+// visit): K6's entries are that offset, K7's carry it in their low half.
+__device__ __forceinline__ const float4* record_at(const float4* lrec, uint32_t off) {
   return reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lrec) + off);
 }
+__device__ __forceinline__ const float4* entry_record(const float4* lrec, uint32_t e) { return record_at(lrec, e & 0xffffu); }
 
 // ---- per-PIXEL LOD remap (hgs_raster_args.lod_per_pixel; oracle: raster_oracle.lod_alpha) -------------------------------
 // alpha' = w a + (1 - w) (1 - (1 - min(a, 0.99))^(1/k)) for k >= 2 sibling nodes, a itself otherwise (ik = 1 / k, 0 for
@@ -253,8 +250,10 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
   constexpr int kLds = LODA ? 4 : 3;
   __shared__ float4 lrec[(kB + 1) * kLds];
-  // entry `it`: byte q = the it-th instance of quadrant q's list (kB: none); three spare entries for the look-ahead
-  __shared__ uint32_t qlist[kB + 3];
+  // entry `it`: 16 bits per quadrant q = the it-th instance of q's list as the BYTE OFFSET of its record in `lrec`
+  // (instance kB: none); three spare entries for the look-ahead
+  __shared__ uint2 qlist[kB + 3];
+  constexpr uint32_t kRecBytes = kLds * 16;
 
   TileGeom tg;
   if (!block_to_tile(T, gx, order, tg)) return;
@@ -284,7 +283,7 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
     if constexpr (LODA) lrec[kB * kLds + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
   }
-  const uint8_t* myq = reinterpret_cast<const uint8_t*>(qlist) + lg.q;
+  const uint16_t* myq = reinterpret_cast<const uint16_t*>(qlist) + lg.q;
 
   for (uint32_t base = r0; base < r1 && alive != 0; base += kB) {
     // wave-uniform by construction; readfirstlane tells the compiler so
@@ -318,12 +317,13 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     const uint64_t m0 = __ballot(hit.q0), m1 = __ballot(hit.q1), m2 = __ballot(hit.q2), m3 = __ballot(hit.q3);
     // the quadrants' lists, front to back: entry = rank of the instance inside its quadrant's mask.  (DS operations of
     // one wave execute in order: the fill is complete before the byte stores.)
-    for (int i = lane; i < kB + 3; i += 64) qlist[i] = 0x01010101u * (uint32_t)kB;
-    uint8_t* ql8 = reinterpret_cast<uint8_t*>(qlist);
-    if (hit.q0) ql8[rank_below(m0) * 4 + 0] = (uint8_t)lane;
-    if (hit.q1) ql8[rank_below(m1) * 4 + 1] = (uint8_t)lane;
-    if (hit.q2) ql8[rank_below(m2) * 4 + 2] = (uint8_t)lane;
-    if (hit.q3) ql8[rank_below(m3) * 4 + 3] = (uint8_t)lane;
+    for (int i = lane; i < kB + 3; i += 64) qlist[i] = make_uint2(0x00010001u * (kB * kRecBytes), 0x00010001u * (kB * kRecBytes));
+    uint16_t* ql16 = reinterpret_cast<uint16_t*>(qlist);
+    const uint16_t mine = (uint16_t)((uint32_t)lane * kRecBytes);
+    if (hit.q0) ql16[rank_below(m0) * 4 + 0] = mine;
+    if (hit.q1) ql16[rank_below(m1) * 4 + 1] = mine;
+    if (hit.q2) ql16[rank_below(m2) * 4 + 2] = mine;
+    if (hit.q3) ql16[rank_below(m3) * 4 + 3] = mine;
     const int nmax = max(max(__builtin_popcountll(m0), __builtin_popcountll(m1)),
                          max(__builtin_popcountll(m2), __builtin_popcountll(m3)));
     __syncthreads();
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
     auto visit = [&](uint32_t j, const float4& q0, const float4& q1, const float4& q2) {
       float lw = 0.0f, lik = 0.0f;
       if constexpr (LODA) {
-        const float4 q3 = staged<kLds>(lrec, j)[3];
+        const float4 q3 = record_at(lrec, j)[3];
         lw = q3.x;
         lik = q3.y;
       }
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
       const float bx = q0.w * dx;
-      const uint32_t idx1 = base - r0 + j + 1;
+      // the last contributor is tracked in the entries' unit ((index + 1) x record bytes) and divided once, at the end
+      const uint32_t idx1 = (base - r0 + 1) * kRecBytes + j;
       const f2 dy0 = gyt - P0.fly;
       const f2 pw0 = fma2(dy0, fma2(splat(q1.x), dy0, splat(bx)), splat(ax));
       const f2 dy1 = gyt - P1.fly;
@@ -350,13 +351,13 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
       fwd_pair_live<DEPTH, LODA>(P1, pw1, q1, q2, idx1, lw, lik);
     };
     uint32_t jA = myq[0], jB = myq[4];
-    float4 A0 = staged<kLds>(lrec, jA)[0], A1 = staged<kLds>(lrec, jA)[1], A2 = staged<kLds>(lrec, jA)[2];
+    float4 A0 = record_at(lrec, jA)[0], A1 = record_at(lrec, jA)[1], A2 = record_at(lrec, jA)[2];
     for (int it = 0; it < nmax; it += 2) {
-      const float4 B0 = staged<kLds>(lrec, jB)[0], B1 = staged<kLds>(lrec, jB)[1], B2 = staged<kLds>(lrec, jB)[2];
+      const float4 B0 = record_at(lrec, jB)[0], B1 = record_at(lrec, jB)[1], B2 = record_at(lrec, jB)[2];
       const uint32_t jA2 = myq[(it + 2) * 4];
       visit(jA, A0, A1, A2);
       if (it + 1 < nmax) {
-        A0 = staged<kLds>(lrec, jA2)[0]; A1 = staged<kLds>(lrec, jA2)[1]; A2 = staged<kLds>(lrec, jA2)[2];
+        A0 = record_at(lrec, jA2)[0]; A1 = record_at(lrec, jA2)[1]; A2 = record_at(lrec, jA2)[2];
         const uint32_t jB2 = myq[(it + 3) * 4];
         visit(jB, B0, B1, B2);
         jB = jB2;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(64) void render_fwd_quad_kernel(
   const float cg[4] = {P0.Cg.x, P0.Cg.y, P1.Cg.x, P1.Cg.y};
   const float cb[4] = {P0.Cb.x, P0.Cb.y, P1.Cb.x, P1.Cb.y};
   const float dd[4] = {P0.Dd.x, P0.Dd.y, P1.Dd.x, P1.Dd.y};
-  const uint32_t la[4] = {P0.last0, P0.last1, P1.last0, P1.last1};
+  const uint32_t la[4] = {P0.last0 / kRecBytes, P0.last1 / kRecBytes, P1.last0 / kRecBytes, P1.last1 / kRecBytes};
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     if (inside[s]) {
@@ -514,10 +515,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
   constexpr int kLds = LODA ? 4 : 3;
   __shared__ float4 lrec[(kB + 1) * kLds];
-  // entry `it`: 16 bits per quadrant q = the it-th (instance, quadrant) pair of q's list: staged instance (low byte; kB:
-  // none) and the pair's slot in `acc` (high byte; kSlots: the sink of the rows that have run out of pairs); three spare
-  // entries for the look-ahead
-  __shared__ uint2 qlist[kB + 3];
+  // entry `it`: 32 bits per quadrant q = the it-th (instance, quadrant) pair of q's list, as the two BYTE OFFSETS the visit
+  // needs: of the staged instance's record in `lrec` (low half; instance kB: none) and of the pair's slot in `acc` (high
+  // half; slot kSlots: the sink of the rows that have run out of pairs); three spare entries for the look-ahead
+  __shared__ uint4 qlist[kB + 3];
+  constexpr uint32_t kRecBytes = kLds * 16, kSlotBytes = kInstStride * 4;
   // One slot of ten sums per (instance, quadrant) pair of the batch, each written by exactly one visit: the pairs of an
   // instance are consecutive (quadrant order) and are added up in that order at the end of the batch, so the result does
   // not depend on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     lrec[kB * kLds + 2] = make_float4(0.f, 0.f, __builtin_inff(), 0.f);
     if constexpr (LODA) lrec[kB * kLds + 3] = make_float4(1.f, 0.f, 0.f, 0.f);
   }
-  const uint16_t* myq = reinterpret_cast<const uint16_t*>(qlist) + lg.q;
+  const uint32_t* myq = reinterpret_cast<const uint32_t*>(qlist) + lg.q;
   // which float of the pair's slot this lane stores after the row reduction (see row_reduce10): only the first lane of
   // every quad takes part
   const int quad = (lane >> 2) & 3;
@@ -649,16 +651,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     // the quadrants' lists, BACK to front: entry = number of the mask's set bits ABOVE the instance.  (DS operations of
     // one wave execute in order: the fill is complete before the entries' stores.)
     {
-      const uint32_t none = (uint32_t)kB | ((uint32_t)kSlots << 8);
-      for (int i = lane; i < kB + 3; i += 64) qlist[i] = make_uint2(none * 0x00010001u, none * 0x00010001u);
+      const uint32_t none = (uint32_t)kB * kRecBytes | ((uint32_t)kSlots * kSlotBytes << 16);
+      for (int i = lane; i < kB + 3; i += 64) qlist[i] = make_uint4(none, none, none, none);
     }
-    uint16_t* ql16 = reinterpret_cast<uint16_t*>(qlist);
+    uint32_t* ql32 = reinterpret_cast<uint32_t*>(qlist);
     {
-      uint32_t sl = slot0;
-      if (hit.q0) { ql16[(c0n - 1 - (int)k0) * 4 + 0] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
-      if (hit.q1) { ql16[(c1n - 1 - (int)k1) * 4 + 1] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
-      if (hit.q2) { ql16[(c2n - 1 - (int)k2) * 4 + 2] = (uint16_t)((uint32_t)lane | (sl << 8)); ++sl; }
-      if (hit.q3) { ql16[(c3n - 1 - (int)k3) * 4 + 3] = (uint16_t)((uint32_t)lane | (sl << 8)); }
+      uint32_t en = (uint32_t)lane * kRecBytes | (slot0 * kSlotBytes << 16);
+      if (hit.q0) { ql32[(c0n - 1 - (int)k0) * 4 + 0] = en; en += kSlotBytes << 16; }
+      if (hit.q1) { ql32[(c1n - 1 - (int)k1) * 4 + 1] = en; en += kSlotBytes << 16; }
+      if (hit.q2) { ql32[(c2n - 1 - (int)k2) * 4 + 2] = en; en += kSlotBytes << 16; }
+      if (hit.q3) { ql32[(c3n - 1 - (int)k3) * 4 + 3] = en; }
     }
     const int nmax = max(max(c0n, c1n), max(c2n, c3n));
     __syncthreads();
@@ -670,11 +672,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     const uint32_t bs = (uint32_t)max(bstart + first, 0);    // the front-most instance this batch processes
     P0.fly = f2{P0.nc0 > bs ? flyb : kBig, P0.nc1 > bs ? flyb + 2.0f : kBig};
     P1.fly = f2{P1.nc0 > bs ? flyb + 4.0f : kBig, P1.nc1 > bs ? flyb + 6.0f : kBig};
+    // "rel < n_contrib" in the units of an entry's low half (staged instance j = rel - bstart as a record offset)
+    auto limit = [&](uint32_t nc) { return (uint32_t)min(max((int)nc - bstart, 0), kB + 1) * kRecBytes; };
+    const uint32_t lim0 = limit(P0.nc0), lim1 = limit(P0.nc1), lim2 = limit(P1.nc0), lim3 = limit(P1.nc1);
 
     // one (instance, quadrant) pair per row of the wave
     auto visit = [&](uint32_t e, const float4& q0, const float4& q1, const float4& q2v, auto&& pin_lookahead) {
-      const uint32_t j = e & 0xffu;                   // staged instance; e >> 8: the pair's slot
-      const uint32_t rel = (uint32_t)(bstart + (int)j);
+      const uint32_t jo = e & 0xffffu;                // the staged instance's record offset; e >> 16: the pair's slot offset
       const float gyt = q0.y;
       const float dx = q0.x - flx;
       const float ax = q0.z * dx * dx;
@@ -685,12 +689,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       const f2 pw1 = fma2(dy1, fma2(splat(q1.x), dy1, splat(bx)), splat(ax));
       // per-pixel predicate "the forward blended this Gaussian into the pixel": rel < n_contrib here, alpha >= 1/255 in
       // bwd_pair_live (exactly the forward's test; a parked pixel and the dummy instance have alpha 0).
-      const bool c0 = rel < P0.nc0, c1 = rel < P0.nc1;
-      const bool c2 = rel < P1.nc0, c3 = rel < P1.nc1;
+      const bool c0 = jo < lim0, c1 = jo < lim1;
+      const bool c2 = jo < lim2, c3 = jo < lim3;
       const f2 q2 = f2{q2v.x, q2v.y};
       float lw = 0.0f, lik = 0.0f;
       if constexpr (LODA) {
-        const float4 q3 = staged<kLds>(lrec, j)[3];
+        const float4 q3 = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(lrec) + jo)[3];
         lw = q3.x;
         lik = q3.y;
       }
@@ -708,7 +712,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       pin_lookahead();
       // the pair's own slot (rows that have run out of pairs: the sink)
       if (writer) {
-        float* row = acc + (e >> 8) * kInstStride;
+        float* row = reinterpret_cast<float*>(reinterpret_cast<char*>(acc) + (e >> 16));
         row[ka] = ta;
         row[4 + ka] = tb;
         if (writer_c) row[kc] = tc;
@@ -719,19 +723,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
       // before the current one is composited: every row's record address depends on a list entry that is itself in
       // LDS, and at 4 waves per SIMD two dependent LDS round trips per iteration are not hidden by the other waves.
       uint32_t jA = myq[0], jB = myq[4];
-      float4 A0 = staged<kLds>(lrec, jA & 0xffu)[0], A1 = staged<kLds>(lrec, jA & 0xffu)[1], A2 = staged<kLds>(lrec, jA & 0xffu)[2];
+      float4 A0 = entry_record(lrec, jA)[0], A1 = entry_record(lrec, jA)[1], A2 = entry_record(lrec, jA)[2];
       // (nothing of the loop's first trip is left pending at its head either)
       asm volatile("" : : "v"(jB), "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), "v"(A2.x),
                    "v"(A2.y));
       for (int it = 0; it < nmax; it += 2) {
-        const float4 B0 = staged<kLds>(lrec, jB & 0xffu)[0], B1 = staged<kLds>(lrec, jB & 0xffu)[1], B2 = staged<kLds>(lrec, jB & 0xffu)[2];
+        const float4 B0 = entry_record(lrec, jB)[0], B1 = entry_record(lrec, jB)[1], B2 = entry_record(lrec, jB)[2];
         const uint32_t jA2 = myq[(it + 2) * 4];
         visit(jA, A0, A1, A2, [&] {
           asm volatile("" : : "v"(B0.x), "v"(B0.y), "v"(B0.z), "v"(B0.w), "v"(B1.x), "v"(B1.y), "v"(B1.z), "v"(B1.w), "v"(B2.x),
                        "v"(B2.y), "v"(jA2));
         });
         if (it + 1 < nmax) {
-          A0 = staged<kLds>(lrec, jA2 & 0xffu)[0]; A1 = staged<kLds>(lrec, jA2 & 0xffu)[1]; A2 = staged<kLds>(lrec, jA2 & 0xffu)[2];
+          A0 = entry_record(lrec, jA2)[0]; A1 = entry_record(lrec, jA2)[1]; A2 = entry_record(lrec, jA2)[2];
           const uint32_t jB2 = myq[(it + 3) * 4];
           visit(jB, B0, B1, B2, [&] {
             asm volatile("" : : "v"(A0.x), "v"(A0.y), "v"(A0.z), "v"(A0.w), "v"(A1.x), "v"(A1.y), "v"(A1.z), "v"(A1.w), "v"(A2.x),
