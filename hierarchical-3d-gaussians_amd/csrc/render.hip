@@ -524,8 +524,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
   // instance are consecutive (quadrant order) and are added up in that order at the end of the batch, so the result does
   // not depend on what else is in the batch (tests/test_properties_gpu.py: appending Gaussians that cannot contribute
   // changes no bit).  64 instances have up to 256 pairs (a hierarchy cut's big nodes reach all four quadrants); 128 slots
-  // hold a whole batch of the benchmark scenes (88 pairs on average) and at least 32 instances of any.
-  constexpr int kSlots = 128;
+  // hold a whole batch of the benchmark scenes (88 pairs on average) and at least 31 instances of any.
+  constexpr int kSlots = LODA ? 124 : 128;      // (the per-pixel LOD build stages 64-byte records: 124 slots keep it at 10 KB)
   __shared__ __attribute__((aligned(8))) float acc[(kSlots + 1) * kInstStride];
 
   TileGeom tg;
@@ -631,7 +631,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     uint32_t k0 = rank_below(m0), k1 = rank_below(m1), k2 = rank_below(m2), k3 = rank_below(m3);
     // The pairs of the lanes below this one = this lane's first slot.  More pairs than slots (wave-uniform, rare outside
     // scenes of very large Gaussians): the batch keeps the longest run of its BACK-most lanes whose pairs fit (at most
-    // four per lane: never fewer than 32 lanes) and the next batch starts at the first lane left out.
+    // four per lane: never fewer than 31 lanes) and the next batch starts at the first lane left out.
     int first = 0;                                           // first lane of the batch that is processed
     if (c0n + c1n + c2n + c3n > kSlots) {
       const uint32_t from_here = (uint32_t)(c0n + c1n + c2n + c3n) - (k0 + k1 + k2 + k3);      // pairs of lanes >= this one
