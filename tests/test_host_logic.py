@@ -405,6 +405,67 @@ def test_k3_share_partition_covers_every_excess_slot_exactly_once():
 
 
 
+def test_k7_slot_assignment_and_batch_cut():
+    """The arithmetic of K7's staging lanes (csrc/render.hip, render_bwd_quad_kernel), restated: a lane's first slot = the
+    (instance, quadrant) pairs of the lanes below it = the sum of the four ballots' ranks; a batch with more pairs than
+    slots keeps the longest run of its BACK-most lanes whose pairs fit and the next batch starts at the first lane left
+    out.  Invariants over random hit patterns: kept lanes are a suffix that starts at lane <= 64 - slots / 4, their pairs
+    take slots 0 .. n - 1 exactly once in (lane, quadrant) order, a lane's pairs are consecutive, no pair of a kept lane is
+    dropped, and walking a whole list in such batches processes every instance exactly once."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    for slots in (128, 124):
+        for trial in range(300):
+            p = rng.choice([0.1, 0.35, 0.7, 0.95, 1.0])
+            hit = rng.random((64, 4)) < p                                   # lane i, quadrant q
+            if trial % 7 == 0:
+                hit[:] = True
+            masks = [sum(int(hit[i, q]) << i for i in range(64)) for q in range(4)]
+            counts = [bin(m).count("1") for m in masks]
+            below = lambda m, i: bin(m & ((1 << i) - 1)).count("1")
+            k = np.array([[below(masks[q], i) for q in range(4)] for i in range(64)])
+            first = 0
+            if sum(counts) > slots:
+                from_here = sum(counts) - k.sum(1)                          # pairs of lanes >= this one
+                keep = from_here <= slots
+                first = int(np.argmax(keep))
+                assert keep[first:].all() and not keep[:first].any()        # a suffix
+                assert first <= 64 - slots // 4
+                low = (1 << first) - 1
+                d = [bin(m & low).count("1") for m in masks]
+                k = k - np.array(d)[None, :]
+                assert first == 0 or hit[first - 1:].sum() > slots                # ... the LONGEST one that fits
+                hit = hit & (np.arange(64) >= first)[:, None]
+            slot0 = k.sum(1)
+            taken = []
+            for i in range(first, 64):
+                s_ = int(slot0[i])
+                for q in range(4):
+                    if hit[i, q]:
+                        taken.append(s_)
+                        s_ += 1
+            assert taken == list(range(len(taken))) and len(taken) <= slots
+            assert len(taken) == int(hit[first:].sum())
+    # a whole list: batches back to front from the last contributor, every instance in exactly one batch
+    for trial in range(50):
+        maxnc = int(rng.integers(1, 700))
+        pairs = rng.integers(0, 5, size=maxnc)                               # pairs per instance
+        seen = np.zeros(maxnc, int)
+        hi = maxnc
+        while hi > 0:
+            bstart = hi - 64
+            lanes = np.arange(64)
+            staged = bstart + lanes >= 0
+            n = np.where(staged, pairs[np.clip(bstart + lanes, 0, maxnc - 1)], 0)
+            first = 0
+            if n.sum() > 128:
+                suffix = n[::-1].cumsum()[::-1]
+                first = int(np.argmax(suffix <= 128))
+            seen[bstart + lanes[(lanes >= first) & staged]] += 1
+            hi = bstart + first
+        assert (seen == 1).all()
+
+
 def test_bench_gpus_flag_means_ranks():
     """`python bench.py --gpus N` with N > 1 and no torchrun environment launches itself under torch.distributed.run --
     and refuses, with a non-zero exit and no JSON line, a node that shows fewer GPUs than ranks (here: none)."""
