@@ -113,12 +113,14 @@ __device__ __forceinline__ float lod_alpha_remap(float a, float w, float ik, flo
 // The SIMD's arbiter serves the OLDEST of its waves first: of the four tiles a SIMD holds, the one dispatched first runs
 // at nearly the speed of a wave alone and the youngest gets what is left, so the waves of a launch's last round end one
 // after the other and the last of them runs alone (timeline of every wave: profiles/r06_notes.md: per SIMD 228 us with
-// four waves resident, 77 us with three, two, one).  s_setprio ranks above age: a wave drops from the top priority over
-// its last three batches (2, 1, 0), so a wave about to finish yields to the ones that still have work and the waves of
-// a SIMD end together (275 us with four resident, 24 us with fewer).  Of the rules tried -- the quarter of its batches
-// or of its list a wave has left, the last round only, by dispatch order -- this one measured best with the slot stores
-// below (K7 0.284 -> 0.270 ms on the metric frame, 0.487 -> 0.470 on heavy_1m; 0.600 -> 0.609 on trained_like_10m).  K6
-// gains nothing from any such rule (measured) and keeps the hardware's order.
+// four waves resident, 77 us with three, two, one).  s_setprio ranks above age: a wave of the launch's LAST ROUND (the
+// last compute units x 4 SIMDs x 4 waves workgroups) drops from the top priority over its last three batches (2, 1,
+// 0), so a wave about to finish yields to the ones that still have work and the waves of a SIMD end together (275 us
+// with four resident, 24 us with fewer); every other wave runs at the top priority throughout.  Of the rules tried --
+// the quarter of its batches or of its list a wave has left, every wave dropping over its last batches, by dispatch
+// order -- this one measured best with the slot stores below (K7 0.281 -> 0.266 ms on the metric frame, 0.477 -> 0.456
+// on heavy_1m, 0.599 -> 0.593 on trained_like_10m, where the drop in EVERY wave costs 0.617).  K6 gains nothing from
+// any such rule (measured) and keeps the hardware's order.
 __device__ __forceinline__ void set_priority(int q) {      // q wave-uniform (the instruction takes an immediate)
   if (q >= 3) __builtin_amdgcn_s_setprio(3);
   else if (q == 2) __builtin_amdgcn_s_setprio(2);
@@ -510,7 +512,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
     const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const uint32_t* __restrict__ offsets, const float* __restrict__ dL_dcolor,
     const float* __restrict__ dL_dinvdepth, float* __restrict__ inst, const uint32_t* __restrict__ order,
-    const float* __restrict__ lod_w, const int32_t* __restrict__ lod_kids) {
+    const float* __restrict__ lod_w, const int32_t* __restrict__ lod_kids, int last_round_waves) {
   constexpr int kB = kBwdBatch;
   // float4 per staged Gaussian: (gxt,gyt,A2,B2) (C2,o,r,g) (b,1/z,thr,-); LODA: + (weight, 1 / siblings or 0, -, -)
   constexpr int kLds = LODA ? 4 : 3;
@@ -594,9 +596,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(kK7Waves, kK
   // Batches back to front, from the last contributor of the tile: lane i stages instance bstart + i of the list (bstart
   // may be negative in the front-most batch: those lanes stage nothing).  Instances behind the last contributor (and every
   // instance of a tile whose pixels blended nothing) only get their zero record written (tail loop below).
+  const bool last_round = (int)blockIdx.x >= (int)gridDim.x - last_round_waves;
   for (int hi = (int)maxnc; hi > 0;) {
     const int bstart = hi - kB;
-    set_priority((hi + kB - 1) / kB - 1);                   // top priority down to the last three batches: 2, 1, 0
+    // a wave of the launch's last round: top priority down to its last three batches (2, 1, 0); the others: top priority
+    set_priority(last_round ? (hi + kB - 1) / kB - 1 : 3);
     __syncthreads();
     QuadHit hit{false, false, false, false};
     uint32_t my_off = 0, my_rect = 0;
@@ -811,7 +815,7 @@ int launch_render_bwd(const hgs_raster_args& a, const GeomWs& g, const BinWs& b,
   hipLaunchKernelGGL(kern, dim3(nblk), dim3(64), 0, s, b.ranges, b.vals_out,
                      reinterpret_cast<const float4*>(g.records), a.width, a.height, gxx, T, a.bg, im.final_T,
                      im.n_contrib, g.offsets, dL_dcolor, dL_dinvdepth, inst_grads, b.tile_order, a.interpolation_weights,
-                     a.num_node_kids);
+                     a.num_node_kids, scan_resident_workgroups() * 4 * kK7Waves);      // wave slots of the device
   HGS_LAUNCH_CHECK("render_bwd_quad", s, a.debug);
   return HGS_OK;
 }
