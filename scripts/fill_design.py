@@ -43,7 +43,7 @@ vals["C5_MS"] = f"{ex.get('config5_50m_4k_render', {}).get('ms_per_step', 0):.1f
 fm = ex.get("config5_budgeted_6gb", {}).get("frame_ms", {})
 vals["C5_P50"], vals["C5_P99"] = f"{fm.get('p50', 0):.1f}", f"{fm.get('p99', 0):.1f}"
 
-vb = b.get("valu") or {}
+vb = b.get("valu") or b["roofline"].get("valu") or {}
 vals["VALU_GUIDE"] = f"{100 * vb.get('frac_of_guide_peak', 0):.0f}"
 vals["VALU_MIX"] = f"{100 * vb.get('frac_of_mix_peak', 0):.0f}"
 vals["ALU_BUSY"] = f"{100 * vb.get('alu_busy_frac', 0):.0f}"
